@@ -1,0 +1,185 @@
+/*
+ * vjf_hip.h -- C ABI of the MI355X (gfx950) implementation of VJF's online filtering step.
+ *
+ * This is the drop-in boundary for ONE hot path of catniplab/vjf: `VJF.filter`
+ * (vjf/model.py:179-221) batched over independent trials, plus the stand-alone operators it is
+ * built from.  The reference has no FFI (it is pure Python on torch-CPU); the entry points below
+ * are what a binding for that path calls -- the Python side (vjf_amd/_native.py, ctypes) is the
+ * reference-shaped host code, see INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (never throws); vjf_last_error() gives text;
+ *   - all tensor pointers are DEVICE pointers to row-major contiguous fp32 unless stated;
+ *   - the library never allocates device memory: the caller owns `state` and `workspace`
+ *     (sizes from vjf_state_size / vjf_workspace_size) and may alias `state` as tensors;
+ *   - calls are asynchronous on the context's HIP stream and ordered on it; one context is not
+ *     re-entrant, several contexts may coexist (SURVEY.md 8b "Threading").
+ */
+#ifndef VJF_HIP_H
+#define VJF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VJF_ABI_VERSION 1
+#define VJF_MAX_HIDDEN 8
+
+/* likelihood kinds (vjf/likelihood.py:9, :43) */
+#define VJF_LIK_GAUSSIAN 0
+#define VJF_LIK_POISSON 1
+
+/* per-call flags of VJF.filter (vjf/model.py:180) */
+#define VJF_FLAG_SGD 1u      /* sgd=True    : backward, clip to +-1, SGD step (model.py:206-214) */
+#define VJF_FLAG_UPDATE 2u   /* update=True : closed-form updates (model.py:215-216, 156-177)   */
+#define VJF_FLAG_WARM_UP 4u  /* warm_up=True: no dynamics term / no RLS (model.py:148, 370)     */
+
+/* sticky status bits, read with vjf_get_status */
+#define VJF_STATUS_NONFINITE_RECON 1u   /* l_recon non-finite -> replaced by 0 (model.py:138-139) */
+#define VJF_STATUS_NONFINITE_DYN 2u     /* l_dynamics non-finite (model.py:141-142)               */
+#define VJF_STATUS_NONFINITE_ENT 4u     /* entropy non-finite (model.py:144-145)                  */
+#define VJF_STATUS_RLS_FAILED 8u        /* Cholesky pivot <= 0 in rls: RLS state left unchanged   */
+
+/* Slots of the state blob, in the reference's state_dict order followed by the plain-attribute
+ * RLS tensors and the scalars the reference keeps as Python numbers. */
+enum vjf_slot {
+    VJF_SLOT_PRIOR_MEAN = 0,   /* (xdim)            VJF.mean            model.py:66  */
+    VJF_SLOT_PRIOR_LOGVAR = 1, /* (xdim)            VJF.logvar          model.py:67  */
+    VJF_SLOT_LIK_LOGVAR = 2,   /* (1) Gaussian only likelihood.logvar   likelihood.py:16 */
+    VJF_SLOT_TR_LOGVAR = 3,    /* (1)               transition.logvar   model.py:331 */
+    VJF_SLOT_CENTROID = 4,     /* (n_rbf, xdim+udim) feature.centroid   module.py:20 */
+    VJF_SLOT_LOGWIDTH = 5,     /* (n_rbf)           feature.logwidth    module.py:21 */
+    VJF_SLOT_REC_W0 = 6,       /* +2k: (h_k, h_{k-1}) recognition.mlp.{2k}.weight  recognition.py:20-26 */
+    VJF_SLOT_REC_B0 = 7,       /* +2k: (h_k)          recognition.mlp.{2k}.bias    */
+    VJF_SLOT_MEAN_W = 22,      /* (xdim, h_L)  recognition.mean.weight    recognition.py:27 */
+    VJF_SLOT_LV_W = 23,        /* (xdim, h_L)  recognition.logvar.weight  recognition.py:28 */
+    VJF_SLOT_LV_B = 24,        /* (xdim)       recognition.logvar.bias    */
+    VJF_SLOT_DEC_W = 25,       /* (ydim, xdim) decoder.decode.weight      model.py:24 */
+    VJF_SLOT_DEC_B = 26,       /* (ydim)       decoder.decode.bias        */
+    VJF_SLOT_W_MEAN = 27,      /* (n_rbf, xdim)  velocity.w_mean       module.py:50  */
+    VJF_SLOT_W_CHOL = 28,      /* (n_rbf, n_rbf) velocity.w_chol       module.py:52  (upper: inv(L^T)) */
+    VJF_SLOT_W_PREC = 29,      /* (n_rbf, n_rbf) velocity.w_precision  module.py:53  */
+    VJF_SLOT_W_PCHOL = 30,     /* (n_rbf, n_rbf) velocity.w_pchol      module.py:54  (lower L) */
+    VJF_SLOT_SCALARS = 31,     /* (16) see vjf_scalar */
+    VJF_N_SLOTS = 32
+};
+
+/* indices into the SCALARS slot (all stored as fp32; the counters are exact integers < 2^24) */
+enum vjf_scalar {
+    VJF_SC_N_LIK = 0,   /* likelihood.n_sample  likelihood.py:17 */
+    VJF_SC_N_TR = 1,    /* transition.n_sample  model.py:332     */
+    VJF_SC_LR_LIK = 2,  /* optimizer.param_groups[0..3]['lr']  model.py:69-77 */
+    VJF_SC_LR_DEC = 3,
+    VJF_SC_LR_TR = 4,
+    VJF_SC_LR_REC = 5,
+    VJF_SC_FREEZE_DEC = 6, /* 1.0 after decoder.requires_grad_(False)  model.py:283 */
+    VJF_SC_STATUS = 7,     /* status bits as an integer-valued float */
+    VJF_N_SCALARS = 16
+};
+
+typedef struct vjf_config {
+    int32_t ydim, xdim, udim, n_rbf;
+    int32_t n_hidden;                /* 1..VJF_MAX_HIDDEN */
+    int32_t hidden[VJF_MAX_HIDDEN];  /* hidden_sizes of Recognition (recognition.py:17) */
+    int32_t likelihood;              /* VJF_LIK_* */
+    int32_t max_batch;               /* largest B (trials per call on this device) the workspace serves */
+    int32_t device;                  /* HIP device ordinal */
+} vjf_config;
+
+typedef struct vjf_ctx vjf_ctx;
+
+int vjf_abi_version(void);
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* vjf_last_error(void);
+
+/* ---- memory plan ------------------------------------------------------------------------- */
+/* Number of fp32 elements of the state blob for `cfg`. */
+int vjf_state_size(const vjf_config* cfg, int64_t* n_floats);
+/* offsets[slot], sizes[slot] (fp32 elements) for the VJF_N_SLOTS slots; unused slots have size 0. */
+int vjf_state_layout(const vjf_config* cfg, int64_t* offsets, int64_t* sizes);
+/* Bytes of scratch the context needs for cfg->max_batch trials. */
+int vjf_workspace_size(const vjf_config* cfg, int64_t* bytes);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* `state` (fp32, vjf_state_size floats) and `workspace` stay owned by the caller and must outlive
+ * the context.  `stream` is a hipStream_t (NULL = the null stream). */
+int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t workspace_bytes,
+                   void* stream, vjf_ctx** out);
+int vjf_ctx_destroy(vjf_ctx* ctx);
+int vjf_set_stream(vjf_ctx* ctx, void* stream);
+/* Synchronises the stream, returns and clears the sticky status bits. */
+int vjf_get_status(vjf_ctx* ctx, uint32_t* status);
+
+/* ---- the hot path: VJF.filter (vjf/model.py:179-221) ---------------------------------------- */
+/* One filtering step on B trials.
+ *   y (B,ydim); u (B,udim) or NULL; mu_s, lv_s (B,xdim) previous posterior, both NULL => prior
+ *   (model.py:107-108); eps_s, eps_t (B,xdim) the two reparametrisation draws in the reference's
+ *   order xs then xt (util.py:11-13); outputs mu_t, lv_t (B,xdim) = qt, loss4 (4) =
+ *   {loss, -l_recon, -l_dynamics, entropy} (model.py:152).  Equivalent to
+ *   vjf_filter_local + vjf_filter_global with B_total = B. */
+int vjf_filter_step(vjf_ctx* ctx, int32_t B, const float* y, const float* u, const float* mu_s,
+                    const float* lv_s, const float* eps_s, const float* eps_t, float* mu_t, float* lv_t,
+                    float* loss4, uint32_t flags);
+
+/* Trial-parallel half of a step: everything per trial plus this device's partial sums, written
+ * to the reduce buffer (gradient sums, RLS statistics Phi^T Phi, Phi^T dx, loss sums).  With
+ * trials sharded over devices the caller all-reduces (sum) that buffer between the two halves. */
+int vjf_filter_local(vjf_ctx* ctx, int32_t B, const float* y, const float* u, const float* mu_s,
+                     const float* lv_s, const float* eps_s, const float* eps_t, float* mu_t, float* lv_t,
+                     uint32_t flags);
+/* Device pointer / length (fp32 elements) of the reduce buffer (lives inside `workspace`). */
+int vjf_reduce_buffer(vjf_ctx* ctx, float** ptr, int64_t* n_floats);
+/* Serial half: finite guards, clip, SGD, likelihood running variance, RLS (Cholesky, solve,
+ * triangular inverse), state-noise running variance, from the (all-reduced) buffer.
+ * B_total = trials summed over all devices. */
+int vjf_filter_global(vjf_ctx* ctx, int32_t B_total, float* loss4, uint32_t flags);
+
+/* T successive steps, each fed the previous posterior: the inner loop of VJF.fit
+ * (model.py:252-261).  y (T,B,ydim); u (T,B,udim) or NULL; eps (T,2,B,xdim);
+ * mu0/lv0 (B,xdim) or NULL => prior; outputs mu, lv (T,B,xdim), loss (T,4). */
+int vjf_filter_seq(vjf_ctx* ctx, int32_t T, int32_t B, const float* y, const float* u, const float* eps,
+                   const float* mu0, const float* lv0, float* mu, float* lv, float* loss, uint32_t flags);
+
+/* ---- stand-alone operators (the reference's vjf.module / vjf.functional surface) ------------ */
+/* functional.rbf (vjf/functional.py:11-22): out(B,n) = exp(-1/2 |x-c|^2 / exp(logw)^2). */
+int vjf_rbf_forward(const float* x, const float* centroid, const float* logwidth, float* out,
+                    int32_t B, int32_t n, int32_t d, void* stream);
+/* LinearRegression.forward(sampling=False) (vjf/module.py:64-77): mean(B,dout), logvar(B,dout). */
+int vjf_blr_predict(const float* x, const float* centroid, const float* logwidth, const float* w_mean,
+                    const float* w_chol, float* mean, float* logvar, int32_t B, int32_t n, int32_t d,
+                    int32_t dout, void* stream);
+/* LinearRegression.forward(sampling=True) (vjf/module.py:70-73): out = feat @ (w_mean + w_chol @ noise). */
+int vjf_blr_sample(const float* x, const float* centroid, const float* logwidth, const float* w_mean,
+                   const float* w_chol, const float* noise, float* out, float* w_scratch, int32_t B,
+                   int32_t n, int32_t d, int32_t dout, void* stream);
+/* LinearRegression.rls (vjf/module.py:79-112), in place on w_mean/w_chol/w_precision/w_pchol.
+ * v: device scalar.  scratch: >= vjf_rls_scratch_size(B,n,dout) bytes.  status: device uint32
+ * (0 ok, VJF_STATUS_RLS_FAILED when the state was left unchanged). */
+int vjf_rls_scratch_size(int32_t B, int32_t n, int32_t dout, int64_t* bytes);
+int vjf_blr_rls(const float* x, const float* target, const float* v, float shrink, const float* centroid,
+                const float* logwidth, float* w_mean, float* w_chol, float* w_precision, float* w_pchol,
+                void* scratch, uint32_t* status, int32_t B, int32_t n, int32_t d, int32_t dout, void* stream);
+/* Recognition.forward (vjf/recognition.py:31-42). Wb: pointers to layer weights/biases on device. */
+int vjf_recognition_forward(const float* y, const float* u, const float* mu_s, const float* lv_s,
+                            const float* const* rec_W, const float* const* rec_b, const float* mean_W,
+                            const float* lv_W, const float* lv_b, float* mu_t, float* lv_t, int32_t B,
+                            int32_t ydim, int32_t udim, int32_t xdim, int32_t n_hidden,
+                            const int32_t* hidden, void* stream);
+/* functional.gaussian_loss (vjf/functional.py:32-75): lv1/lv2 NULL for point arguments;
+ * logvar: device scalar; out: device scalar. */
+int vjf_gaussian_loss(const float* m1, const float* lv1, const float* m2, const float* lv2,
+                      const float* logvar, float* out, int32_t B, int32_t d, void* stream);
+/* functional.gaussian_entropy (vjf/functional.py:25-29). */
+int vjf_gaussian_entropy(const float* lv, float* out, int32_t B, int32_t d, void* stream);
+/* PoissonLikelihood.loss (vjf/likelihood.py:51-62). */
+int vjf_poisson_loss(const float* eta, const float* target, float* out, int32_t B, int32_t d, void* stream);
+/* LinearDecoder.forward, Tensor branch (vjf/model.py:28-30): out(B,ydim) = x @ W^T + b. */
+int vjf_linear_forward(const float* x, const float* W, const float* b, float* out, int32_t B, int32_t din,
+                       int32_t dout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VJF_HIP_H */

@@ -1,0 +1,309 @@
+"""Parity of the HIP path (through the C ABI / vjf_amd host mirror) with the golden vectors captured
+from the reference and with the CPU oracle.  All tests need a real MI355X:  pytest -m gpu.
+
+Stated fp32 tolerances: posterior mean / logvar
+atol 2e-5 + rtol 2e-5, loss components rtol 2e-5, RLS weights/factors rtol 1e-3 (their
+conditioning amplifies fp32 rounding; the fp32 reference itself differs from fp64 by ~4e-6..1e-4).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vjf_oracle as orc
+from tests import goldenio as gio
+from tests.helpers import load_fixture_state, load_oracle_state, state_close
+
+pytestmark = pytest.mark.gpu
+
+POST = dict(rtol=2e-5, atol=2e-5)
+
+
+def close(a, b, **kw):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), **kw)
+
+
+@pytest.fixture(scope="module")
+def vjf():
+    import vjf_amd
+    assert torch.cuda.is_available()
+    return vjf_amd
+
+
+# ------------------------------------------------------------------ stand-alone operators vs golden
+def test_rbf_golden(vjf):
+    z = gio.load("g1_rbf")
+    for i in range(int(z["count"])):
+        out = vjf.functional.rbf(torch.tensor(z[f"x{i}"]), torch.tensor(z[f"c{i}"]), torch.tensor(z[f"w{i}"]))
+        close(out, z[f"phi{i}"], rtol=2e-5, atol=1e-7)
+
+
+def test_losses_golden(vjf):
+    z = gio.load("g2_losses")
+    G, F = vjf.Gaussian, vjf.functional
+    a, b, la, lb, lv = (torch.tensor(z[k]) for k in ("a", "b", "la", "lb", "lv"))
+    close(F.gaussian_loss(a, b, lv), z["tt"], rtol=1e-5)
+    close(F.gaussian_loss(G(a, la), G(b, lb), lv), z["gg"], rtol=1e-5)
+    close(F.gaussian_loss(G(a, la), b, lv), z["gt"], rtol=1e-5)
+    close(F.gaussian_loss(a, G(b, lb), lv), z["tg"], rtol=1e-5)
+    close(F.gaussian_entropy(G(a, la)), z["ent"], rtol=1e-5, atol=1e-6)
+    close(vjf.likelihood.PoissonLikelihood.loss(torch.tensor(z["eta"]), torch.tensor(z["tgt"])), z["poisson"], rtol=1e-5)
+
+
+def test_recognition_golden(vjf):
+    z = gio.load("g3_recognition")
+    for i in range(int(z["count"])):
+        meta = [int(v) for v in z[f"{i}.meta"]]
+        dy, dz, du, B = meta[:4]
+        hid = meta[4:]
+        r = vjf.recognition.Recognition(dy, dz, du, hid)
+        for k, lin in enumerate(r.linears()):
+            lin.weight.copy_(torch.tensor(z[f"{i}.rec_W{k}"]))
+            lin.bias.copy_(torch.tensor(z[f"{i}.rec_b{k}"]))
+        r.mean.weight.copy_(torch.tensor(z[f"{i}.mean_W"]))
+        r.logvar.weight.copy_(torch.tensor(z[f"{i}.lv_W"]))
+        r.logvar.bias.copy_(torch.tensor(z[f"{i}.lv_b"]))
+        u = torch.tensor(z[f"{i}.u"]) if du else None
+        q = r(torch.tensor(z[f"{i}.y"]), vjf.Gaussian(torch.tensor(z[f"{i}.mu"]), torch.tensor(z[f"{i}.lv"])), u)
+        close(q.mean, z[f"{i}.out_mu"], rtol=1e-5, atol=2e-6)
+        close(q.logvar, z[f"{i}.out_lv"], rtol=1e-5, atol=2e-6)
+
+
+def test_blr_predict_and_rls_golden(vjf):
+    z = gio.load("g4_blr")
+    for i in range(int(z["count"])):
+        n, d = z[f"{i}.centroid"].shape
+        dout = z[f"{i}.t1"].shape[1]
+        blr = vjf.module.LinearRegression(vjf.module.RBF(d, n), dout)
+        blr.feature.centroid.copy_(torch.tensor(z[f"{i}.centroid"]))
+        blr.feature.logwidth.copy_(torch.tensor(z[f"{i}.logwidth"]))
+        p = blr(torch.tensor(z[f"{i}.x1"]), sampling=False)
+        close(p.mean, z[f"{i}.p0_mean"], rtol=1e-5, atol=1e-6)
+        close(p.logvar, z[f"{i}.p0_logvar"], rtol=1e-5, atol=1e-5)
+        for j, (x, t) in enumerate([(z[f"{i}.x1"], z[f"{i}.t1"]), (z[f"{i}.x2"], z[f"{i}.t2"])]):
+            blr.rls(torch.tensor(x), torch.tensor(t), torch.tensor(z[f"{i}.r{j}.v"]))
+            close(blr.w_precision, z[f"{i}.r{j}.P"], rtol=1e-5, atol=1e-5)
+            close(blr.w_pchol, z[f"{i}.r{j}.w_pchol"], rtol=1e-4, atol=1e-5)
+            close(blr.w_mean, z[f"{i}.r{j}.W"], rtol=1e-3, atol=1e-5)
+            close(blr.w_chol, z[f"{i}.r{j}.w_chol"], rtol=1e-3, atol=1e-5)
+            p = blr(torch.tensor(z[f"{i}.x2"]), sampling=False)
+            close(p.mean, z[f"{i}.r{j}.mean"], rtol=1e-3, atol=1e-5)
+            close(p.logvar, z[f"{i}.r{j}.logvar"], rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ the hot path vs golden trajectories
+def _model_for(vjf, info, lr=1e-4):
+    return vjf.VJF.make_model(info["dy"], info["dz"], info["du"], info["n"], info["hidden"], likelihood=info["lik"], lr=lr)
+
+
+@pytest.mark.parametrize("name", gio.traj_names())
+def test_filter_trajectory_golden(vjf, name):
+    z, info, _ = gio.traj_case(name)
+    model = _model_for(vjf, info)
+    load_fixture_state(model, z, "s0")
+    u = z["u"] if info["du"] else None
+    q = None
+    for t in range(info["T"]):
+        ut = None if u is None else torch.tensor(u[t])
+        q, loss, *comp = model.filter(torch.tensor(z["y"][t]), ut, q, sgd=True, update=True, verbose=True,
+                                      warm_up=info["warm_up"], eps=(torch.tensor(z["eps"][t, 0]), torch.tensor(z["eps"][t, 1])))
+        close(q.mean, z["out.mu"][t], **POST)
+        close(q.logvar, z["out.lv"][t], **POST)
+        close(torch.stack([loss, *comp]), z["out.loss"][t], rtol=2e-5, atol=2e-5)
+        close(model.transition.logvar, z["out.sigma"][t], rtol=0, atol=2e-5)
+        if info["lik"] == "gaussian":
+            close(model.likelihood.logvar, z["out.rho"][t], rtol=0, atol=2e-5)
+            assert model.likelihood.n_sample == int(z["out.n_lik"][t])
+        assert model.transition.n_sample == int(z["out.n_tr"][t])
+        if f"s{t + 1}.w_mean" in z.files:
+            state_close(model, z, prefix=f"s{t + 1}", rtol=2e-4, atol=2e-5, rls_rtol=1e-3)
+    state_close(model, z, prefix="sT", rtol=2e-4, atol=2e-5, rls_rtol=2e-3)
+    assert model.status() == 0
+
+
+def test_filter_sequence_equals_steps(vjf):
+    z, info, _ = gio.traj_case("g5_gaussian_du2_wu0_f32")
+    m1, m2 = _model_for(vjf, info), _model_for(vjf, info)
+    load_fixture_state(m1, z, "s0")
+    load_fixture_state(m2, z, "s0")
+    mu, lv, loss = m1.filter_sequence(torch.tensor(z["y"]), torch.tensor(z["u"]), None, eps=torch.tensor(z["eps"]))
+    q = None
+    for t in range(info["T"]):
+        q, l, *c = m2.filter(torch.tensor(z["y"][t]), torch.tensor(z["u"][t]), q, verbose=True,
+                             eps=(torch.tensor(z["eps"][t, 0]), torch.tensor(z["eps"][t, 1])))
+        assert torch.equal(q.mean, mu[t]) and torch.equal(q.logvar, lv[t])      # same kernels, same order: bitwise
+        assert torch.equal(torch.stack([l, *c]), loss[t])
+    assert torch.equal(m1._blob, m2._blob)
+    close(mu, z["out.mu"], **POST)
+
+
+def test_seeded_drop_in(vjf):
+    """make_model under torch.manual_seed + noise drawn from the CPU generator in the reference's
+    order reproduce the reference's un-patched trajectory."""
+    z = gio.load("g5_seeded_f32")
+    torch.manual_seed(int(z["seeds"][0]))
+    model = vjf.VJF.make_model(10, 3, 2, 16, [8], likelihood="gaussian")
+    state_close(model, z, prefix="s0", rtol=0, atol=0)
+    torch.manual_seed(int(z["seeds"][1]))
+    q = None
+    for t in range(z["y"].shape[0]):
+        q, loss, *comp = model.filter(torch.tensor(z["y"][t]), torch.tensor(z["u"][t]), q, verbose=True)
+        close(q.mean, z["out.mu"][t], **POST)
+        close(q.logvar, z["out.lv"][t], **POST)
+        close(torch.stack([loss, *comp]), z["out.loss"][t], rtol=2e-5, atol=2e-5)
+    state_close(model, z, prefix="sT", rtol=2e-4, atol=2e-5, rls_rtol=1e-3)
+
+
+# ------------------------------------------------------------------ vs the oracle on fresh seeded inputs
+CASES = [
+    dict(B=1, dz=3, dy=10, du=0, n=100, hidden=[20], lik="gaussian", T=3),          # BASELINE configs[0]-like, one trial
+    dict(B=300, dz=10, dy=50, du=0, n=200, hidden=[128], lik="gaussian", T=3),      # config B dims, ragged batch
+    dict(B=77, dz=10, dy=200, du=0, n=200, hidden=[128], lik="poisson", T=2),       # config C dims
+    dict(B=50, dz=5, dy=7, du=3, n=33, hidden=[40, 24, 9], lik="gaussian", T=3),     # odd sizes, 3 layers, control input
+    dict(B=37, dz=64, dy=512, du=0, n=300, hidden=[512, 512], lik="gaussian", T=2),  # config E layer widths (n reduced)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"B{c['B']}_dz{c['dz']}_dy{c['dy']}_{c['lik']}")
+def test_filter_vs_oracle(vjf, case):
+    torch.manual_seed(5)
+    c = dict(case)
+    T = c.pop("T")
+    model = vjf.VJF.make_model(c["dy"], c["dz"], c["du"], c["n"], c["hidden"], likelihood=c["lik"], lr=1e-3)
+    if c["dz"] >= 32:      # default RBF init underflows at large dz: use initialize-style init
+        r = float(np.sqrt(c["dz"]))
+        model.transition.velocity.feature.centroid.uniform_(-r, r)
+        model.transition.velocity.feature.logwidth.fill_(float(np.log(r)))
+    s = load_oracle_state(model, np.float64)
+    g = torch.Generator().manual_seed(9)
+    B, dz = c["B"], c["dz"]
+    if c["lik"] == "poisson":
+        y = torch.poisson(torch.exp(0.5 * torch.randn(T, B, c["dy"], generator=g) - 0.5), generator=g)
+    else:
+        y = torch.randn(T, B, c["dy"], generator=g)
+    u = torch.randn(T, B, c["du"], generator=g) if c["du"] else None
+    eps = torch.randn(T, 2, B, dz, generator=g)
+    q, mu, lv = None, None, None
+    for t in range(T):
+        ut = None if u is None else u[t]
+        q, loss, *comp = model.filter(y[t], ut, q, verbose=True, eps=(eps[t, 0], eps[t, 1]))
+        o = orc.filter_step(s, y[t].numpy(), None if u is None else ut.numpy(), mu, lv, eps[t, 0].numpy(), eps[t, 1].numpy())
+        mu, lv = o.mu_t, o.lv_t
+        close(q.mean, o.mu_t, rtol=3e-5, atol=3e-5)
+        close(q.logvar, o.lv_t, rtol=3e-5, atol=3e-5)
+        close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=3e-5, atol=3e-5)
+        close(model.transition.logvar, s.tr_logvar, rtol=0, atol=3e-5)
+    state_close(model, s, rtol=3e-4, atol=3e-5, rls_rtol=3e-3)
+    assert model.status() == 0
+
+
+def test_flags_sgd_update_off(vjf):
+    """sgd=False leaves the optimised tensors untouched; update=False leaves RLS state / variances untouched."""
+    torch.manual_seed(2)
+    model = vjf.VJF.make_model(10, 3, 0, 16, [8], likelihood="gaussian", lr=1e-2)
+    g = torch.Generator().manual_seed(3)
+    y, eps = torch.randn(32, 10, generator=g), torch.randn(2, 32, 3, generator=g)
+    before = model._blob.clone()
+    q, loss = model.filter(y, eps=(eps[0], eps[1]), sgd=False, update=False)
+    assert torch.equal(before, model._blob)
+    s = load_oracle_state(model)
+    o = orc.filter_step(s, y.numpy(), None, None, None, eps[0].numpy(), eps[1].numpy(), sgd=False, update=False)
+    close(q.mean, o.mu_t, **POST)
+    close(loss, o.loss, rtol=2e-5)
+    model.filter(y, eps=(eps[0], eps[1]), sgd=True, update=False)
+    o = orc.filter_step(s, y.numpy(), None, None, None, eps[0].numpy(), eps[1].numpy(), sgd=True, update=False)
+    state_close(model, s, rtol=2e-4, atol=2e-5)
+    assert model.transition.n_sample == 0 and model.likelihood.n_sample == 0
+
+
+def test_nonfinite_loss_is_flagged(vjf):
+    torch.manual_seed(2)
+    model = vjf.VJF.make_model(10, 3, 0, 16, [8], likelihood="poisson")
+    y = torch.ones(8, 10)
+    y[0, 0] = float("nan")
+    g = torch.Generator().manual_seed(3)
+    eps = torch.randn(2, 8, 3, generator=g)
+    q, loss, recon, dyn, ent = model.filter(y, eps=(eps[0], eps[1]), verbose=True)
+    st = model.status()
+    assert st & 1, st                      # VJF_STATUS_NONFINITE_RECON
+    assert float(recon) == 0.0             # replaced by the constant 0 (model.py:138-139)
+    assert np.isfinite(float(loss))
+
+
+def test_bad_arguments(vjf):
+    model = vjf.VJF.make_model(10, 3, 2, 16, [8], likelihood="gaussian")
+    with pytest.raises(TypeError):
+        model.filter(torch.randn(4, 10))                 # u missing
+    with pytest.raises(AssertionError):
+        model.filter(torch.randn(4, 9), torch.randn(4, 2))
+
+
+# ------------------------------------------------------------------ full BASELINE size: size-independent properties
+def test_full_size_shard_sum_and_permutation(vjf):
+    """Config B (B=4096, dz=10, dy=50, n=200, h=[128]).  (1) the two-call protocol used for multi-GPU
+    -- local halves, summed reduce buffers, one global update -- gives the single-call result;
+    (2) permuting trials permutes the posterior and leaves the loss and the shared state unchanged
+    up to fp32 summation order; (3) a few steps match the fp64 oracle."""
+    import ctypes
+    from vjf_amd import _native as N
+    torch.manual_seed(0)
+    B, dz, dy, n, hid = 4096, 10, 50, 200, [128]
+    mk = lambda: vjf.VJF.make_model(dy, dz, 0, n, hid, likelihood="gaussian")     # noqa: E731
+    torch.manual_seed(0); m_full = mk()
+    torch.manual_seed(0); m_half = mk()
+    torch.manual_seed(0); m_perm = mk()
+    g = torch.Generator().manual_seed(1)
+    y = torch.randn(B, dy, generator=g).cuda()
+    eps = torch.randn(2, B, dz, generator=g).cuda()
+    s = load_oracle_state(m_full)
+    q, loss, *comp = m_full.filter(y, eps=(eps[0], eps[1]), verbose=True)
+    o = orc.filter_step(s, y.cpu().numpy(), None, None, None, eps[0].cpu().numpy(), eps[1].cpu().numpy())
+    close(q.mean, o.mu_t, rtol=3e-5, atol=3e-5)
+    close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=3e-5)
+    state_close(m_full, s, rtol=3e-4, atol=3e-5, rls_rtol=3e-3)
+    # (1) shards
+    m_half._ensure_ctx(B)
+    L, ctx = m_half._backend(), m_half._ctx
+    flags = N.FLAG_SGD | N.FLAG_UPDATE
+    h = B // 2
+    mu = torch.empty(B, dz, device="cuda"); lv = torch.empty(B, dz, device="cuda"); loss4 = torch.empty(4, device="cuda")
+    acc = None
+    for a, b in ((0, h), (h, B)):
+        N.check(L.vjf_filter_local(ctx, b - a, N.ptr(y[a:b]), None, None, None, N.ptr(eps[0][a:b]), N.ptr(eps[1][a:b]),
+                                   N.ptr(mu[a:b]), N.ptr(lv[a:b]), flags))
+        acc = m_half._reduce.clone() if acc is None else acc + m_half._reduce
+    m_half._reduce.copy_(acc)
+    N.check(L.vjf_filter_global(ctx, B, N.ptr(loss4), flags))
+    close(mu, q.mean, rtol=0, atol=0)                       # per-trial work does not depend on the shard
+    close(loss4[0], loss, rtol=2e-6)
+    close(m_half._blob, m_full._blob, rtol=2e-4, atol=2e-6)
+    # (2) permutation
+    perm = torch.randperm(B, generator=g).cuda()
+    qp, lossp = m_perm.filter(y[perm], eps=(eps[0][perm], eps[1][perm]))
+    close(qp.mean, q.mean[perm], rtol=0, atol=0)
+    close(lossp, loss, rtol=2e-6)
+    close(m_perm._blob, m_full._blob, rtol=2e-4, atol=2e-6)
+
+
+def test_fit_harness_golden(vjf):
+    """fit(): warm-up -> decoder freeze -> RBF re-initialisation -> convergence, against G8."""
+    z = gio.load("g8_fit")
+    T, B, dy, dz, du, n = [int(v) for v in z["meta"][:6]]
+    hid = [int(v) for v in z["meta"][6:]]
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)      # the fixture drew its noise in float64
+    try:
+        model = vjf.VJF.make_model(dy, dz, du, n, hid, likelihood="gaussian")
+        load_fixture_state(model, z, "s0")
+        torch.manual_seed(int(z["fit_seed"]))
+        mu, lv, epoch_loss = model.fit(torch.tensor(z["y"]), max_iter=3, rtol=10.0)
+        close(mu, z["mu"], rtol=1e-4, atol=1e-4)
+        close(lv, z["lv"], rtol=1e-4, atol=1e-4)
+        close(epoch_loss, z["epoch_loss"], rtol=1e-4)
+        state_close(model, z, prefix="sT", rtol=1e-3, atol=1e-4, rls_rtol=5e-3)
+        torch.manual_seed(int(z["fc_seed"]))
+        x, yf = model.forecast(torch.tensor(z["fc_x0"]), n_step=z["fc_wnoise"].shape[0], noise=False)
+        close(x, z["fc_x"], rtol=1e-3, atol=1e-3)
+        close(yf, z["fc_y"], rtol=1e-3, atol=1e-3)
+    finally:
+        torch.set_default_dtype(old)

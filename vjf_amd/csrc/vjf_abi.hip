@@ -1,0 +1,606 @@
+// vjf_abi.hip -- extern "C" entry points declared in include/vjf_hip.h.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/vjf_hip.h"
+#include "vjf_gram_kernel.h"
+#include "vjf_ops_kernels.h"
+#include "vjf_plan.h"
+#include "vjf_serial_kernel.h"
+#include "vjf_trial_kernel.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define VJF_HIP(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail(-100, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+int split_for(int B) {
+    int s = B / 512;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
+    jobs.clear();
+    // kind 0: lower tiles of E^T E that touch Phi columns
+    const int nt = P.ldE / VJF_TILE;
+    for (int ti = 0; ti < nt; ++ti)
+        for (int tj = 0; tj <= ti; ++tj) {
+            if (tj * VJF_TILE >= P.n) continue;                 // dx x dx tiles are not needed
+            if (ti * VJF_TILE >= P.n + P.dz) continue;          // pure padding rows
+            VjfJob j{};
+            j.kind = 0; j.xc = ti * VJF_TILE; j.yc = tj * VJF_TILE; j.xn = VJF_TILE; j.yn = VJF_TILE;
+            j.ti = ti; j.tj = tj; j.dst = 0; j.ld = 0; j.ncol_w = 0; j.dst_b = -1;
+            jobs.push_back(j);
+        }
+    // kind 1: DEL[:, xcol..+M]^T ACT[:, ycol..+K+1]  ->  weight (M,K) + bias (M)
+    auto grad = [&](int xcol, int M, int ycol, int K, int slotW, int slotB) {
+        const int offW = P.off[slotW] - P.train_off;
+        const int offB = slotB >= 0 ? P.off[slotB] - P.train_off : -1;
+        const int ncols = K + 1;
+        for (int ri = 0; ri * VJF_TILE < M; ++ri)
+            for (int ci = 0; ci * VJF_TILE < ncols; ++ci) {
+                VjfJob j{};
+                j.kind = 1;
+                j.xc = xcol + ri * VJF_TILE; j.xn = M - ri * VJF_TILE < VJF_TILE ? M - ri * VJF_TILE : VJF_TILE;
+                j.yc = ycol + ci * VJF_TILE; j.yn = ncols - ci * VJF_TILE < VJF_TILE ? ncols - ci * VJF_TILE : VJF_TILE;
+                j.dst = offW + ri * VJF_TILE * K + ci * VJF_TILE;
+                j.ld = K;
+                int nw = K - ci * VJF_TILE;
+                j.ncol_w = nw < 0 ? 0 : (nw > VJF_TILE ? VJF_TILE : nw);
+                j.dst_b = offB >= 0 ? offB + ri * VJF_TILE : -1;
+                jobs.push_back(j);
+            }
+    };
+    int prev = P.din;
+    for (int l = 0; l < P.L; ++l) {
+        grad(P.colD_da[l], P.h[l], P.colA_act[l], prev, VJF_SLOT_REC_W0 + 2 * l, VJF_SLOT_REC_B0 + 2 * l);
+        prev = P.h[l];
+    }
+    grad(P.colD_dmu, P.dz, P.colA_act[P.L], prev, VJF_SLOT_MEAN_W, -1);
+    grad(P.colD_dlv, P.dz, P.colA_act[P.L], prev, VJF_SLOT_LV_W, VJF_SLOT_LV_B);
+    grad(P.colD_dpy, P.dy, P.colA_xt, P.dz, VJF_SLOT_DEC_W, VJF_SLOT_DEC_B);
+}
+
+struct Carve {
+    size_t E, ACT, DEL, partial, slabs, red, work, jobs, total;
+};
+
+Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
+    Carve c{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = (o + bytes + 255) / 256 * 256; return at; };
+    c.E = take((size_t)max_batch * P.ldE * 4);
+    c.ACT = take((size_t)max_batch * P.ldA * 4);
+    c.DEL = take((size_t)max_batch * P.ldD * 4);
+    c.partial = take(((size_t)max_batch / 4 + 2) * RS_N * 4);
+    c.slabs = take((size_t)njobs * split_for(max_batch) * 1024 * 4);
+    c.red = take((size_t)P.red_len * 4);
+    c.work = take(vjf_serial_work_floats(P) * 4);
+    c.jobs = take((size_t)njobs * sizeof(VjfJob));
+    c.total = o;
+    return c;
+}
+
+template <class K>
+void allow_lds(K kernel, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+struct vjf_ctx {
+    vjf_config cfg;
+    VjfPlan plan;
+    float* state;
+    char* ws;
+    int64_t ws_bytes;
+    hipStream_t stream;
+    Carve cv;
+    int njobs;
+    int TB;
+    size_t lds_k1, lds_k2;
+};
+
+extern "C" {
+
+int vjf_abi_version(void) { return VJF_ABI_VERSION; }
+const char* vjf_last_error(void) { return g_err.c_str(); }
+
+int vjf_state_size(const vjf_config* cfg, int64_t* n_floats) {
+    VjfPlan P;
+    int rc = vjf_make_plan(cfg, &P);
+    if (rc) return fail(rc, "vjf_state_size: invalid config (%d)", rc);
+    if (!n_floats) return fail(-1, "vjf_state_size: null output");
+    *n_floats = P.n_state;
+    return 0;
+}
+
+int vjf_state_layout(const vjf_config* cfg, int64_t* offsets, int64_t* sizes) {
+    VjfPlan P;
+    int rc = vjf_make_plan(cfg, &P);
+    if (rc) return fail(rc, "vjf_state_layout: invalid config (%d)", rc);
+    if (!offsets || !sizes) return fail(-1, "vjf_state_layout: null output");
+    for (int s = 0; s < VJF_N_SLOTS; ++s) { offsets[s] = P.off[s]; sizes[s] = P.size[s]; }
+    return 0;
+}
+
+int vjf_workspace_size(const vjf_config* cfg, int64_t* bytes) {
+    VjfPlan P;
+    int rc = vjf_make_plan(cfg, &P);
+    if (rc) return fail(rc, "vjf_workspace_size: invalid config (%d)", rc);
+    if (!bytes) return fail(-1, "vjf_workspace_size: null output");
+    if (cfg->max_batch < 1) return fail(-7, "vjf_workspace_size: max_batch must be >= 1");
+    std::vector<VjfJob> jobs;
+    build_jobs(P, jobs);
+    *bytes = (int64_t)carve_ws(P, cfg->max_batch, (int)jobs.size()).total;
+    return 0;
+}
+
+int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t workspace_bytes, void* stream,
+                   vjf_ctx** out) {
+    if (!cfg || !state || !workspace || !out) return fail(-1, "vjf_ctx_create: null argument");
+    VjfPlan P;
+    int rc = vjf_make_plan(cfg, &P);
+    if (rc) return fail(rc, "vjf_ctx_create: invalid config (%d)", rc);
+    if (cfg->max_batch < 1) return fail(-7, "vjf_ctx_create: max_batch must be >= 1");
+    std::vector<VjfJob> jobs;
+    build_jobs(P, jobs);
+    if ((int)jobs.size() > VJF_MAX_JOBS) return fail(-8, "vjf_ctx_create: %zu Gram tiles exceed the limit", jobs.size());
+    Carve cv = carve_ws(P, cfg->max_batch, (int)jobs.size());
+    if ((int64_t)cv.total > workspace_bytes)
+        return fail(-9, "vjf_ctx_create: workspace too small (%lld < %zu bytes)", (long long)workspace_bytes, cv.total);
+    int TB = 0;
+    for (int t : {16, 8, 4})
+        if (vjf_trial_lds_floats(P, t) * 4 <= kMaxLds - 1024) { TB = t; break; }
+    if (!TB) return fail(-10, "vjf_ctx_create: per-trial working set does not fit LDS (dims too large)");
+    const size_t lds_k2 = vjf_serial_lds_floats(P) * 4;
+    if (lds_k2 > kMaxLds - 1024) return fail(-11, "vjf_ctx_create: n_rbf=%d too large for the single-workgroup RLS kernel", P.n);
+    VJF_HIP(hipSetDevice(cfg->device));
+    vjf_ctx* c = new (std::nothrow) vjf_ctx();
+    if (!c) return fail(-12, "vjf_ctx_create: out of host memory");
+    c->cfg = *cfg; c->plan = P; c->state = state; c->ws = (char*)workspace; c->ws_bytes = workspace_bytes;
+    c->stream = (hipStream_t)stream; c->cv = cv; c->njobs = (int)jobs.size(); c->TB = TB;
+    c->lds_k1 = vjf_trial_lds_floats(P, TB) * 4; c->lds_k2 = lds_k2;
+    hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs` (host) must outlive the copy
+    if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
+    allow_lds(vjf_trial_kernel<16>, kMaxLds); allow_lds(vjf_trial_kernel<8>, kMaxLds); allow_lds(vjf_trial_kernel<4>, kMaxLds);
+    allow_lds(vjf_serial_kernel, kMaxLds); allow_lds(vjf_rls_kernel, kMaxLds);
+    *out = c;
+    return 0;
+}
+
+int vjf_ctx_destroy(vjf_ctx* ctx) {
+    delete ctx;
+    return 0;
+}
+
+int vjf_set_stream(vjf_ctx* ctx, void* stream) {
+    if (!ctx) return fail(-1, "vjf_set_stream: null context");
+    ctx->stream = (hipStream_t)stream;
+    return 0;
+}
+
+int vjf_get_status(vjf_ctx* ctx, uint32_t* status) {
+    if (!ctx || !status) return fail(-1, "vjf_get_status: null argument");
+    float* p = ctx->state + ctx->plan.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
+    float v = 0.f;
+    VJF_HIP(hipMemcpyAsync(&v, p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VJF_HIP(hipMemsetAsync(p, 0, 4, ctx->stream));
+    VJF_HIP(hipStreamSynchronize(ctx->stream));
+    *status = (uint32_t)v;
+    return 0;
+}
+
+int vjf_reduce_buffer(vjf_ctx* ctx, float** ptr, int64_t* n_floats) {
+    if (!ctx || !ptr || !n_floats) return fail(-1, "vjf_reduce_buffer: null argument");
+    *ptr = (float*)(ctx->ws + ctx->cv.red);
+    *n_floats = ctx->plan.red_len;
+    return 0;
+}
+
+int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
+                     const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags) {
+    if (!c) return fail(-1, "vjf_filter_local: null context");
+    if (B < 1 || B > c->cfg.max_batch) return fail(-20, "vjf_filter_local: B=%d outside [1, max_batch=%d]", B, c->cfg.max_batch);
+    if (!y || !eps_s || !eps_t || !mu_t || !lv_t) return fail(-1, "vjf_filter_local: null tensor");
+    if (c->plan.du > 0 && !u) return fail(-21, "vjf_filter_local: u is required when udim > 0");
+    if ((mu_s == nullptr) != (lv_s == nullptr)) return fail(-22, "vjf_filter_local: mu_s and lv_s must both be given or both be null");
+    const VjfPlan& P = c->plan;
+    VjfTrialArgs a{};
+    a.y = y; a.u = u; a.mu_s = mu_s; a.lv_s = lv_s; a.eps_s = eps_s; a.eps_t = eps_t; a.mu_t = mu_t; a.lv_t = lv_t;
+    a.state = c->state;
+    a.E = (float*)(c->ws + c->cv.E); a.ACT = (float*)(c->ws + c->cv.ACT); a.DEL = (float*)(c->ws + c->cv.DEL);
+    a.partial = (float*)(c->ws + c->cv.partial);
+    a.B = B; a.flags = flags;
+    const int nblk = (B + c->TB - 1) / c->TB;
+    switch (c->TB) {
+        case 16: hipLaunchKernelGGL(vjf_trial_kernel<16>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
+        case 8: hipLaunchKernelGGL(vjf_trial_kernel<8>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
+        default: hipLaunchKernelGGL(vjf_trial_kernel<4>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
+    }
+    VJF_HIP(hipGetLastError());
+    const int nsplit = split_for(B);
+    VjfGramArgs g{};
+    g.jobs = (const VjfJob*)(c->ws + c->cv.jobs);
+    g.E = a.E; g.ACT = a.ACT; g.DEL = a.DEL;
+    g.slabs = (float*)(c->ws + c->cv.slabs);
+    g.B = B; g.nsplit = nsplit;
+    g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
+    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c->njobs, nsplit), dim3(256), 0, c->stream, P, g);
+    VJF_HIP(hipGetLastError());
+    VjfReduceArgs r{};
+    r.jobs = g.jobs; r.slabs = g.slabs; r.partial = a.partial; r.red = (float*)(c->ws + c->cv.red);
+    r.njobs = c->njobs; r.nsplit = nsplit; r.nblocks_k1 = nblk;
+    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c->njobs + 1), dim3(256), 0, c->stream, P, r);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags) {
+    if (!c) return fail(-1, "vjf_filter_global: null context");
+    if (B_total < 1) return fail(-20, "vjf_filter_global: B_total=%d", B_total);
+    VjfSerialArgs s{};
+    s.state = c->state; s.red = (const float*)(c->ws + c->cv.red); s.work = (float*)(c->ws + c->cv.work);
+    s.loss4 = loss4; s.B_total = B_total; s.flags = flags;
+    hipLaunchKernelGGL(vjf_serial_kernel, dim3(1), dim3(VJF_K2_THREADS), c->lds_k2, c->stream, c->plan, s);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+int vjf_filter_step(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
+                    const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, float* loss4, uint32_t flags) {
+    int rc = vjf_filter_local(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags);
+    if (rc) return rc;
+    return vjf_filter_global(c, B, loss4, flags);
+}
+
+int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
+                   const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
+    if (!c) return fail(-1, "vjf_filter_seq: null context");
+    if (T < 1) return fail(-23, "vjf_filter_seq: T=%d", T);
+    if (!y || !eps || !mu || !lv) return fail(-1, "vjf_filter_seq: null tensor");
+    const VjfPlan& P = c->plan;
+    const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
+    const float* ms = mu0; const float* ls = lv0;
+    for (int t = 0; t < T; ++t) {
+        int rc = vjf_filter_step(c, B, y + t * sy, u ? u + t * su : nullptr, ms, ls, eps + (size_t)t * 2 * sz,
+                                 eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, loss ? loss + 4 * (size_t)t : nullptr, flags);
+        if (rc) return rc;
+        ms = mu + t * sz; ls = lv + t * sz;
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone operators
+// ------------------------------------------------------------------------------------------------
+namespace {
+inline dim3 grid1d(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+struct VjfPredArgs {
+    const float* x; const float* c; const float* logw; const float* w_mean; const float* w_chol;
+    float* mean; float* logvar; int B, n, d, dout;
+};
+// 8 trials per workgroup: features in LDS, then Phi W (mean) and the row norm of Phi w_chol (logvar).
+__global__ __launch_bounds__(VJF_K1_THREADS) void vjf_blr_predict_kernel(VjfPredArgs A) {
+    constexpr int TB = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_phi = smem;                 // TB x n
+    float* s_red = s_phi + TB * A.n;     // 4 x TB
+    const int tid = threadIdx.x, b0 = blockIdx.x * TB, nb = min(TB, A.B - b0);
+    for (int i = tid; i < TB * A.n; i += VJF_K1_THREADS) {
+        const int b = i / A.n, k = i - b * A.n;
+        float ph = 0.f;
+        if (b < nb) {
+            float d2 = 0.f;
+            for (int j = 0; j < A.d; ++j) { const float t = A.x[(size_t)(b0 + b) * A.d + j] - A.c[(size_t)k * A.d + j]; d2 = fmaf(t, t, d2); }
+            const float w = expf(A.logw[k]);
+            ph = expf(-0.5f * d2 / (w * w));
+        }
+        s_phi[i] = ph;
+    }
+    __syncthreads();
+    if (A.mean)
+        dense_nn<TB>(A.w_mean, A.n, A.dout, s_phi, A.n, [&](int j, const float* acc) {
+#pragma unroll
+            for (int b = 0; b < TB; ++b) if (b < nb) A.mean[(size_t)(b0 + b) * A.dout + j] = acc[b];
+        });
+    if (!A.logvar) return;
+    float v2[TB];
+#pragma unroll
+    for (int b = 0; b < TB; ++b) v2[b] = 0.f;
+    dense_nn<TB>(A.w_chol, A.n, A.n, s_phi, A.n, [&](int, const float* acc) {
+#pragma unroll
+        for (int b = 0; b < TB; ++b) v2[b] = fmaf(acc[b], acc[b], v2[b]);
+    });
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+        float v = v2[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((tid & 63) == 0) s_red[(tid >> 6) * TB + b] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < nb * A.dout; i += VJF_K1_THREADS) {
+        const int b = i / A.dout;
+        A.logvar[(size_t)(b0 + b) * A.dout + (i - b * A.dout)] = logf(((s_red[b] + s_red[TB + b]) + s_red[2 * TB + b]) + s_red[3 * TB + b]);
+    }
+}
+
+struct VjfRecArgs {
+    const float* y; const float* u; const float* mu_s; const float* lv_s;
+    const float* W[VJF_MAX_HIDDEN]; const float* b[VJF_MAX_HIDDEN];
+    const float* mean_W; const float* lv_W; const float* lv_b;
+    float* mu_t; float* lv_t;
+    int B, dy, du, dz, L; int h[VJF_MAX_HIDDEN];
+};
+// Recognition.forward for 8 trials per workgroup, activations ping-pong in LDS.
+__global__ __launch_bounds__(VJF_K1_THREADS) void vjf_recognition_kernel(VjfRecArgs A, int hmax) {
+    constexpr int TB = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int din = A.dy + A.du + 2 * A.dz;
+    float* s_in = smem;                  // TB x din
+    float* s_a = s_in + TB * din;        // TB x hmax
+    float* s_b = s_a + TB * hmax;        // TB x hmax
+    const int tid = threadIdx.x, b0 = blockIdx.x * TB, nb = min(TB, A.B - b0);
+    for (int i = tid; i < TB * din; i += VJF_K1_THREADS) {
+        const int b = i / din, c = i - b * din;
+        float v = 0.f;
+        if (b < nb) {
+            const size_t g = (size_t)(b0 + b);
+            if (c < A.dy) v = A.y[g * A.dy + c];
+            else if (c < A.dy + A.du) v = A.u[g * A.du + c - A.dy];
+            else if (c < A.dy + A.du + A.dz) v = A.mu_s[g * A.dz + c - A.dy - A.du];
+            else v = A.lv_s[g * A.dz + c - A.dy - A.du - A.dz];
+        }
+        s_in[i] = v;
+    }
+    __syncthreads();
+    const float* xin = s_in; int kin = din;
+    float* cur = s_a; float* nxt = s_b;
+    for (int l = 0; l < A.L; ++l) {
+        const int hl = A.h[l];
+        const float* bias = A.b[l];
+        dense_nt<TB>(A.W[l], hl, kin, xin, kin, [&](int f, const float* acc) {
+            const float bf = bias[f];
+#pragma unroll
+            for (int b = 0; b < TB; ++b) cur[b * hl + f] = tanhf(acc[b] + bf);
+        });
+        __syncthreads();
+        xin = cur; kin = hl;
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    dense_nt<TB>(A.mean_W, A.dz, kin, xin, kin, [&](int f, const float* acc) {
+#pragma unroll
+        for (int b = 0; b < TB; ++b) if (b < nb) A.mu_t[(size_t)(b0 + b) * A.dz + f] = acc[b];
+    });
+    dense_nt<TB>(A.lv_W, A.dz, kin, xin, kin, [&](int f, const float* acc) {
+        const float bf = A.lv_b[f];
+#pragma unroll
+        for (int b = 0; b < TB; ++b) if (b < nb) A.lv_t[(size_t)(b0 + b) * A.dz + f] = acc[b] + bf;
+    });
+}
+
+// features + target rows of the stand-alone RLS:  E[b] = [Phi(x_b) | target_b | 0]
+__global__ void vjf_rls_rows_kernel(const float* x, const float* c, const float* logw, const float* target, float* E,
+                                    int B, int n, int d, int dout, int ldE) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * ldE) return;
+    const int b = (int)(i / ldE), k = (int)(i - (size_t)b * ldE);
+    float v = 0.f;
+    if (k < n) {
+        float d2 = 0.f;
+        for (int j = 0; j < d; ++j) { const float t = x[(size_t)b * d + j] - c[(size_t)k * d + j]; d2 = fmaf(t, t, d2); }
+        const float w = expf(logw[k]);
+        v = expf(-0.5f * d2 / (w * w));
+    } else if (k < n + dout) {
+        v = target[(size_t)b * dout + (k - n)];
+    }
+    E[i] = v;
+}
+
+// plan for the stand-alone RLS (only the fields the Gram kernels read for kind-0 jobs)
+void rls_plan(int n, int dout, VjfPlan* P) {
+    memset(P, 0, sizeof *P);
+    P->n = n; P->dz = dout;
+    P->ldE = (int)vjf_align(n + dout, VJF_TILE);
+    P->red_G = 0; P->red_FDX = n * n; P->red_SC = (int)vjf_align((int64_t)n * n + (int64_t)n * dout, 4);
+    P->red_len = P->red_SC + RS_N;
+}
+struct RlsCarve { size_t E, slabs, red, work, jobs, partial, total; int njobs, nsplit; };
+RlsCarve rls_carve(int B, int n, int dout, std::vector<VjfJob>* jobs_out) {
+    VjfPlan P; rls_plan(n, dout, &P);
+    std::vector<VjfJob> jobs; build_jobs(P, jobs);
+    // build_jobs also emits gradient jobs from the (zeroed) plan: keep kind 0 only
+    std::vector<VjfJob> k0;
+    for (auto& j : jobs) if (j.kind == 0) k0.push_back(j);
+    RlsCarve c{};
+    c.njobs = (int)k0.size(); c.nsplit = split_for(B);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = (o + bytes + 255) / 256 * 256; return at; };
+    c.E = take((size_t)B * P.ldE * 4);
+    c.slabs = take((size_t)c.njobs * c.nsplit * 1024 * 4);
+    c.red = take((size_t)P.red_len * 4);
+    VjfPlan Q = P;
+    c.work = take(vjf_serial_work_floats(Q) * 4);
+    c.jobs = take(k0.size() * sizeof(VjfJob));
+    c.partial = take(RS_N * 4);
+    c.total = o;
+    if (jobs_out) *jobs_out = k0;
+    return c;
+}
+}  // namespace
+
+extern "C" {
+
+int vjf_rbf_forward(const float* x, const float* centroid, const float* logwidth, float* out, int32_t B, int32_t n, int32_t d,
+                    void* stream) {
+    if (!x || !centroid || !logwidth || !out) return fail(-1, "vjf_rbf_forward: null tensor");
+    if (B < 1 || n < 1 || d < 1) return fail(-20, "vjf_rbf_forward: bad shape");
+    hipLaunchKernelGGL(vjf_rbf_kernel, grid1d((size_t)B * n), dim3(256), 0, (hipStream_t)stream, x, centroid, logwidth, out, B, n, d);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+int vjf_blr_predict(const float* x, const float* centroid, const float* logwidth, const float* w_mean, const float* w_chol,
+                    float* mean, float* logvar, int32_t B, int32_t n, int32_t d, int32_t dout, void* stream) {
+    if (!x || !centroid || !logwidth || !w_mean || !w_chol) return fail(-1, "vjf_blr_predict: null tensor");
+    if (B < 1 || n < 1 || d < 1 || dout < 1) return fail(-20, "vjf_blr_predict: bad shape");
+    const size_t lds = (size_t)(8 * n + 32) * 4;
+    if (lds > kMaxLds - 1024) return fail(-11, "vjf_blr_predict: n=%d too large", n);
+    allow_lds(vjf_blr_predict_kernel, kMaxLds);
+    VjfPredArgs a{x, centroid, logwidth, w_mean, w_chol, mean, logvar, B, n, d, dout};
+    hipLaunchKernelGGL(vjf_blr_predict_kernel, dim3((B + 7) / 8), dim3(VJF_K1_THREADS), lds, (hipStream_t)stream, a);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+int vjf_blr_sample(const float* x, const float* centroid, const float* logwidth, const float* w_mean, const float* w_chol,
+                   const float* noise, float* out, float* w_scratch, int32_t B, int32_t n, int32_t d, int32_t dout, void* stream) {
+    if (!x || !centroid || !logwidth || !w_mean || !w_chol || !noise || !out || !w_scratch) return fail(-1, "vjf_blr_sample: null tensor");
+    if (B < 1 || n < 1 || d < 1 || dout < 1) return fail(-20, "vjf_blr_sample: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    // w = w_mean + w_chol @ noise   (module.py:71)
+    hipLaunchKernelGGL(vjf_matmul_nn_kernel, grid1d((size_t)n * dout), dim3(256), 0, s, w_chol, noise, w_mean, w_scratch, n, n, dout);
+    VJF_HIP(hipGetLastError());
+    const size_t lds = (size_t)(8 * n + 32) * 4;
+    if (lds > kMaxLds - 1024) return fail(-11, "vjf_blr_sample: n=%d too large", n);
+    allow_lds(vjf_blr_predict_kernel, kMaxLds);
+    VjfPredArgs a{x, centroid, logwidth, w_scratch, w_chol, out, nullptr, B, n, d, dout};
+    hipLaunchKernelGGL(vjf_blr_predict_kernel, dim3((B + 7) / 8), dim3(VJF_K1_THREADS), lds, s, a);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+int vjf_rls_scratch_size(int32_t B, int32_t n, int32_t dout, int64_t* bytes) {
+    if (!bytes || B < 1 || n < 1 || dout < 1) return fail(-20, "vjf_rls_scratch_size: bad argument");
+    *bytes = (int64_t)rls_carve(B, n, dout, nullptr).total;
+    return 0;
+}
+
+int vjf_blr_rls(const float* x, const float* target, const float* v, float shrink, const float* centroid, const float* logwidth,
+                float* w_mean, float* w_chol, float* w_precision, float* w_pchol, void* scratch, uint32_t* status, int32_t B,
+                int32_t n, int32_t d, int32_t dout, void* stream) {
+    if (!x || !target || !v || !centroid || !logwidth || !w_mean || !w_chol || !w_precision || !w_pchol || !scratch)
+        return fail(-1, "vjf_blr_rls: null tensor");
+    if (B < 1 || n < 1 || d < 1 || dout < 1) return fail(-20, "vjf_blr_rls: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    VjfPlan P; rls_plan(n, dout, &P);
+    const size_t lds = vjf_serial_lds_floats(P) * 4;
+    if (lds > kMaxLds - 1024) return fail(-11, "vjf_blr_rls: n=%d too large for the single-workgroup RLS kernel", n);
+    std::vector<VjfJob> jobs;
+    RlsCarve c = rls_carve(B, n, dout, &jobs);
+    char* ws = (char*)scratch;
+    VJF_HIP(hipMemcpyAsync(ws + c.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, s));
+    VJF_HIP(hipStreamSynchronize(s));     // host vector goes out of scope
+    VJF_HIP(hipMemsetAsync(ws + c.partial, 0, RS_N * 4, s));
+    float* E = (float*)(ws + c.E);
+    hipLaunchKernelGGL(vjf_rls_rows_kernel, grid1d((size_t)B * P.ldE), dim3(256), 0, s, x, centroid, logwidth, target, E, B, n, d, dout, P.ldE);
+    VJF_HIP(hipGetLastError());
+    VjfGramArgs g{};
+    g.jobs = (const VjfJob*)(ws + c.jobs); g.E = E; g.ACT = E; g.DEL = E; g.slabs = (float*)(ws + c.slabs);
+    g.B = B; g.nsplit = c.nsplit; g.rows_per_split = ((B + c.nsplit - 1) / c.nsplit + 7) / 8 * 8;
+    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c.njobs, c.nsplit), dim3(256), 0, s, P, g);
+    VJF_HIP(hipGetLastError());
+    VjfReduceArgs r{};
+    r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(ws + c.partial); r.red = (float*)(ws + c.red);
+    r.njobs = c.njobs; r.nsplit = c.nsplit; r.nblocks_k1 = 1;
+    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c.njobs + 1), dim3(256), 0, s, P, r);
+    VJF_HIP(hipGetLastError());
+    allow_lds(vjf_rls_kernel, kMaxLds);
+    VjfRlsArgs a{};
+    a.Pm = w_precision; a.Wm = w_mean; a.Wc = w_chol; a.Lm = w_pchol;
+    a.G = r.red + P.red_G; a.FDX = r.red + P.red_FDX; a.v = v; a.work = (float*)(ws + c.work); a.status = status;
+    a.n = n; a.dout = dout; a.shrink = shrink;
+    hipLaunchKernelGGL(vjf_rls_kernel, dim3(1), dim3(VJF_K2_THREADS), lds, s, a);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+int vjf_recognition_forward(const float* y, const float* u, const float* mu_s, const float* lv_s, const float* const* rec_W,
+                            const float* const* rec_b, const float* mean_W, const float* lv_W, const float* lv_b, float* mu_t,
+                            float* lv_t, int32_t B, int32_t ydim, int32_t udim, int32_t xdim, int32_t n_hidden,
+                            const int32_t* hidden, void* stream) {
+    if (!y || !mu_s || !lv_s || !rec_W || !rec_b || !mean_W || !lv_W || !lv_b || !mu_t || !lv_t || !hidden)
+        return fail(-1, "vjf_recognition_forward: null tensor");
+    if (udim > 0 && !u) return fail(-21, "vjf_recognition_forward: u is required when udim > 0");
+    if (n_hidden < 1 || n_hidden > VJF_MAX_HIDDEN) return fail(-3, "vjf_recognition_forward: n_hidden=%d", n_hidden);
+    if (B < 1) return fail(-20, "vjf_recognition_forward: bad shape");
+    VjfRecArgs a{};
+    a.y = y; a.u = u; a.mu_s = mu_s; a.lv_s = lv_s; a.mean_W = mean_W; a.lv_W = lv_W; a.lv_b = lv_b; a.mu_t = mu_t; a.lv_t = lv_t;
+    a.B = B; a.dy = ydim; a.du = udim; a.dz = xdim; a.L = n_hidden;
+    int hmax = 0;
+    for (int l = 0; l < n_hidden; ++l) { a.W[l] = rec_W[l]; a.b[l] = rec_b[l]; a.h[l] = hidden[l]; if (hidden[l] > hmax) hmax = hidden[l]; }
+    const size_t lds = (size_t)8 * (ydim + udim + 2 * xdim + 2 * hmax) * 4;
+    if (lds > kMaxLds - 1024) return fail(-10, "vjf_recognition_forward: layer widths do not fit LDS");
+    allow_lds(vjf_recognition_kernel, kMaxLds);
+    hipLaunchKernelGGL(vjf_recognition_kernel, dim3((B + 7) / 8), dim3(VJF_K1_THREADS), lds, (hipStream_t)stream, a, hmax);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+int vjf_gaussian_loss(const float* m1, const float* lv1, const float* m2, const float* lv2, const float* logvar, float* out,
+                      int32_t B, int32_t d, void* stream) {
+    if (!m1 || !m2 || !logvar || !out) return fail(-1, "vjf_gaussian_loss: null tensor");
+    if (B < 1 || d < 1) return fail(-20, "vjf_gaussian_loss: bad shape");
+    hipLaunchKernelGGL(vjf_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, 0, m1, lv1, m2, lv2, logvar, out, B, d);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+int vjf_gaussian_entropy(const float* lv, float* out, int32_t B, int32_t d, void* stream) {
+    if (!lv || !out) return fail(-1, "vjf_gaussian_entropy: null tensor");
+    if (B < 1 || d < 1) return fail(-20, "vjf_gaussian_entropy: bad shape");
+    hipLaunchKernelGGL(vjf_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, 1, lv, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, out, B, d);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+int vjf_poisson_loss(const float* eta, const float* target, float* out, int32_t B, int32_t d, void* stream) {
+    if (!eta || !target || !out) return fail(-1, "vjf_poisson_loss: null tensor");
+    if (B < 1 || d < 1) return fail(-20, "vjf_poisson_loss: bad shape");
+    hipLaunchKernelGGL(vjf_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, 2, eta, (const float*)nullptr, target,
+                       (const float*)nullptr, (const float*)nullptr, out, B, d);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+int vjf_linear_forward(const float* x, const float* W, const float* b, float* out, int32_t B, int32_t din, int32_t dout, void* stream) {
+    if (!x || !W || !out) return fail(-1, "vjf_linear_forward: null tensor");
+    if (B < 1 || din < 1 || dout < 1) return fail(-20, "vjf_linear_forward: bad shape");
+    hipLaunchKernelGGL(vjf_linear_kernel, grid1d((size_t)B * dout), dim3(256), 0, (hipStream_t)stream, x, din, W, b, out, B, din, dout, 0);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

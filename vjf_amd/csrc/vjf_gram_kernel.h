@@ -1,0 +1,113 @@
+// vjf_gram_kernel.h -- K1b: every sum over trials that the step needs, as split-K Gram tiles on
+// the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+//
+//   kind 0:  E^T E       -> G = Phi^T Phi (module.py:96) and Phi^T dx (module.py:94)
+//   kind 1:  DEL^T ACT   -> the weight/bias gradients that autograd's backward produces for the
+//                           recognition layers, heads and decoder (model.py:209)
+// A job is one 32x32 output tile; blockIdx.y splits the trial axis.  The 4 wavefronts of a
+// workgroup take interleaved 2-trial slices of the split, are summed through LDS in wave order
+// and written as one slab; vjf_gram_reduce_kernel adds the slabs in split order (deterministic)
+// and scatters to the reduce buffer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vjf_plan.h"
+
+typedef float vjf_f32x16 __attribute__((ext_vector_type(16)));
+
+struct VjfGramArgs {
+    const VjfJob* jobs;
+    const float* E; const float* ACT; const float* DEL;
+    float* slabs;            // (njobs, nsplit, 1024)
+    int B, nsplit, rows_per_split;
+};
+
+__global__ __launch_bounds__(256) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A) {
+    __shared__ float s_acc[3 * 1024];
+    const VjfJob job = A.jobs[blockIdx.x];
+    const int split = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, kh = lane >> 5;
+    const float* X; const float* Y; int ldx, ldy;
+    if (job.kind == 0) { X = A.E; Y = A.E; ldx = ldy = P.ldE; }
+    else { X = A.DEL; Y = A.ACT; ldx = P.ldD; ldy = P.ldA; }
+    const bool xok = r < job.xn, yok = r < job.yn;
+    const float* xp = X + job.xc + (xok ? r : 0);
+    const float* yp = Y + job.yc + (yok ? r : 0);
+    const int k_begin = split * A.rows_per_split;
+    const int k_end = min(A.B, k_begin + A.rows_per_split);
+    vjf_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // wave w takes trials k_begin + 8*j + 2*w + {0,1}
+    for (int k = k_begin + 2 * wave + kh; k < k_end + kh; k += 8) {
+        const bool kok = k < k_end;
+        const float a = (kok && xok) ? xp[(size_t)k * ldx] : 0.f;
+        const float b = (kok && yok) ? yp[(size_t)k * ldy] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    // D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_acc[(wave - 1) * 1024 + i * 64 + lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* slab = A.slabs + ((size_t)blockIdx.x * A.nsplit + split) * 1024;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = ((acc[i] + s_acc[i * 64 + lane]) + s_acc[1024 + i * 64 + lane]) + s_acc[2048 + i * 64 + lane];
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+            slab[row * 32 + r] = v;
+        }
+    }
+}
+
+struct VjfReduceArgs {
+    const VjfJob* jobs;
+    const float* slabs;
+    const float* partial;     // (nblocks_k1, RS_N) per-workgroup loss sums from K1
+    float* red;               // reduce buffer
+    int njobs, nsplit, nblocks_k1;
+};
+
+// grid = njobs + 1 workgroups of 256 threads; the extra workgroup sums K1's loss partials.
+__global__ __launch_bounds__(256) void vjf_gram_reduce_kernel(VjfPlan P, VjfReduceArgs A) {
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x == A.njobs) {
+        __shared__ double s_part[256];
+        // RS_N scalars; 32 threads per scalar accumulate strided partials in double, fixed order
+        const int sc = tid >> 5, l = tid & 31;
+        double v = 0.0;
+        for (int b = l; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
+        s_part[tid] = v;
+        __syncthreads();
+        if (l == 0) {
+            double t = 0.0;
+            for (int i = 0; i < 32; ++i) t += s_part[sc * 32 + i];
+            A.red[P.red_SC + sc] = (float)t;
+        }
+        return;
+    }
+    const VjfJob job = A.jobs[blockIdx.x];
+    const float* slab = A.slabs + (size_t)blockIdx.x * A.nsplit * 1024;
+    for (int e = tid; e < 1024; e += 256) {
+        float v = 0.f;
+        for (int s = 0; s < A.nsplit; ++s) v += slab[(size_t)s * 1024 + e];
+        const int i = e >> 5, j = e & 31;
+        if (i >= job.xn || j >= job.yn) continue;
+        if (job.kind == 0) {
+            const int gr = job.ti * VJF_TILE + i, gc = job.tj * VJF_TILE + j;   // gr: X column, gc: Y column of E
+            if (gr < P.n) {
+                if (gc < P.n && gc <= gr) {
+                    A.red[P.red_G + (size_t)gr * P.n + gc] = v;
+                    A.red[P.red_G + (size_t)gc * P.n + gr] = v;
+                }
+            } else if (gr < P.n + P.dz && gc < P.n) {
+                A.red[P.red_FDX + (size_t)gc * P.dz + (gr - P.n)] = v;
+            }
+        } else {
+            if (j < job.ncol_w) A.red[job.dst + (size_t)i * job.ld + j] = v;
+            else if (j == job.ncol_w && job.dst_b >= 0) A.red[job.dst_b + i] = v;
+        }
+    }
+}

@@ -1,0 +1,107 @@
+// vjf_ops_kernels.h -- stand-alone operator kernels behind the vjf.module / vjf.functional surface.
+// These serve the reference's operator API one call at a time; the fused step does not use them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// functional.rbf (vjf/functional.py:11-22)
+__global__ void vjf_rbf_kernel(const float* __restrict__ x, const float* __restrict__ c, const float* __restrict__ logw,
+                               float* __restrict__ out, int B, int n, int d) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * n) return;
+    const int b = (int)(i / n), k = (int)(i - (size_t)b * n);
+    float d2 = 0.f;
+    for (int j = 0; j < d; ++j) { const float t = x[(size_t)b * d + j] - c[(size_t)k * d + j]; d2 = fmaf(t, t, d2); }
+    const float w = expf(logw[k]);
+    out[i] = expf(-0.5f * d2 / (w * w));
+}
+
+// out(B,N) = X(B,K) @ M(K,N)   (+ optional addend(B,N))
+__global__ void vjf_matmul_nn_kernel(const float* __restrict__ X, const float* __restrict__ M, const float* __restrict__ add,
+                                     float* __restrict__ out, int B, int K, int N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * N) return;
+    const int b = (int)(i / N), j = (int)(i - (size_t)b * N);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(X[(size_t)b * K + k], M[(size_t)k * N + j], acc);
+    out[i] = add ? acc + add[i] : acc;
+}
+
+// out(B,N) = act( X(B,K) @ W(N,K)^T + bias(N) )    act: 0 none, 1 tanh
+__global__ void vjf_linear_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, const float* __restrict__ bias,
+                                  float* __restrict__ out, int B, int K, int N, int act) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * N) return;
+    const int b = (int)(i / N), j = (int)(i - (size_t)b * N);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(X[(size_t)b * ldx + k], W[(size_t)j * K + k], acc);
+    if (bias) acc += bias[j];
+    out[i] = act ? tanhf(acc) : acc;
+}
+
+// logvar(B,dout) = log sum_j (feat @ w_chol)[b][j]^2, tiled over dout   (vjf/module.py:75-76, row-sum form)
+__global__ void vjf_blr_logvar_kernel(const float* __restrict__ feat, const float* __restrict__ w_chol, float* __restrict__ logvar,
+                                      int B, int n, int dout) {
+    const int b = blockIdx.x;
+    __shared__ float s_w[4];
+    float v = 0.f;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc = fmaf(feat[(size_t)b * n + k], w_chol[(size_t)k * n + j], acc);
+        v = fmaf(acc, acc, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_w[w];
+    const float lv = logf(t);
+    for (int j = threadIdx.x; j < dout; j += blockDim.x) logvar[(size_t)b * dout + j] = lv;
+}
+
+// concat rows: out(B, d1+d2+d3+d4) = [a|b|c|d] (null parts have width 0)
+__global__ void vjf_concat4_kernel(const float* a, int d1, const float* b, int d2, const float* c, int d3, const float* d, int d4,
+                                   float* out, int B) {
+    const int D = d1 + d2 + d3 + d4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * D) return;
+    const int r = (int)(i / D), col = (int)(i - (size_t)r * D);
+    float v;
+    if (col < d1) v = a[(size_t)r * d1 + col];
+    else if (col < d1 + d2) v = b[(size_t)r * d2 + col - d1];
+    else if (col < d1 + d2 + d3) v = c[(size_t)r * d3 + col - d1 - d2];
+    else v = d[(size_t)r * d4 + col - d1 - d2 - d3];
+    out[i] = v;
+}
+
+// Scalar losses: one workgroup, fp64 accumulation, fixed order.
+//   mode 0: gaussian_loss (functional.py:32-75)  mode 1: gaussian_entropy (:25-29)  mode 2: poisson (likelihood.py:51-62)
+__global__ void vjf_loss_kernel(int mode, const float* m1, const float* lv1, const float* m2, const float* lv2,
+                                const float* logvar, float* out, int B, int d) {
+    __shared__ double s_p[16];
+    double acc = 0.0;
+    const size_t N = (size_t)B * d;
+    const float lvr = (mode == 0) ? logvar[0] : 0.f;
+    const float p = expf(-0.5f * lvr);
+    for (size_t i = threadIdx.x; i < N; i += blockDim.x) {
+        float t;
+        if (mode == 0) {
+            const float dsc = m1[i] * p - m2[i] * p;
+            t = 0.5f * (dsc * dsc + lvr);
+            if (lv1 || lv2) t += 0.5f * expf((lv1 ? lv1[i] : 0.f) + (lv2 ? lv2[i] : 0.f) - lvr);
+        } else if (mode == 1) {
+            t = 0.5f * m1[i];
+        } else {
+            const float eta = fminf(m1[i], 10.f);
+            t = expf(eta) - m2[i] * eta;
+        }
+        acc += (double)t;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_p[w];
+        out[0] = (float)(t / (double)B);
+    }
+}

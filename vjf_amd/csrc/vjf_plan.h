@@ -1,0 +1,129 @@
+// vjf_plan.h -- dimensions, state-blob layout and workspace layout shared by host code and kernels.
+#pragma once
+#include <stdint.h>
+#include "../../include/vjf_hip.h"
+
+#define VJF_TILE 32            // Gram tile edge (v_mfma_f32_32x32x2_f32)
+#define VJF_MAX_JOBS 4096
+
+static inline int64_t vjf_align(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// Everything a kernel needs to find its operands.  Passed by value as a kernel argument.
+struct VjfPlan {
+    int dy, dz, du, n, L, lik;
+    int h[VJF_MAX_HIDDEN];
+    int din;          // dy + du + 2 dz   (recognition input, recognition.py:20)
+    int dxu;          // dz + du          (RBF input, model.py:335)
+    int hmax, hsum;
+    int off[VJF_N_SLOTS];    // state-blob offsets (fp32 elements)
+    int size[VJF_N_SLOTS];
+    int n_state;
+    // trainable region = [REC_W0 .. DEC_B] contiguous in the blob; gradients mirror it
+    int train_off, train_len;
+    int dec_off;             // offset of DEC_W inside the blob (decoder group starts here)
+    // workspace matrices, one row per trial
+    int ldE;                 // E   = [ Phi (n) | dx (dz) | 0 ]           -> RLS statistics
+    int ldA;                 // ACT = [ in | 1 | h_1 | 1 | ... | h_L | 1 | xt | 1 | 0 ]
+    int ldD;                 // DEL = [ da_1 | ... | da_L | dmu | dlv | dpy | 0 ]
+    int colA_act[VJF_MAX_HIDDEN + 1];   // column of acts[k] in ACT (k = 0: recognition input)
+    int colA_xt;
+    int colD_da[VJF_MAX_HIDDEN];
+    int colD_dmu, colD_dlv, colD_dpy;
+    // reduce buffer (fp32 elements): [ grad (train_len) | G (n*n) | FDX (n*dz) | scalars (8) ]
+    int red_G, red_FDX, red_SC, red_len;
+};
+
+// reduce-buffer scalars
+enum { RS_LRECON = 0, RS_LDYN = 1, RS_ENT = 2, RS_SSEY = 3, RS_SDX2 = 4, RS_N = 8 };
+
+static inline int vjf_make_plan(const vjf_config* c, VjfPlan* p) {
+    if (!c || !p) return -1;
+    if (c->ydim < 1 || c->xdim < 1 || c->udim < 0 || c->n_rbf < 1) return -2;
+    if (c->n_hidden < 1 || c->n_hidden > VJF_MAX_HIDDEN) return -3;
+    if (c->likelihood != VJF_LIK_GAUSSIAN && c->likelihood != VJF_LIK_POISSON) return -4;
+    p->dy = c->ydim; p->dz = c->xdim; p->du = c->udim; p->n = c->n_rbf; p->L = c->n_hidden;
+    p->lik = c->likelihood;
+    p->din = p->dy + p->du + 2 * p->dz;
+    p->dxu = p->dz + p->du;
+    p->hmax = 0; p->hsum = 0;
+    for (int k = 0; k < VJF_MAX_HIDDEN; ++k) {
+        p->h[k] = k < p->L ? c->hidden[k] : 0;
+        if (k < p->L && p->h[k] < 1) return -5;
+        if (p->h[k] > p->hmax) p->hmax = p->h[k];
+        p->hsum += p->h[k];
+    }
+    for (int s = 0; s < VJF_N_SLOTS; ++s) p->size[s] = 0;
+    p->size[VJF_SLOT_PRIOR_MEAN] = p->dz;
+    p->size[VJF_SLOT_PRIOR_LOGVAR] = p->dz;
+    p->size[VJF_SLOT_LIK_LOGVAR] = 1;     // kept (unused) for Poisson so layouts agree
+    p->size[VJF_SLOT_TR_LOGVAR] = 1;
+    p->size[VJF_SLOT_CENTROID] = p->n * p->dxu;
+    p->size[VJF_SLOT_LOGWIDTH] = p->n;
+    int prev = p->din;
+    for (int k = 0; k < p->L; ++k) {
+        p->size[VJF_SLOT_REC_W0 + 2 * k] = p->h[k] * prev;
+        p->size[VJF_SLOT_REC_B0 + 2 * k] = p->h[k];
+        prev = p->h[k];
+    }
+    p->size[VJF_SLOT_MEAN_W] = p->dz * prev;
+    p->size[VJF_SLOT_LV_W] = p->dz * prev;
+    p->size[VJF_SLOT_LV_B] = p->dz;
+    p->size[VJF_SLOT_DEC_W] = p->dy * p->dz;
+    p->size[VJF_SLOT_DEC_B] = p->dy;
+    p->size[VJF_SLOT_W_MEAN] = p->n * p->dz;
+    p->size[VJF_SLOT_W_CHOL] = p->n * p->n;
+    p->size[VJF_SLOT_W_PREC] = p->n * p->n;
+    p->size[VJF_SLOT_W_PCHOL] = p->n * p->n;
+    p->size[VJF_SLOT_SCALARS] = VJF_N_SCALARS;
+    // blob order = state_dict order of the reference, then RLS tensors, then scalars
+    int64_t o = 0;
+    const int order_head[] = {VJF_SLOT_PRIOR_MEAN, VJF_SLOT_PRIOR_LOGVAR, VJF_SLOT_LIK_LOGVAR,
+                              VJF_SLOT_TR_LOGVAR, VJF_SLOT_CENTROID, VJF_SLOT_LOGWIDTH};
+    for (int i = 0; i < 6; ++i) { p->off[order_head[i]] = (int)o; o = vjf_align(o + p->size[order_head[i]], 4); }
+    p->train_off = (int)o;
+    for (int k = 0; k < VJF_MAX_HIDDEN; ++k) {
+        p->off[VJF_SLOT_REC_W0 + 2 * k] = (int)o; o = vjf_align(o + p->size[VJF_SLOT_REC_W0 + 2 * k], 4);
+        p->off[VJF_SLOT_REC_B0 + 2 * k] = (int)o; o = vjf_align(o + p->size[VJF_SLOT_REC_B0 + 2 * k], 4);
+    }
+    const int order_tail[] = {VJF_SLOT_MEAN_W, VJF_SLOT_LV_W, VJF_SLOT_LV_B, VJF_SLOT_DEC_W, VJF_SLOT_DEC_B};
+    for (int i = 0; i < 5; ++i) { p->off[order_tail[i]] = (int)o; o = vjf_align(o + p->size[order_tail[i]], 4); }
+    p->train_len = (int)o - p->train_off;
+    p->dec_off = p->off[VJF_SLOT_DEC_W];
+    const int order_rls[] = {VJF_SLOT_W_MEAN, VJF_SLOT_W_CHOL, VJF_SLOT_W_PREC, VJF_SLOT_W_PCHOL, VJF_SLOT_SCALARS};
+    for (int i = 0; i < 5; ++i) { p->off[order_rls[i]] = (int)o; o = vjf_align(o + p->size[order_rls[i]], 4); }
+    if (o > 0x7fffffff) return -6;
+    p->n_state = (int)o;
+    // workspace matrices
+    p->ldE = (int)vjf_align(p->n + p->dz, VJF_TILE);
+    int col = 0;
+    p->colA_act[0] = col; col += p->din + 1;
+    for (int k = 0; k < p->L; ++k) { p->colA_act[k + 1] = col; col += p->h[k] + 1; }
+    p->colA_xt = col; col += p->dz + 1;
+    p->ldA = (int)vjf_align(col, 4);
+    col = 0;
+    for (int k = 0; k < p->L; ++k) { p->colD_da[k] = col; col += p->h[k]; }
+    p->colD_dmu = col; col += p->dz;
+    p->colD_dlv = col; col += p->dz;
+    p->colD_dpy = col; col += p->dy;
+    p->ldD = (int)vjf_align(col, 4);
+    int64_t r = p->train_len;
+    p->red_G = (int)r; r += (int64_t)p->n * p->n;
+    p->red_FDX = (int)r; r = vjf_align(r + (int64_t)p->n * p->dz, 4);
+    p->red_SC = (int)r; r += RS_N;
+    if (r > 0x7fffffff) return -6;
+    p->red_len = (int)r;
+    return 0;
+}
+
+// One 32x32 output tile of a Gram product  out[i][j] = sum_b X[b][xc+i] * Y[b][yc+j].
+struct VjfJob {
+    int kind;          // 0: E^T E tile (RLS statistics), 1: gradient tile DEL^T ACT
+    int xc, yc;        // first column in X / Y
+    int xn, yn;        // valid rows (<=32) / cols (<=32) of the tile
+    int ti, tj;        // tile coordinates (kind 0)
+    int dst;           // kind 1: offset in the grad region of element (row 0, col 0) of this tile
+    int ld;            // kind 1: leading dimension of the weight matrix
+    int ncol_w;        // kind 1: columns [0, ncol_w) of the tile are weights, column ncol_w is the bias
+    int dst_b;         // kind 1: offset in the grad region of the bias (-1: none)
+    int row_skip;      // kind 1: first row_skip... unused, 0
+};
