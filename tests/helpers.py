@@ -59,7 +59,7 @@ def load_oracle_state(model, dtype=np.float64):
 LOOSE = ("w_mean", "w_chol", "w_pchol", "w_precision")
 
 
-def state_close(model, ref, *, rtol, atol, rls_rtol=None, prefix=None):
+def state_close(model, ref, *, rtol, atol, rls_rtol=None, rls_atol=None, prefix=None):
     """Compare the model's device state with an OracleState (ref) or fixture arrays (ref=z, prefix)."""
     got = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in model_arrays(model).items()}
     if prefix is None:
@@ -71,5 +71,6 @@ def state_close(model, ref, *, rtol, atol, rls_rtol=None, prefix=None):
         if k not in want or want[k] is None:
             continue
         rt = (rls_rtol or rtol) if k in LOOSE else rtol
-        np.testing.assert_allclose(got[k], np.asarray(want[k], np.float64).reshape(got[k].shape), rtol=rt, atol=atol,
+        at = (rls_atol or atol) if k in LOOSE else atol
+        np.testing.assert_allclose(got[k], np.asarray(want[k], np.float64).reshape(got[k].shape), rtol=rt, atol=at,
                                    err_msg=f"state tensor {k}")

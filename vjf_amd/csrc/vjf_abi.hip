@@ -108,7 +108,10 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
 
 template <class K>
 void allow_lds(K kernel, size_t bytes) {
+    // raise the dynamic-LDS cap (kernels here use up to ~150 KiB of the CU's 160 KiB); a refusal is
+    // not fatal by itself -- the launch reports it -- so clear the sticky error state
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    (void)hipGetLastError();
 }
 
 }  // namespace
@@ -190,8 +193,8 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs` (host) must outlive the copy
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
-    allow_lds(vjf_trial_kernel<16>, kMaxLds); allow_lds(vjf_trial_kernel<8>, kMaxLds); allow_lds(vjf_trial_kernel<4>, kMaxLds);
-    allow_lds(vjf_serial_kernel, kMaxLds); allow_lds(vjf_rls_kernel, kMaxLds);
+    allow_lds(vjf_trial_kernel<16>, c->lds_k1); allow_lds(vjf_trial_kernel<8>, c->lds_k1); allow_lds(vjf_trial_kernel<4>, c->lds_k1);
+    allow_lds(vjf_serial_kernel, c->lds_k2);
     *out = c;
     return 0;
 }
@@ -477,7 +480,7 @@ int vjf_blr_predict(const float* x, const float* centroid, const float* logwidth
     if (B < 1 || n < 1 || d < 1 || dout < 1) return fail(-20, "vjf_blr_predict: bad shape");
     const size_t lds = (size_t)(8 * n + 32) * 4;
     if (lds > kMaxLds - 1024) return fail(-11, "vjf_blr_predict: n=%d too large", n);
-    allow_lds(vjf_blr_predict_kernel, kMaxLds);
+    allow_lds(vjf_blr_predict_kernel, lds);
     VjfPredArgs a{x, centroid, logwidth, w_mean, w_chol, mean, logvar, B, n, d, dout};
     hipLaunchKernelGGL(vjf_blr_predict_kernel, dim3((B + 7) / 8), dim3(VJF_K1_THREADS), lds, (hipStream_t)stream, a);
     VJF_HIP(hipGetLastError());
@@ -494,7 +497,7 @@ int vjf_blr_sample(const float* x, const float* centroid, const float* logwidth,
     VJF_HIP(hipGetLastError());
     const size_t lds = (size_t)(8 * n + 32) * 4;
     if (lds > kMaxLds - 1024) return fail(-11, "vjf_blr_sample: n=%d too large", n);
-    allow_lds(vjf_blr_predict_kernel, kMaxLds);
+    allow_lds(vjf_blr_predict_kernel, lds);
     VjfPredArgs a{x, centroid, logwidth, w_scratch, w_chol, out, nullptr, B, n, d, dout};
     hipLaunchKernelGGL(vjf_blr_predict_kernel, dim3((B + 7) / 8), dim3(VJF_K1_THREADS), lds, s, a);
     VJF_HIP(hipGetLastError());
@@ -536,7 +539,7 @@ int vjf_blr_rls(const float* x, const float* target, const float* v, float shrin
     r.njobs = c.njobs; r.nsplit = c.nsplit; r.nblocks_k1 = 1;
     hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c.njobs + 1), dim3(256), 0, s, P, r);
     VJF_HIP(hipGetLastError());
-    allow_lds(vjf_rls_kernel, kMaxLds);
+    allow_lds(vjf_rls_kernel, lds);
     VjfRlsArgs a{};
     a.Pm = w_precision; a.Wm = w_mean; a.Wc = w_chol; a.Lm = w_pchol;
     a.G = r.red + P.red_G; a.FDX = r.red + P.red_FDX; a.v = v; a.work = (float*)(ws + c.work); a.status = status;
@@ -562,7 +565,7 @@ int vjf_recognition_forward(const float* y, const float* u, const float* mu_s, c
     for (int l = 0; l < n_hidden; ++l) { a.W[l] = rec_W[l]; a.b[l] = rec_b[l]; a.h[l] = hidden[l]; if (hidden[l] > hmax) hmax = hidden[l]; }
     const size_t lds = (size_t)8 * (ydim + udim + 2 * xdim + 2 * hmax) * 4;
     if (lds > kMaxLds - 1024) return fail(-10, "vjf_recognition_forward: layer widths do not fit LDS");
-    allow_lds(vjf_recognition_kernel, kMaxLds);
+    allow_lds(vjf_recognition_kernel, lds);
     hipLaunchKernelGGL(vjf_recognition_kernel, dim3((B + 7) / 8), dim3(VJF_K1_THREADS), lds, (hipStream_t)stream, a, hmax);
     VJF_HIP(hipGetLastError());
     return 0;

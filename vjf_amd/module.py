@@ -106,10 +106,12 @@ class LinearRegression(Module):
     def _draw_weight_noise(self) -> Tensor:
         """randn_like(w_mean) from torch's CPU generator.  In the reference w_mean is column-major
         once rls has run (cholesky_solve returns a Fortran-ordered tensor, module.py:101) and
-        randn_like fills memory order, so the draw is transposed from then on."""
+        randn_like then takes torch's non-contiguous (serial, memory-order) path: the draw is
+        made on a tensor with the same strides so the same values come out."""
         n, dout = self.w_mean.shape
         if self._w_colmajor:
-            return torch.randn(dout, n, dtype=torch.get_default_dtype()).t()
+            # same strides as the reference's w_mean => same (serial, memory-order) normal_ path
+            return torch.randn_like(torch.empty(dout, n, dtype=torch.get_default_dtype()).t())
         return torch.randn(n, dout, dtype=torch.get_default_dtype())
 
     @torch.no_grad()
