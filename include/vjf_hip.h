@@ -76,6 +76,8 @@ enum vjf_scalar {
     VJF_SC_LR_REC = 5,
     VJF_SC_FREEZE_DEC = 6, /* 1.0 after decoder.requires_grad_(False)  model.py:283 */
     VJF_SC_STATUS = 7,     /* status bits as an integer-valued float */
+    VJF_SC_TRI_CLEAN = 8,  /* device-internal: 1 once the zero halves of w_chol / w_pchol have been cleared;
+                              write 0 after storing a dense matrix into either tensor from the host */
     VJF_N_SCALARS = 16
 };
 
@@ -111,6 +113,10 @@ int vjf_ctx_destroy(vjf_ctx* ctx);
 int vjf_set_stream(vjf_ctx* ctx, void* stream);
 /* Synchronises the stream, returns and clears the sticky status bits. */
 int vjf_get_status(vjf_ctx* ctx, uint32_t* status);
+
+/* Diagnostic: enable/disable s_memtime phase stamps in the serial kernel and (out32 != NULL) copy the
+ * 32 stamp words of the last step to the host.  Not part of the reference surface. */
+int vjf_debug_stamps(vjf_ctx* ctx, int enable, uint64_t* out32);
 
 /* ---- the hot path: VJF.filter (vjf/model.py:179-221) ---------------------------------------- */
 /* One filtering step on B trials.

@@ -1,0 +1,24 @@
+"""Diagnostic: phase stamps of the serial kernel at the bench configuration (not a benchmark)."""
+import ctypes, sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch, vjf_amd
+from vjf_amd import _native as N
+torch.manual_seed(0)
+B, dz, dy, n = 4096, 10, 50, 200
+m = vjf_amd.VJF.make_model(dy, dz, 0, n, [128], likelihood="gaussian", noise="device")
+y = torch.randn(8, B, dy, device="cuda"); 
+m.filter_sequence(y[:4])
+N.check(m._backend().vjf_debug_stamps(m._ctx, 1, None))
+m.filter_sequence(y[4:])
+out = (ctypes.c_uint64 * 32)()
+N.check(m._backend().vjf_debug_stamps(m._ctx, 0, out))
+t = list(out)[:9]
+names = ["load", "chol", "writeL", "dinv", "inverse", "diagcopy+wchol", "solveW", "residual"]
+for i, nm in enumerate(names):
+    print(f"{nm:16s} {(t[i+1]-t[i]):8d} cycles(100MHz ticks?)")
+print("total", t[8]-t[0])
+T=list(out)
+print("k=0: potrf", T[9]-T[1], "panel", T[10]-T[9], "trailing", T[11]-T[10])
+
+
+print("k=1: blk_load", T[17]-T[16], "chain+stores", T[18]-T[17], "barrier", T[19]-T[18], "panel", T[20]-T[19], "trailing", T[21]-T[20])

@@ -21,7 +21,7 @@ SLOT_MEAN_W, SLOT_LV_W, SLOT_LV_B, SLOT_DEC_W, SLOT_DEC_B = 22, 23, 24, 25, 26
 SLOT_W_MEAN, SLOT_W_CHOL, SLOT_W_PREC, SLOT_W_PCHOL, SLOT_SCALARS = 27, 28, 29, 30, 31
 N_SLOTS = 32
 # enum vjf_scalar
-SC_N_LIK, SC_N_TR, SC_LR_LIK, SC_LR_DEC, SC_LR_TR, SC_LR_REC, SC_FREEZE_DEC, SC_STATUS = range(8)
+SC_N_LIK, SC_N_TR, SC_LR_LIK, SC_LR_DEC, SC_LR_TR, SC_LR_REC, SC_FREEZE_DEC, SC_STATUS, SC_TRI_CLEAN = range(9)
 N_SCALARS = 16
 
 
@@ -50,6 +50,7 @@ SIGNATURES = {
     "vjf_ctx_destroy": [_P],
     "vjf_set_stream": [_P, _P],
     "vjf_get_status": [_P, C.POINTER(_U)],
+    "vjf_debug_stamps": [_P, _I, C.POINTER(C.c_uint64)],
     "vjf_filter_step": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U],
     "vjf_filter_local": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _U],
     "vjf_reduce_buffer": [_P, C.POINTER(_P), C.POINTER(C.c_int64)],

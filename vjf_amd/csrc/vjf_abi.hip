@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/vjf_hip.h"
+#include "vjf_chol_kernel.h"
 #include "vjf_gram_kernel.h"
 #include "vjf_ops_kernels.h"
 #include "vjf_plan.h"
@@ -100,7 +101,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.partial = take(((size_t)max_batch / 4 + 2) * RS_N * 4);
     c.slabs = take((size_t)njobs * split_for(max_batch) * 1024 * 4);
     c.red = take((size_t)P.red_len * 4);
-    c.work = take(vjf_serial_work_floats(P) * 4);
+    c.work = take(vjf_serial_work_floats(P) * 4 + 256);   // + 32 u64 diagnostic stamps
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.total = o;
     return c;
@@ -127,6 +128,9 @@ struct vjf_ctx {
     int njobs;
     int TB;
     size_t lds_k1, lds_k2;
+    bool stamps;           // diagnostic: record s_memtime phase stamps in the serial kernel
+    bool fast_chol;        // n_rbf <= 224: prep kernel + LDS-resident MFMA Cholesky; else the generic serial kernel
+    size_t lds_chol;
 };
 
 extern "C" {
@@ -182,19 +186,25 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
         if (vjf_trial_lds_floats(P, t) * 4 <= kMaxLds - 1024) { TB = t; break; }
     if (!TB) return fail(-10, "vjf_ctx_create: per-trial working set does not fit LDS (dims too large)");
     const size_t lds_k2 = vjf_serial_lds_floats(P) * 4;
-    if (lds_k2 > kMaxLds - 1024) return fail(-11, "vjf_ctx_create: n_rbf=%d too large for the single-workgroup RLS kernel", P.n);
+    const bool fast_chol = vjf_chol_lds_ok(P);
+    if (!fast_chol && lds_k2 > kMaxLds - 1024)
+        return fail(-11, "vjf_ctx_create: n_rbf=%d too large for the single-workgroup RLS kernel", P.n);
     VJF_HIP(hipSetDevice(cfg->device));
     vjf_ctx* c = new (std::nothrow) vjf_ctx();
     if (!c) return fail(-12, "vjf_ctx_create: out of host memory");
     c->cfg = *cfg; c->plan = P; c->state = state; c->ws = (char*)workspace; c->ws_bytes = workspace_bytes;
     c->stream = (hipStream_t)stream; c->cv = cv; c->njobs = (int)jobs.size(); c->TB = TB;
     c->lds_k1 = vjf_trial_lds_floats(P, TB) * 4; c->lds_k2 = lds_k2;
+    c->fast_chol = fast_chol; c->lds_chol = vjf_chol_lds_bytes(P); c->stamps = false;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs` (host) must outlive the copy
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
     allow_lds(vjf_trial_kernel<16>, c->lds_k1); allow_lds(vjf_trial_kernel<8>, c->lds_k1); allow_lds(vjf_trial_kernel<4>, c->lds_k1);
     allow_lds(vjf_serial_kernel, c->lds_k2);
+    allow_lds(vjf_chol_lds_kernel<4>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<8>, c->lds_chol);
+    allow_lds(vjf_chol_lds_kernel<12>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<16>, c->lds_chol);
+    allow_lds(vjf_chol_lds_kernel<32>, c->lds_chol);
     *out = c;
     return 0;
 }
@@ -218,6 +228,16 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status) {
     VJF_HIP(hipMemsetAsync(p, 0, 4, ctx->stream));
     VJF_HIP(hipStreamSynchronize(ctx->stream));
     *status = (uint32_t)v;
+    return 0;
+}
+
+int vjf_debug_stamps(vjf_ctx* ctx, int enable, uint64_t* out32) {
+    if (!ctx) return fail(-1, "vjf_debug_stamps: null context");
+    ctx->stamps = enable != 0;
+    if (out32) {
+        VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.work + vjf_serial_work_floats(ctx->plan) * 4, 256, hipMemcpyDeviceToHost, ctx->stream));
+        VJF_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return 0;
 }
 
@@ -269,6 +289,30 @@ int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, cons
 int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_global: null context");
     if (B_total < 1) return fail(-20, "vjf_filter_global: B_total=%d", B_total);
+    if (c->fast_chol) {
+        const VjfPlan& P = c->plan;
+        VjfPrepArgs p{};
+        p.state = c->state; p.red = (const float*)(c->ws + c->cv.red); p.gbuf = (float*)(c->ws + c->cv.work);
+        p.loss4 = loss4; p.B_total = B_total; p.flags = flags;
+        p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
+        p.n_sgdblk = (P.train_len + 1023) / 1024;
+        hipLaunchKernelGGL(vjf_prep_kernel, dim3(p.n_rowblk + p.n_sgdblk + 1), dim3(256), 0, c->stream, P, p);
+        VJF_HIP(hipGetLastError());
+        if (flags & VJF_FLAG_UPDATE) {
+            VjfCholArgs a{};
+            a.state = c->state; a.red = p.red; a.gbuf = p.gbuf; a.B_total = B_total; a.flags = flags;
+            a.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
+            switch (vjf_chol_dzp(P.dz)) {
+                case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
+                case 8: hipLaunchKernelGGL(vjf_chol_lds_kernel<8>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
+                case 12: hipLaunchKernelGGL(vjf_chol_lds_kernel<12>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
+                case 16: hipLaunchKernelGGL(vjf_chol_lds_kernel<16>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
+                default: hipLaunchKernelGGL(vjf_chol_lds_kernel<32>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
+            }
+            VJF_HIP(hipGetLastError());
+        }
+        return 0;
+    }
     VjfSerialArgs s{};
     s.state = c->state; s.red = (const float*)(c->ws + c->cv.red); s.work = (float*)(c->ws + c->cv.work);
     s.loss4 = loss4; s.B_total = B_total; s.flags = flags;

@@ -1,0 +1,574 @@
+// vjf_chol_kernel.h -- fast path of the once-per-step serial half for n_rbf <= 224.
+//
+//   vjf_prep_kernel  (many workgroups): everything element-wise that the step's serial half
+//       needs -- finite guards + loss (model.py:138-154), clip + SGD (model.py:210-211),
+//       likelihood running variance (likelihood.py:28-40), g = P W + Phi^T dx / v and
+//       P += Phi^T Phi / v (module.py:94-96) -- so that ONE compute unit is left with nothing
+//       but the dependent chain.
+//   vjf_chol_lds_kernel (one workgroup, 8 wavefronts): L = chol(P) (module.py:99),
+//       W = P^-1 g (module.py:101), w_chol = L^-T (module.py:102), residual -> state-noise
+//       running variance (model.py:373-377).  The matrix lives in LDS as XOR-swizzled 32x32
+//       blocks; all block products run on the f32 matrix cores (v_mfma_f32_32x32x2_f32).
+//       The two column-sequential pieces (diagonal-block Cholesky, triangular block solve) are
+//       written as chains of rank-1 MFMA updates on an accumulator tile: the symmetric tile has
+//       row j already spread over the lanes (column index on the lane), which is exactly the
+//       A- and B-operand layout, so a column step is  readlane(pivot) -> rsqrt -> scale -> MFMA
+//       with no cross-lane data movement.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vjf_gram_kernel.h"   // vjf_f32x16
+#include "vjf_plan.h"
+
+#define VJF_CHOL_THREADS 512
+#define VJF_CHOL_MAXBLK 7                 // n <= 224
+#define VJF_PREP_ROWS 8                   // rows of P per prep workgroup
+
+// ---------------------------------------------------------------------------------------------
+struct VjfPrepArgs {
+    float* state;
+    const float* red;
+    float* gbuf;          // (n, dz) g = P W + FDX / v
+    float* loss4;
+    int B_total;
+    unsigned flags;
+    int n_rowblk, n_sgdblk;
+};
+
+// grid = n_rowblk + n_sgdblk + 1
+__global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A) {
+    const int tid = threadIdx.x, bid = blockIdx.x;
+    float* S = A.state;
+    float* SC = S + P.off[VJF_SLOT_SCALARS];
+    const float* RSC = A.red + P.red_SC;
+    const bool do_sgd = A.flags & VJF_FLAG_SGD, do_upd = A.flags & VJF_FLAG_UPDATE, warm = A.flags & VJF_FLAG_WARM_UP;
+    const float Bf = (float)A.B_total, invB = 1.0f / Bf;
+    float l_recon = RSC[RS_LRECON] * invB, l_dyn = RSC[RS_LDYN] * invB, ent = RSC[RS_ENT] * invB;
+    const bool ok_r = isfinite(l_recon), ok_d = isfinite(l_dyn), ok_h = isfinite(ent);
+    const bool grad_ok = ok_r && ok_h && (warm || ok_d);       // see vjf_serial_kernel / DESIGN.md
+
+    if (bid < A.n_rowblk) {                                    // ---- RLS operands, VJF_PREP_ROWS rows of P each
+        if (!do_upd || warm) return;
+        __shared__ float s_g[VJF_PREP_ROWS * 64];
+        const int n = P.n, dz = P.dz;
+        const int i0 = bid * VJF_PREP_ROWS;
+        const float inv_v = expf(-S[P.off[VJF_SLOT_TR_LOGVAR]]);
+        float* Pm = S + P.off[VJF_SLOT_W_PREC];
+        const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
+        const float* G = A.red + P.red_G;
+        const float* FDX = A.red + P.red_FDX;
+        // g rows: 32 lanes per output split k, then a 32-lane xor reduction
+        const int lane = tid & 31, grp = tid >> 5;               // 8 groups of 32 lanes
+        for (int o = grp; o < VJF_PREP_ROWS * dz; o += 8) {
+            const int i = i0 + o / dz, j = o % dz;
+            float acc = 0.f;
+            if (i < n) for (int k = lane; k < n; k += 32) acc = fmaf(Pm[(size_t)i * n + k], Wm[(size_t)k * dz + j], acc);
+#pragma unroll
+            for (int s = 16; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+            if (lane == 0 && i < n) A.gbuf[(size_t)i * dz + j] = acc + FDX[(size_t)i * dz + j] * inv_v;
+        }
+        __syncthreads();                                       // all reads of the old rows done
+        for (int e = tid; e < VJF_PREP_ROWS * n; e += 256) {
+            const int i = i0 + e / n, k = e % n;
+            if (i < n) Pm[(size_t)i * n + k] = Pm[(size_t)i * n + k] + G[(size_t)i * n + k] * inv_v;
+        }
+        (void)s_g;
+        return;
+    }
+    if (bid < A.n_rowblk + A.n_sgdblk) {                       // ---- clip + SGD on the trainable region
+        if (!(do_sgd && grad_ok)) return;
+        const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
+        const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
+        const int dec_rel = P.dec_off - P.train_off;
+        for (int i = (bid - A.n_rowblk) * 256 + tid; i < P.train_len; i += A.n_sgdblk * 256) {
+            const bool dec = i >= dec_rel;
+            if (dec && freeze) continue;
+            float g = A.red[i] * invB;
+            g = fminf(fmaxf(g, -1.f), 1.f);
+            S[P.train_off + i] -= (dec ? lr_dec : lr_rec) * g;
+        }
+        return;
+    }
+    if (tid == 0) {                                            // ---- scalars: loss, likelihood log-variance
+        if (!ok_r) l_recon = 0.f;
+        if (!ok_d) l_dyn = 0.f;
+        if (!ok_h) ent = 0.f;
+        float loss = l_recon - ent;
+        if (!warm) loss += l_dyn;
+        if (A.loss4) { A.loss4[0] = loss; A.loss4[1] = -l_recon; A.loss4[2] = -l_dyn; A.loss4[3] = ent; }
+        const unsigned st = (ok_r ? 0u : VJF_STATUS_NONFINITE_RECON) | (ok_d ? 0u : VJF_STATUS_NONFINITE_DYN) |
+                            (ok_h ? 0u : VJF_STATUS_NONFINITE_ENT);
+        if (st) SC[VJF_SC_STATUS] = (float)((unsigned)SC[VJF_SC_STATUS] | st);
+        if (P.lik == VJF_LIK_GAUSSIAN) {
+            const float sse_y = RSC[RS_SSEY];
+            float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
+            if (do_sgd && grad_ok) {
+                float g = 0.5f * ((float)P.dy - expf(-rho) * sse_y * invB);
+                g = fminf(fmaxf(g, -1.f), 1.f);
+                rho -= SC[VJF_SC_LR_LIK] * g;
+            }
+            if (do_upd) {
+                const float mse = sse_y / (Bf * (float)P.dy);
+                const float acc = fminf(SC[VJF_SC_N_LIK], 1000.f), tot = acc + Bf;
+                rho = logf((acc / tot) * expf(rho) + (Bf / tot) * mse);
+                SC[VJF_SC_N_LIK] = tot;
+            }
+            S[P.off[VJF_SLOT_LIK_LOGVAR]] = rho;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS block helpers.  A 32x32 block is 1024 floats; element (r,c) sits at r*32 + (c ^ r), which
+// makes row reads, column reads and the MFMA operand reads bank-conflict free.
+__device__ __forceinline__ int vsw(int r, int c) { return r * 32 + (c ^ r); }
+__device__ __forceinline__ int vtri(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }
+// accumulator layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ __forceinline__ int vrow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+__device__ __forceinline__ float vrl(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float vrsqrt(float d) {               // rsqrt with one Newton step: ~0.5 ulp
+    float s = __builtin_amdgcn_rsqf(d);
+    return s * fmaf(-0.5f * d * s, s, 1.5f);
+}
+
+__device__ __forceinline__ void blk_load(vjf_f32x16& acc, const float* blk, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = blk[vsw(vrow(r, h), c)];
+}
+__device__ __forceinline__ void blk_load_t(vjf_f32x16& acc, const float* blk, int lane) {   // acc = blk^T
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = blk[vsw(c, vrow(r, h))];
+}
+__device__ __forceinline__ void blk_store(const vjf_f32x16& acc, float* blk, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) blk[vsw(vrow(r, h), c)] = acc[r];
+}
+// acc += sign * Ab * Bb      (Bt: use Bb^T)
+template <bool Bt>
+__device__ __forceinline__ void blk_mma(vjf_f32x16& acc, const float* Ab, const float* Bb, float sign, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int m = 2 * t + h;
+        const float a = sign * Ab[vsw(c, m)];
+        const float b = Bt ? Bb[vsw(c, m)] : Bb[vsw(m, c)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+}
+
+// Cholesky of the symmetric tile held in `acc` (one wavefront) together with the inverse of its
+// factor: a second accumulator starts as I and receives the same column's rank-1 update
+// (R[c][:] -= L[c][j] * X[j][:]), so the two MFMAs of a step overlap in the pipe.
+// Writes L (lower part) into `out`, L^-1 (lower) into `inv`.  Returns false on a bad pivot.
+// Nothing but the dependent chain sits inside the column loop; the LDS stores follow it.
+__device__ __forceinline__ bool potrf_inv_chain(vjf_f32x16& acc, float* out, float* inv, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+    bool ok = true;
+    float lcol[32], xrow[32];
+    vjf_f32x16 racc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) racc[r] = (vrow(r, h) == c) ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int rj = (j & 3) + 4 * (j >> 3), hj = (j >> 2) & 1;      // vrow(rj, hj) == j
+        const float d = vrl(acc[rj], j + 32 * hj);
+        if (!(d > 0.f) || !(d < 3.0e38f)) ok = false;
+        const float s = __builtin_amdgcn_rsqf(d);
+        const bool on = (h == hj);
+        const float l = (on && (c >= j)) ? acc[rj] * s : 0.f;           // l[c] = L[c][j]
+        const float x = on ? racc[rj] * s : 0.f;                        // x[c] = Linv[j][c]
+        const float lo = (on && (c > j)) ? -l : 0.f;                    // strictly below the pivot
+        lcol[j] = l;
+        xrow[j] = x;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-l, l, acc, 0, 0, 0);
+        racc = __builtin_amdgcn_mfma_f32_32x32x2f32(lo, x, racc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int hj = (j >> 2) & 1;
+        if (h == hj) {
+            if (c >= j) out[vsw(c, j)] = lcol[j];
+            inv[vsw(j, c)] = (c <= j) ? xrow[j] : 0.f;
+        }
+    }
+    return ok;
+}
+
+struct VjfCholArgs {
+    float* state;
+    const float* red;
+    const float* gbuf;     // from vjf_prep_kernel
+    int B_total;
+    unsigned flags;
+    unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memtime at phase boundaries
+};
+
+#define VJF_STAMP(i)                                                                        \
+    do {                                                                                    \
+        if (A.stamps && tid == 0) {                                                         \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+            A.stamps[i] = t_;                                                               \
+        }                                                                                   \
+    } while (0)
+
+static inline int vjf_chol_dzp(int dz) { return dz <= 4 ? 4 : dz <= 8 ? 8 : dz <= 12 ? 12 : dz <= 16 ? 16 : 32; }
+static inline size_t vjf_chol_lds_bytes(const VjfPlan& P) {
+    const int nbl = (P.n + 31) / 32;
+    const size_t blocks = (size_t)(nbl * (nbl + 1) / 2 + nbl) * 1024;
+    return (blocks + (size_t)nbl * 32 * vjf_chol_dzp(P.dz) + 192) * 4;
+}
+static inline bool vjf_chol_lds_ok(const VjfPlan& P) {
+    return (P.n + 31) / 32 <= VJF_CHOL_MAXBLK && P.n % 4 == 0 && P.dz <= 32 && vjf_chol_lds_bytes(P) <= 160 * 1024 - 512;
+}
+
+#define VJF_CHOL_Q 14          // float4 chunks per thread when sweeping the <= 28 lower blocks
+
+// acc[0..DZP) += x * row[0..DZP)   (row: 16-byte aligned LDS, same address on every lane => broadcast)
+template <int DZP>
+__device__ __forceinline__ void axpy_row(float (&acc)[DZP], float x, const float* row) {
+#pragma unroll
+    for (int j = 0; j < DZP; j += 4) {
+        const float4 w = *reinterpret_cast<const float4*>(row + j);
+        acc[j] = fmaf(x, w.x, acc[j]); acc[j + 1] = fmaf(x, w.y, acc[j + 1]);
+        acc[j + 2] = fmaf(x, w.z, acc[j + 2]); acc[j + 3] = fmaf(x, w.w, acc[j + 3]);
+    }
+}
+
+template <int DZP>
+__global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan P, VjfCholArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = P.n, dz = P.dz;
+    const int nbl = (n + 31) / 32, npad = nbl * 32, ntri = nbl * (nbl + 1) / 2;
+    float* S = A.state;
+    float* SC = S + P.off[VJF_SLOT_SCALARS];
+    const bool do_upd = A.flags & VJF_FLAG_UPDATE, warm = A.flags & VJF_FLAG_WARM_UP;
+    if (!do_upd) return;
+    float* s_blk = lds;                               // ntri blocks: lower block triangle of P -> L -> L^-1
+    float* s_aux = s_blk + (size_t)ntri * 1024;       // nbl blocks: inverted diagonal blocks of L; later scratch
+    float* s_g = s_aux + (size_t)nbl * 1024;          // npad x DZP  g, later W
+    float* s_y = s_aux + (size_t)npad * DZP;          // npad x DZP  y = L^-1 g: lives in the upper part of s_aux once the
+                                                      //             inverted diagonal blocks have been copied out (2*npad*DZP <= nbl*1024)
+    int* s_flag = (int*)(s_g + (size_t)npad * DZP);   // [0] ok
+    double* s_d = (double*)(s_flag + 8);              // 16 doubles for the final reduction
+    int* s_bi = s_flag + 64;                          // block-row / block-column of lower block b
+    int* s_bj = s_bi + 32;
+
+    float* Wm = S + P.off[VJF_SLOT_W_MEAN];
+    float* Wc = S + P.off[VJF_SLOT_W_CHOL];
+    float* Pm = S + P.off[VJF_SLOT_W_PREC];
+    float* Lm = S + P.off[VJF_SLOT_W_PCHOL];
+    const float* G = A.red + P.red_G;
+    const float* FDX = A.red + P.red_FDX;
+    const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
+    const float Bf = (float)A.B_total;
+    unsigned st = 0;
+    VJF_STAMP(0);
+    if (tid < ntri) {
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= tid) ++bi;
+        s_bi[tid] = bi;
+        s_bj[tid] = tid - bi * (bi + 1) / 2;
+    }
+    if (tid == 0) s_flag[0] = 1;
+    __syncthreads();
+
+    if (!warm) {
+        // ---- load the lower block triangle of P_new (vjf_prep_kernel already added Phi^T Phi / v): all loads
+        //      of a thread are issued before the first LDS store
+        {
+            float4 v[VJF_CHOL_Q];
+#pragma unroll
+            for (int q = 0; q < VJF_CHOL_Q; ++q) {
+                const int idx = tid + q * VJF_CHOL_THREADS;
+                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < ntri * 256) {
+                    const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
+                    const int gi = s_bi[b] * 32 + r, gj = s_bj[b] * 32 + c4;
+                    if (gi < n && gj < n) v[q] = *reinterpret_cast<const float4*>(Pm + (size_t)gi * n + gj);
+                    else { v[q].x = gi == gj ? 1.f : 0.f; v[q].y = gi == gj + 1 ? 1.f : 0.f; v[q].z = gi == gj + 2 ? 1.f : 0.f; v[q].w = gi == gj + 3 ? 1.f : 0.f; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < VJF_CHOL_Q; ++q) {
+                const int idx = tid + q * VJF_CHOL_THREADS;
+                if (idx < ntri * 256) {
+                    const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
+                    float* blk = s_blk + (size_t)b * 1024;
+                    blk[vsw(r, c4)] = v[q].x; blk[vsw(r, c4 + 1)] = v[q].y; blk[vsw(r, c4 + 2)] = v[q].z; blk[vsw(r, c4 + 3)] = v[q].w;
+                }
+            }
+        }
+        for (int e = tid; e < npad * DZP; e += VJF_CHOL_THREADS) {
+            const int r = e / DZP, j = e - r * DZP;
+            s_g[e] = (r < n && j < dz) ? A.gbuf[(size_t)r * dz + j] : 0.f;
+        }
+        __syncthreads();
+        VJF_STAMP(1);
+
+        // ---- blocked right-looking Cholesky
+        for (int k = 0; k < nbl; ++k) {
+            if (wave == 0) {                                           // diagonal block: L_kk and L_kk^-1 in one chain
+                float* dk = s_blk + (size_t)vtri(k, k) * 1024;
+                vjf_f32x16 acc;
+                if (k == 1) VJF_STAMP(16);
+                blk_load(acc, dk, lane);
+                if (k == 1) VJF_STAMP(17);
+                if (!potrf_inv_chain(acc, dk, s_aux + (size_t)k * 1024, lane) && lane == 0) s_flag[0] = 0;
+                if (k == 1) VJF_STAMP(18);
+            }
+            __syncthreads();
+            if (k == 1) VJF_STAMP(19);
+            if (k == 0) VJF_STAMP(9);
+            if (!s_flag[0]) break;
+            {                                                          // panel: L_ik = A_ik L_kk^-T, a plain block product
+                const float* ik = s_aux + (size_t)k * 1024;
+                for (int bi = k + 1 + wave; bi < nbl; bi += VJF_CHOL_THREADS / 64) {
+                    float* pb = s_blk + (size_t)vtri(bi, k) * 1024;
+                    vjf_f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    blk_mma<true>(acc, pb, ik, 1.f, lane);
+                    blk_store(acc, pb, lane);                           // same wavefront read all of pb before writing
+                }
+            }
+            __syncthreads();
+            if (k == 1) VJF_STAMP(20);
+            if (k == 0) VJF_STAMP(10);
+            {                                                          // trailing update A_ij -= L_ik L_jk^T
+                const int m = nbl - 1 - k, nt = m * (m + 1) / 2;
+                for (int t = wave; t < nt; t += VJF_CHOL_THREADS / 64) {
+                    const int bi = k + 1 + s_bi[t], bj = k + 1 + s_bj[t];
+                    float* cb = s_blk + (size_t)vtri(bi, bj) * 1024;
+                    vjf_f32x16 acc;
+                    blk_load(acc, cb, lane);
+                    blk_mma<true>(acc, s_blk + (size_t)vtri(bi, k) * 1024, s_blk + (size_t)vtri(bj, k) * 1024, -1.f, lane);
+                    blk_store(acc, cb, lane);
+                }
+            }
+            __syncthreads();
+            if (k == 1) VJF_STAMP(21);
+            if (k == 0) VJF_STAMP(11);
+        }
+        const bool ok = s_flag[0] != 0;
+        VJF_STAMP(2);
+        if (!ok) {
+            // Reference: the fallback calls the removed torch.eig and raises (module.py:104-112).  Here:
+            // undo P += G / v (exact up to one rounding) and leave W, w_chol, w_pchol as they were.
+            st |= VJF_STATUS_RLS_FAILED;
+            const float inv_v = expf(-sig);
+            for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) Pm[e] = Pm[e] - G[e] * inv_v;
+        } else {
+            // ---- w_pchol = L (lower, module.py:99-100)
+            {
+                float4 v[VJF_CHOL_Q];
+#pragma unroll
+                for (int q = 0; q < VJF_CHOL_Q; ++q) {
+                    const int idx = tid + q * VJF_CHOL_THREADS;
+                    if (idx < ntri * 256) {
+                        const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
+                        const float* blk = s_blk + (size_t)b * 1024;
+                        const bool dg = s_bi[b] == s_bj[b];
+                        v[q].x = (!dg || c4 <= r) ? blk[vsw(r, c4)] : 0.f;
+                        v[q].y = (!dg || c4 + 1 <= r) ? blk[vsw(r, c4 + 1)] : 0.f;
+                        v[q].z = (!dg || c4 + 2 <= r) ? blk[vsw(r, c4 + 2)] : 0.f;
+                        v[q].w = (!dg || c4 + 3 <= r) ? blk[vsw(r, c4 + 3)] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < VJF_CHOL_Q; ++q) {
+                    const int idx = tid + q * VJF_CHOL_THREADS;
+                    if (idx < ntri * 256) {
+                        const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
+                        const int gi = s_bi[b] * 32 + r, gj = s_bj[b] * 32 + c4;
+                        if (gi < n && gj < n) *reinterpret_cast<float4*>(Lm + (size_t)gi * n + gj) = v[q];
+                    }
+                }
+            }
+            VJF_STAMP(3);
+            VJF_STAMP(4);
+            // ---- X = L^-1, block row by block row, in place over L:
+            //      X_ij = -Dinv_i * sum_{k=j}^{i-1} L_ik X_kj   (X_jj = Dinv_j)
+            for (int bi = 1; bi < nbl; ++bi) {
+                vjf_f32x16 xacc;
+                const int bj = wave;                                   // bi <= 6 < 8 wavefronts
+                if (bj < bi) {
+                    vjf_f32x16 t;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = 0.f;
+                    for (int k = bj; k < bi; ++k) {
+                        const float* xb = (k == bj) ? s_aux + (size_t)bj * 1024 : s_blk + (size_t)vtri(k, bj) * 1024;
+                        blk_mma<false>(t, s_blk + (size_t)vtri(bi, k) * 1024, xb, 1.f, lane);
+                    }
+                    // X_ij = -Dinv_i * T with T taken straight from the accumulator: register r of T holds
+                    // rows vrow(r,0) / vrow(r,1) on the two lane halves = the k pair of MFMA step r.
+                    const float* di = s_aux + (size_t)bi * 1024;
+                    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xacc[r] = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-di[vsw(c, vrow(r, h))], t[r], xacc, 0, 0, 0);
+                }
+                __syncthreads();                                       // every reader of row bi of L is done
+                if (bj < bi) blk_store(xacc, s_blk + (size_t)vtri(bi, bj) * 1024, lane);
+                __syncthreads();
+            }
+            VJF_STAMP(5);
+            // diagonal blocks of X
+            for (int e = tid; e < nbl * 1024; e += VJF_CHOL_THREADS) s_blk[(size_t)vtri(e >> 10, e >> 10) * 1024 + (e & 1023)] = s_aux[e];
+            __syncthreads();
+            // ---- w_chol = X^T (upper, module.py:102): row (bj*32+c) of w_chol, 4 consecutive r per store
+            {
+                float4 v[VJF_CHOL_Q];
+#pragma unroll
+                for (int q = 0; q < VJF_CHOL_Q; ++q) {
+                    const int idx = tid + q * VJF_CHOL_THREADS;
+                    if (idx < ntri * 256) {
+                        const int b = idx >> 8, c = (idx >> 3) & 31, r4 = (idx & 7) * 4;
+                        const float* blk = s_blk + (size_t)b * 1024;
+                        const bool dg = s_bi[b] == s_bj[b];
+                        v[q].x = (!dg || c <= r4) ? blk[vsw(r4, c)] : 0.f;
+                        v[q].y = (!dg || c <= r4 + 1) ? blk[vsw(r4 + 1, c)] : 0.f;
+                        v[q].z = (!dg || c <= r4 + 2) ? blk[vsw(r4 + 2, c)] : 0.f;
+                        v[q].w = (!dg || c <= r4 + 3) ? blk[vsw(r4 + 3, c)] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < VJF_CHOL_Q; ++q) {
+                    const int idx = tid + q * VJF_CHOL_THREADS;
+                    if (idx < ntri * 256) {
+                        const int b = idx >> 8, c = (idx >> 3) & 31, r4 = (idx & 7) * 4;
+                        const int gi = s_bi[b] * 32 + r4, gj = s_bj[b] * 32 + c;          // X[gi..gi+3][gj]
+                        if (gi < n && gj < n) *reinterpret_cast<float4*>(Wc + (size_t)gj * n + gi) = v[q];
+                    }
+                }
+            }
+            // The off-diagonal blocks on the other side of the diagonal (upper for w_pchol, lower for
+            // w_chol) are zero and stay zero; they are cleared once per state blob, not every step.
+            if (SC[VJF_SC_TRI_CLEAN] == 0.f) {
+                for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) {
+                    const int i = e / n, j = e - i * n;
+                    if ((i >> 5) < (j >> 5)) Lm[e] = 0.f;
+                    if ((i >> 5) > (j >> 5)) Wc[e] = 0.f;
+                }
+                __syncthreads();
+                if (tid == 0) SC[VJF_SC_TRI_CLEAN] = 1.f;
+            }
+            VJF_STAMP(6);
+            // ---- y = X g ; W = X^T y  (cholesky_solve, module.py:101).  Thread (row, part): the part-th half of the
+            //      sum by column parity, so every lane of a wavefront walks the same column (broadcast reads of g / y).
+            {
+                const int r = tid & 255, part = tid >> 8;
+                float acc[DZP];
+#pragma unroll
+                for (int j = 0; j < DZP; ++j) acc[j] = 0.f;
+                if (r < npad) {
+                    const int br = r >> 5, rr = r & 31;
+                    for (int c = part; c < npad; c += 2) {
+                        const float x = (c <= r) ? s_blk[(size_t)vtri(br, min(c >> 5, br)) * 1024 + vsw(rr, c & 31)] : 0.f;
+                        axpy_row<DZP>(acc, x, s_g + c * DZP);
+                    }
+                }
+                float* dst = part ? s_aux : s_y;     // s_aux (Dinv) is free now (copied into the diagonal slots)
+                if (r < npad) {
+#pragma unroll
+                    for (int j = 0; j < DZP; ++j) dst[r * DZP + j] = acc[j];
+                }
+                __syncthreads();
+                for (int e = tid; e < npad * DZP; e += VJF_CHOL_THREADS) s_y[e] += s_aux[e];
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < DZP; ++j) acc[j] = 0.f;
+                if (r < npad) {
+                    const int bk = r >> 5, kk = r & 31;                 // r plays the role of the column k of X
+                    for (int q = part; q < npad; q += 2) {
+                        const float x = (q >= r) ? s_blk[(size_t)vtri(max(q >> 5, bk), bk) * 1024 + vsw(q & 31, kk)] : 0.f;
+                        axpy_row<DZP>(acc, x, s_y + q * DZP);
+                    }
+                }
+                dst = part ? s_aux : s_g;
+                __syncthreads();
+                if (r < npad) {
+#pragma unroll
+                    for (int j = 0; j < DZP; ++j) dst[r * DZP + j] = acc[j];
+                }
+                __syncthreads();
+                for (int e = tid; e < npad * DZP; e += VJF_CHOL_THREADS) {
+                    const int rw = e / DZP, j = e - rw * DZP;
+                    const float w = s_g[e] + s_aux[e];
+                    s_g[e] = w;
+                    if (rw < n && j < dz) Wm[(size_t)rw * dz + j] = w;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (warm || st) {                                                  // residual needs W in LDS
+        for (int e = tid; e < npad * DZP; e += VJF_CHOL_THREADS) {
+            const int r = e / DZP, j = e - r * DZP;
+            s_g[e] = (r < n && j < dz) ? Wm[(size_t)r * dz + j] : 0.f;
+        }
+        __syncthreads();
+    }
+    VJF_STAMP(7);
+    // ---- residual mean square:  sum|dx|^2 - 2 tr(W^T FDX) + tr(W^T G W), fp64 accumulation (model.py:373-374).
+    //      thread (i, part) forms half of row i of G W:  G row chunks as float4 (8 in flight), W rows broadcast
+    double part_sum = 0.0;
+    {
+        const int i = tid & 255, part = tid >> 8;
+        if (i < n) {
+            float acc[DZP];
+#pragma unroll
+            for (int j = 0; j < DZP; ++j) acc[j] = 0.f;
+            const int half = (n / 4 + 1) / 2 * 4;                      // columns [0,half) and [half,n), multiples of 4
+            const int c0 = part ? half : 0, c1 = part ? n : half;
+            const float* grow = G + (size_t)i * n;
+            for (int cb = c0; cb < c1; cb += 32) {
+                float4 gv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) gv[q] = (cb + 4 * q < c1) ? *reinterpret_cast<const float4*>(grow + cb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = cb + 4 * q;
+                    if (c < c1) {
+                        axpy_row<DZP>(acc, gv[q].x, s_g + c * DZP);
+                        axpy_row<DZP>(acc, gv[q].y, s_g + (c + 1) * DZP);
+                        axpy_row<DZP>(acc, gv[q].z, s_g + (c + 2) * DZP);
+                        axpy_row<DZP>(acc, gv[q].w, s_g + (c + 3) * DZP);
+                    }
+                }
+            }
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < DZP; ++j) q = fmaf(s_g[i * DZP + j], acc[j], q);
+            part_sum = (double)q;
+            if (part == 0) {
+                float f = 0.f;
+                for (int j = 0; j < dz; ++j) f = fmaf(s_g[i * DZP + j], FDX[(size_t)i * dz + j], f);
+                part_sum -= 2.0 * (double)f;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part_sum += __shfl_xor(part_sum, o, 64);
+    if (lane == 0) s_d[wave] = part_sum;
+    __syncthreads();
+    if (tid == 0) {
+        double t = (double)A.red[P.red_SC + RS_SDX2];
+        for (int w = 0; w < VJF_CHOL_THREADS / 64; ++w) t += s_d[w];
+        if (t < 0.0) t = 0.0;
+        const float mse = (float)(t / ((double)Bf * (double)dz));
+        const float acc = fminf(SC[VJF_SC_N_TR], 500.f), tot = acc + Bf;   // running_var, size_cap=500 (model.py:375)
+        S[P.off[VJF_SLOT_TR_LOGVAR]] = logf((acc / tot) * expf(sig) + (Bf / tot) * mse);
+        SC[VJF_SC_N_TR] = tot;
+        if (st) SC[VJF_SC_STATUS] = (float)((unsigned)SC[VJF_SC_STATUS] | st);
+    }
+    VJF_STAMP(8);
+}
