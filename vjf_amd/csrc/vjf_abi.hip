@@ -15,6 +15,7 @@
 #include "vjf_plan.h"
 #include "vjf_serial_kernel.h"
 #include "vjf_trial_kernel.h"
+#include "vjf_trial_mfma_kernel.h"
 
 namespace {
 
@@ -88,7 +89,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t E, ACT, DEL, partial, slabs, red, work, jobs, total;
+    size_t E, ACT, DEL, partial, slabs, red, work, jobs, aux, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -103,6 +104,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.red = take((size_t)P.red_len * 4);
     c.work = take(vjf_serial_work_floats(P) * 4 + 256);   // + 32 u64 diagnostic stamps
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
+    c.aux = take((size_t)P.aux_len * 4);
     c.total = o;
     return c;
 }
@@ -128,6 +130,8 @@ struct vjf_ctx {
     int njobs;
     int TB;
     size_t lds_k1, lds_k2;
+    bool mfma_trial;       // 16 trials' working set fits LDS: matrix-core trial kernel
+    size_t lds_k1m;
     bool stamps;           // diagnostic: record s_memtime phase stamps in the serial kernel
     bool fast_chol;        // n_rbf <= 224: prep kernel + LDS-resident MFMA Cholesky; else the generic serial kernel
     size_t lds_chol;
@@ -196,12 +200,15 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->stream = (hipStream_t)stream; c->cv = cv; c->njobs = (int)jobs.size(); c->TB = TB;
     c->lds_k1 = vjf_trial_lds_floats(P, TB) * 4; c->lds_k2 = lds_k2;
     c->fast_chol = fast_chol; c->lds_chol = vjf_chol_lds_bytes(P); c->stamps = false;
+    c->lds_k1m = vjf_trial_mfma_lds_floats(P) * 4;
+    c->mfma_trial = c->lds_k1m <= kMaxLds - 1024;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs` (host) must outlive the copy
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
     allow_lds(vjf_trial_kernel<16>, c->lds_k1); allow_lds(vjf_trial_kernel<8>, c->lds_k1); allow_lds(vjf_trial_kernel<4>, c->lds_k1);
     allow_lds(vjf_serial_kernel, c->lds_k2);
+    if (c->mfma_trial) allow_lds(vjf_trial_mfma_kernel, c->lds_k1m);
     allow_lds(vjf_chol_lds_kernel<4>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<8>, c->lds_chol);
     allow_lds(vjf_chol_lds_kernel<12>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<16>, c->lds_chol);
     allow_lds(vjf_chol_lds_kernel<32>, c->lds_chol);
@@ -248,13 +255,21 @@ int vjf_reduce_buffer(vjf_ctx* ctx, float** ptr, int64_t* n_floats) {
     return 0;
 }
 
-int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
-                     const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags) {
-    if (!c) return fail(-1, "vjf_filter_local: null context");
-    if (B < 1 || B > c->cfg.max_batch) return fail(-20, "vjf_filter_local: B=%d outside [1, max_batch=%d]", B, c->cfg.max_batch);
-    if (!y || !eps_s || !eps_t || !mu_t || !lv_t) return fail(-1, "vjf_filter_local: null tensor");
-    if (c->plan.du > 0 && !u) return fail(-21, "vjf_filter_local: u is required when udim > 0");
-    if ((mu_s == nullptr) != (lv_s == nullptr)) return fail(-22, "vjf_filter_local: mu_s and lv_s must both be given or both be null");
+namespace {
+int refresh_aux(vjf_ctx* c) {
+    if (!c->mfma_trial) return 0;
+    hipLaunchKernelGGL(vjf_aux_kernel, dim3(32), dim3(256), 0, c->stream, c->plan, (const float*)c->state, (float*)(c->ws + c->cv.aux));
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+// K1 + Gram + slab reduce.  `aux_fresh`: the transposed weight copies are known to match the state blob.
+int launch_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
+                 const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags, bool aux_fresh) {
+    if (B < 1 || B > c->cfg.max_batch) return fail(-20, "vjf_filter: B=%d outside [1, max_batch=%d]", B, c->cfg.max_batch);
+    if (!y || !eps_s || !eps_t || !mu_t || !lv_t) return fail(-1, "vjf_filter: null tensor");
+    if (c->plan.du > 0 && !u) return fail(-21, "vjf_filter: u is required when udim > 0");
+    if ((mu_s == nullptr) != (lv_s == nullptr)) return fail(-22, "vjf_filter: mu_s and lv_s must both be given or both be null");
     const VjfPlan& P = c->plan;
     VjfTrialArgs a{};
     a.y = y; a.u = u; a.mu_s = mu_s; a.lv_s = lv_s; a.eps_s = eps_s; a.eps_t = eps_t; a.mu_t = mu_t; a.lv_t = lv_t;
@@ -262,11 +277,20 @@ int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, cons
     a.E = (float*)(c->ws + c->cv.E); a.ACT = (float*)(c->ws + c->cv.ACT); a.DEL = (float*)(c->ws + c->cv.DEL);
     a.partial = (float*)(c->ws + c->cv.partial);
     a.B = B; a.flags = flags;
-    const int nblk = (B + c->TB - 1) / c->TB;
-    switch (c->TB) {
-        case 16: hipLaunchKernelGGL(vjf_trial_kernel<16>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
-        case 8: hipLaunchKernelGGL(vjf_trial_kernel<8>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
-        default: hipLaunchKernelGGL(vjf_trial_kernel<4>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
+    int nblk;
+    if (c->mfma_trial) {
+        if (!aux_fresh) { int rc = refresh_aux(c); if (rc) return rc; }
+        VjfTrialMfmaArgs m{};
+        m.t = a; m.aux = (const float*)(c->ws + c->cv.aux);
+        nblk = (B + 15) / 16;
+        hipLaunchKernelGGL(vjf_trial_mfma_kernel, dim3(nblk), dim3(256), c->lds_k1m, c->stream, P, m);
+    } else {
+        nblk = (B + c->TB - 1) / c->TB;
+        switch (c->TB) {
+            case 16: hipLaunchKernelGGL(vjf_trial_kernel<16>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
+            case 8: hipLaunchKernelGGL(vjf_trial_kernel<8>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
+            default: hipLaunchKernelGGL(vjf_trial_kernel<4>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
+        }
     }
     VJF_HIP(hipGetLastError());
     const int nsplit = split_for(B);
@@ -285,6 +309,13 @@ int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, cons
     VJF_HIP(hipGetLastError());
     return 0;
 }
+}  // namespace
+
+int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
+                     const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags) {
+    if (!c) return fail(-1, "vjf_filter_local: null context");
+    return launch_local(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags, false);
+}
 
 int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_global: null context");
@@ -293,6 +324,7 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
         const VjfPlan& P = c->plan;
         VjfPrepArgs p{};
         p.state = c->state; p.red = (const float*)(c->ws + c->cv.red); p.gbuf = (float*)(c->ws + c->cv.work);
+        p.aux = (float*)(c->ws + c->cv.aux);
         p.loss4 = loss4; p.B_total = B_total; p.flags = flags;
         p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
         p.n_sgdblk = (P.train_len + 1023) / 1024;
@@ -337,8 +369,13 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
     const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
     const float* ms = mu0; const float* ls = lv0;
     for (int t = 0; t < T; ++t) {
-        int rc = vjf_filter_step(c, B, y + t * sy, u ? u + t * su : nullptr, ms, ls, eps + (size_t)t * 2 * sz,
-                                 eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, loss ? loss + 4 * (size_t)t : nullptr, flags);
+        // the prep kernel keeps the transposed weight copies current inside a sequence; the generic
+        // serial kernel does not, so that path refreshes them every step
+        const bool fresh = t > 0 && c->fast_chol;
+        int rc = launch_local(c, B, y + t * sy, u ? u + t * su : nullptr, ms, ls, eps + (size_t)t * 2 * sz,
+                              eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags, fresh);
+        if (rc) return rc;
+        rc = vjf_filter_global(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags);
         if (rc) return rc;
         ms = mu + t * sz; ls = lv + t * sz;
     }

@@ -21,13 +21,14 @@
 
 #define VJF_CHOL_THREADS 512
 #define VJF_CHOL_MAXBLK 7                 // n <= 224
-#define VJF_PREP_ROWS 8                   // rows of P per prep workgroup
+#define VJF_PREP_ROWS 1                   // rows of P per prep workgroup
 
 // ---------------------------------------------------------------------------------------------
 struct VjfPrepArgs {
     float* state;
     const float* red;
     float* gbuf;          // (n, dz) g = P W + FDX / v
+    float* aux;           // transposed weight copies, kept in step with the SGD update
     float* loss4;
     int B_total;
     unsigned flags;
@@ -46,45 +47,52 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
     const bool ok_r = isfinite(l_recon), ok_d = isfinite(l_dyn), ok_h = isfinite(ent);
     const bool grad_ok = ok_r && ok_h && (warm || ok_d);       // see vjf_serial_kernel / DESIGN.md
 
-    if (bid < A.n_rowblk) {                                    // ---- RLS operands, VJF_PREP_ROWS rows of P each
+    if (bid < A.n_rowblk) {                                    // ---- RLS operands: one row of P per workgroup
         if (!do_upd || warm) return;
-        __shared__ float s_g[VJF_PREP_ROWS * 64];
-        const int n = P.n, dz = P.dz;
-        const int i0 = bid * VJF_PREP_ROWS;
+        __shared__ float s_part[4 * 32];
+        const int n = P.n, dz = P.dz, i = bid;
         const float inv_v = expf(-S[P.off[VJF_SLOT_TR_LOGVAR]]);
         float* Pm = S + P.off[VJF_SLOT_W_PREC];
         const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
         const float* G = A.red + P.red_G;
         const float* FDX = A.red + P.red_FDX;
-        // g rows: 32 lanes per output split k, then a 32-lane xor reduction
-        const int lane = tid & 31, grp = tid >> 5;               // 8 groups of 32 lanes
-        for (int o = grp; o < VJF_PREP_ROWS * dz; o += 8) {
-            const int i = i0 + o / dz, j = o % dz;
-            float acc = 0.f;
-            if (i < n) for (int k = lane; k < n; k += 32) acc = fmaf(Pm[(size_t)i * n + k], Wm[(size_t)k * dz + j], acc);
+        // g[i][:] = sum_k P[i][k] W[k][:] : thread k (n <= 224 < 256 on this path) holds one term per output,
+        // then wave + workgroup reduction
+        const int k = tid;
+        float p = 0.f;
+        if (k < n) {
+            p = Pm[(size_t)i * n + k];
+            Pm[(size_t)i * n + k] = p + G[(size_t)i * n + k] * inv_v;      // P += Phi^T Phi / v (module.py:96)
+        }
+        for (int j = 0; j < dz; ++j) {
+            float v = (k < n) ? p * Wm[(size_t)k * dz + j] : 0.f;
 #pragma unroll
-            for (int s = 16; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
-            if (lane == 0 && i < n) A.gbuf[(size_t)i * dz + j] = acc + FDX[(size_t)i * dz + j] * inv_v;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((tid & 63) == 0) s_part[(tid >> 6) * 32 + j] = v;
         }
-        __syncthreads();                                       // all reads of the old rows done
-        for (int e = tid; e < VJF_PREP_ROWS * n; e += 256) {
-            const int i = i0 + e / n, k = e % n;
-            if (i < n) Pm[(size_t)i * n + k] = Pm[(size_t)i * n + k] + G[(size_t)i * n + k] * inv_v;
-        }
-        (void)s_g;
+        __syncthreads();
+        if (tid < dz) A.gbuf[(size_t)i * dz + tid] = ((s_part[tid] + s_part[32 + tid]) + s_part[64 + tid]) + s_part[96 + tid] + FDX[(size_t)i * dz + tid] * inv_v;
         return;
     }
-    if (bid < A.n_rowblk + A.n_sgdblk) {                       // ---- clip + SGD on the trainable region
+    if (bid < A.n_rowblk + A.n_sgdblk) {                       // ---- clip + SGD, tensor by tensor; transposed copies follow
         if (!(do_sgd && grad_ok)) return;
         const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
         const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
-        const int dec_rel = P.dec_off - P.train_off;
-        for (int i = (bid - A.n_rowblk) * 256 + tid; i < P.train_len; i += A.n_sgdblk * 256) {
-            const bool dec = i >= dec_rel;
-            if (dec && freeze) continue;
-            float g = A.red[i] * invB;
-            g = fminf(fmaxf(g, -1.f), 1.f);
-            S[P.train_off + i] -= (dec ? lr_dec : lr_rec) * g;
+        const int g0 = (bid - A.n_rowblk) * 256 + tid, gs = A.n_sgdblk * 256;
+        for (int t = 0; t < P.n_train; ++t) {
+            if (P.tr_dec[t] && freeze) continue;
+            const float lr = P.tr_dec[t] ? lr_dec : lr_rec;
+            const int rows = P.tr_rows[t], cols = P.tr_cols[t], off = P.tr_off[t];
+            for (int e = g0; e < rows * cols; e += gs) {
+                float g = A.red[off - P.train_off + e] * invB;
+                g = fminf(fmaxf(g, -1.f), 1.f);
+                const float w = S[off + e] - lr * g;
+                S[off + e] = w;
+                if (P.tr_aux[t] >= 0) {
+                    const int r = e / cols, c = e - r * cols;
+                    A.aux[P.tr_aux[t] + (size_t)c * P.tr_auxld[t] + P.tr_auxcol[t] + r] = w;
+                }
+            }
         }
         return;
     }

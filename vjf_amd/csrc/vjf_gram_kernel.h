@@ -38,8 +38,21 @@ __global__ __launch_bounds__(256) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A)
     vjf_f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // wave w takes trials k_begin + 8*j + 2*w + {0,1}
-    for (int k = k_begin + 2 * wave + kh; k < k_end + kh; k += 8) {
+    // wave w takes trials k_begin + 8*j + 2*w + {0,1}; 8 steps' operands (16 loads) are in flight before the first MFMA
+    int k = k_begin + 2 * wave + kh;
+    for (; k + 56 < k_end + kh; k += 64) {
+        float a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int kq = k + 8 * q;
+            const bool kok = kq < k_end;
+            a[q] = (kok && xok) ? xp[(size_t)kq * ldx] : 0.f;
+            b[q] = (kok && yok) ? yp[(size_t)kq * ldy] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+    }
+    for (; k < k_end + kh; k += 8) {
         const bool kok = k < k_end;
         const float a = (kok && xok) ? xp[(size_t)k * ldx] : 0.f;
         const float b = (kok && yok) ? yp[(size_t)k * ldy] : 0.f;
@@ -92,7 +105,15 @@ __global__ __launch_bounds__(256) void vjf_gram_reduce_kernel(VjfPlan P, VjfRedu
     const float* slab = A.slabs + (size_t)blockIdx.x * A.nsplit * 1024;
     for (int e = tid; e < 1024; e += 256) {
         float v = 0.f;
-        for (int s = 0; s < A.nsplit; ++s) v += slab[(size_t)s * 1024 + e];
+        int s = 0;
+        for (; s + 8 <= A.nsplit; s += 8) {                      // 8 independent loads, summed in split order
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = slab[(size_t)(s + q) * 1024 + e];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += t[q];
+        }
+        for (; s < A.nsplit; ++s) v += slab[(size_t)s * 1024 + e];
         const int i = e >> 5, j = e & 31;
         if (i >= job.xn || j >= job.yn) continue;
         if (job.kind == 0) {

@@ -31,6 +31,18 @@ struct VjfPlan {
     int colD_dmu, colD_dlv, colD_dpy;
     // reduce buffer (fp32 elements): [ grad (train_len) | G (n*n) | FDX (n*dz) | scalars (8) ]
     int red_G, red_FDX, red_SC, red_len;
+    // "aux": k-major (transposed) copies of the weights whose torch layout is output-major, so that the
+    // MFMA A-operand of the forward products is read in 64-byte row segments.  Workspace, fp32 elements.
+    //   aux_recT[l] : (h_{l-1}, h_l)      = rec_W[l]^T
+    //   aux_headT   : (h_L, 2 dz)         = [mean_W ; lv_W]^T
+    //   aux_decT    : (dz, dy)            = dec_W^T
+    int aux_recT[VJF_MAX_HIDDEN], aux_headT, aux_decT, aux_len;
+    // trainable tensors for the SGD sweep: offset in the blob, rows, cols, aux destination
+    int n_train;
+    int tr_off[2 * VJF_MAX_HIDDEN + 5], tr_rows[2 * VJF_MAX_HIDDEN + 5], tr_cols[2 * VJF_MAX_HIDDEN + 5];
+    int tr_aux[2 * VJF_MAX_HIDDEN + 5];      // -1: none; else aux[tr_aux + c * tr_auxld + tr_auxcol + r]
+    int tr_auxld[2 * VJF_MAX_HIDDEN + 5], tr_auxcol[2 * VJF_MAX_HIDDEN + 5];
+    int tr_dec[2 * VJF_MAX_HIDDEN + 5];      // 1: decoder group (lr_dec, freeze flag)
 };
 
 // reduce-buffer scalars
@@ -112,6 +124,30 @@ static inline int vjf_make_plan(const vjf_config* c, VjfPlan* p) {
     p->red_SC = (int)r; r += RS_N;
     if (r > 0x7fffffff) return -6;
     p->red_len = (int)r;
+    // aux layout + trainable-tensor table
+    int64_t a = 0;
+    int nt = 0;
+    auto add = [&](int slot, int rows, int cols, int aux, int auxld, int auxcol, int dec) {
+        p->tr_off[nt] = p->off[slot]; p->tr_rows[nt] = rows; p->tr_cols[nt] = cols;
+        p->tr_aux[nt] = aux; p->tr_auxld[nt] = auxld; p->tr_auxcol[nt] = auxcol; p->tr_dec[nt] = dec; ++nt;
+    };
+    int prevw = p->din;
+    for (int k = 0; k < VJF_MAX_HIDDEN; ++k) p->aux_recT[k] = 0;
+    for (int k = 0; k < p->L; ++k) {
+        p->aux_recT[k] = (int)a; a = vjf_align(a + (int64_t)prevw * p->h[k], 4);
+        add(VJF_SLOT_REC_W0 + 2 * k, p->h[k], prevw, p->aux_recT[k], p->h[k], 0, 0);
+        add(VJF_SLOT_REC_B0 + 2 * k, p->h[k], 1, -1, 0, 0, 0);
+        prevw = p->h[k];
+    }
+    p->aux_headT = (int)a; a = vjf_align(a + (int64_t)prevw * 2 * p->dz, 4);
+    add(VJF_SLOT_MEAN_W, p->dz, prevw, p->aux_headT, 2 * p->dz, 0, 0);
+    add(VJF_SLOT_LV_W, p->dz, prevw, p->aux_headT, 2 * p->dz, p->dz, 0);
+    add(VJF_SLOT_LV_B, p->dz, 1, -1, 0, 0, 0);
+    p->aux_decT = (int)a; a = vjf_align(a + (int64_t)p->dz * p->dy, 4);
+    add(VJF_SLOT_DEC_W, p->dy, p->dz, p->aux_decT, p->dy, 0, 1);
+    add(VJF_SLOT_DEC_B, p->dy, 1, -1, 0, 0, 1);
+    p->aux_len = (int)a;
+    p->n_train = nt;
     return 0;
 }
 

@@ -372,5 +372,6 @@ __global__ __launch_bounds__(VJF_K2_THREADS) void vjf_serial_kernel(VjfPlan P, V
         SC[VJF_SC_N_LIK] = n_lik;
         SC[VJF_SC_N_TR] = n_tr;
         if (st) SC[VJF_SC_STATUS] = (float)((unsigned)SC[VJF_SC_STATUS] | st);
+        if (do_upd && !warm && !(st & VJF_STATUS_RLS_FAILED)) SC[VJF_SC_TRI_CLEAN] = 1.f;   // w_chol / w_pchol fully rewritten
     }
 }

@@ -1,0 +1,407 @@
+// vjf_trial_mfma_kernel.h -- K1 on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+//
+// Same contract as vjf_trial_kernel (see vjf_trial_kernel.h for the reference citations); this
+// version is used when 16 trials' working set fits LDS.  One workgroup = 4 wavefronts = 16 trials.
+// Every dense product is evaluated transposed, out^T (features x 16 trials) = A (features x K) *
+// X^T (K x 16 trials), so that
+//   * the trial index sits on the MFMA column (lane & 15): per-trial reductions stay inside a lane,
+//   * the B operand is the LDS-resident activation matrix, stored feature-major [feature][17]
+//     (17 = 16 trials + 1 pad word: operand reads and transposed copies are bank-conflict free),
+//   * the A operand comes straight from L2 in "k-major" matrices (row k contiguous over features),
+//     64-byte segments per k: w_chol, w_mean and the backward weights already have that layout,
+//     the forward weights are read from their transposed copies in the aux buffer.
+// w_chol is upper triangular (module.py:102), so variance tile j0 only runs k <= j0 + 15.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vjf_plan.h"
+#include "vjf_trial_kernel.h"      // VjfTrialArgs, group_sum
+
+#define VJF_LDT 17
+typedef float vjf_f32x4 __attribute__((ext_vector_type(4)));
+
+// acc(row = 4*(lane>>4)+r, col = lane&15) += sum_{k<K} Ag[k*lda + m0 + row] * Xs[k*17 + col]
+// rows m0+i >= M contribute 0.
+__device__ __forceinline__ void mma_tile(vjf_f32x4& acc, const float* __restrict__ Ag, int lda, int M, int m0,
+                                         const float* Xs, int K, int lane) {
+    const int i = lane & 15, kk = lane >> 4;
+    const bool rv = (m0 + i) < M;
+    const float* ap = Ag + m0 + i + (size_t)kk * lda;
+    const float* xp = Xs + kk * VJF_LDT + i;
+    const int K4 = K & ~3, K32 = K & ~31;
+    int k0 = 0;
+    for (; k0 < K32; k0 += 32) {                       // 8 steps: all 16 operand loads are issued before the first MFMA
+        float a[8], x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            a[q] = rv ? ap[(size_t)(k0 + 4 * q) * lda] : 0.f;
+            x[q] = xp[(k0 + 4 * q) * VJF_LDT];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], x[q], acc, 0, 0, 0);
+    }
+    for (; k0 < K4; k0 += 4) {
+        const float a = rv ? ap[(size_t)k0 * lda] : 0.f;
+        const float x = xp[k0 * VJF_LDT];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x, acc, 0, 0, 0);
+    }
+    if (K4 < K) {
+        const bool kv = (K4 + kk) < K;
+        const float a = (rv && kv) ? ap[(size_t)K4 * lda] : 0.f;
+        const float x = kv ? xp[K4 * VJF_LDT] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x, acc, 0, 0, 0);
+    }
+}
+
+struct VjfTrialMfmaArgs {
+    VjfTrialArgs t;
+    const float* aux;      // transposed weights (VjfPlan::aux_*)
+};
+
+static inline size_t vjf_trial_mfma_lds_floats(const VjfPlan& P) {
+    const size_t feat = (size_t)P.din + P.dxu + P.n + P.hsum + 2 * (size_t)P.hmax + 8 * (size_t)P.dz + 2 * (size_t)P.dy;
+    return feat * VJF_LDT + 16 * RS_N + 4 * 16 + 16 + 64;
+}
+
+__global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrialMfmaArgs AA) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const VjfTrialArgs& A = AA.t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * 16;
+    const int nb = min(16, A.B - b0);
+    const int dz = P.dz, dy = P.dy, du = P.du, n = P.n, din = P.din, dxu = P.dxu;
+    const float* S = A.state;
+    const bool prior = (A.mu_s == nullptr);
+    const bool warm = (A.flags & VJF_FLAG_WARM_UP) != 0;
+    const bool tri = S[P.off[VJF_SLOT_SCALARS] + VJF_SC_TRI_CLEAN] != 0.f;   // w_chol known upper triangular
+    constexpr int LD = VJF_LDT;
+
+    // ---- LDS carve: feature-major [feature][17] matrices
+    float* s_in = smem;                          // din   [y | u | mu_s | lv_s]
+    float* s_xu = s_in + din * LD;               // dxu   [xs | u]
+    float* s_phi = s_xu + dxu * LD;              // n
+    float* s_act = s_phi + n * LD;               // hsum  hidden activations, layer after layer
+    float* s_d0 = s_act + P.hsum * LD;           // hmax  deltas (ping)
+    float* s_d1 = s_d0 + P.hmax * LD;            // hmax  deltas (pong)
+    float* s_mu = s_d1 + P.hmax * LD;            // dz    mu_t
+    float* s_lv = s_mu + dz * LD;                // dz    lv_t   (directly after s_mu: the heads write 2dz rows)
+    float* s_xt = s_lv + dz * LD;                // dz
+    float* s_e2 = s_xt + dz * LD;                // dz    eps_t
+    float* s_pm = s_e2 + dz * LD;                // dz    pt.mean
+    float* s_dmu = s_pm + dz * LD;               // dz
+    float* s_dlv = s_dmu + dz * LD;              // dz    (directly after s_dmu)
+    float* s_dxt = s_dlv + dz * LD;              // dz
+    float* s_py = s_dxt + dz * LD;               // dy
+    float* s_dpy = s_py + dy * LD;               // dy
+    float* s_sc = s_dpy + dy * LD;               // 16 x RS_N per-trial scalars
+    float* s_red = s_sc + 16 * RS_N;             // 4 x 16 variance partials
+    float* s_plv = s_red + 64;                   // 16 pt.logvar
+
+    // ---- stage 0: inputs (coalesced global reads, transposed LDS writes), eps_t, xs
+    for (int e = tid; e < 16 * din; e += 256) {
+        const int b = e / din, c = e - b * din;
+        float v = 0.f;
+        if (b < nb) {
+            const size_t g = (size_t)(b0 + b);
+            if (c < dy) v = A.y[g * dy + c];
+            else if (c < dy + du) v = A.u[g * du + (c - dy)];
+            else if (c < dy + du + dz) { const int j = c - dy - du; v = prior ? S[P.off[VJF_SLOT_PRIOR_MEAN] + j] : A.mu_s[g * dz + j]; }
+            else { const int j = c - dy - du - dz; v = prior ? S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j] : A.lv_s[g * dz + j]; }
+        }
+        s_in[c * LD + b] = v;
+    }
+    for (int e = tid; e < 16 * dz; e += 256) {
+        const int b = e / dz, j = e - b * dz;
+        s_e2[j * LD + b] = (b < nb) ? A.eps_t[(size_t)(b0 + b) * dz + j] : 0.f;
+        s_xt[j * LD + b] = (b < nb) ? A.eps_s[(size_t)(b0 + b) * dz + j] : 0.f;      // eps_s parked in s_xt
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * dxu; e += 256) {
+        const int c = e >> 4, b = e & 15;
+        float v;
+        if (c < dz) v = fmaf(s_xt[c * LD + b], expf(0.5f * s_in[(dy + du + dz + c) * LD + b]), s_in[(dy + du + c) * LD + b]);
+        else v = s_in[(dy + c - dz) * LD + b];
+        s_xu[c * LD + b] = v;
+    }
+    __syncthreads();
+
+    // ---- stage 1: RBF features (functional.py:11-22); lanes walk the trial index
+    {
+        const float* cen = S + P.off[VJF_SLOT_CENTROID];
+        const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
+        for (int e = tid; e < 16 * n; e += 256) {
+            const int k = e >> 4, b = e & 15;
+            float d2 = 0.f;
+            for (int c = 0; c < dxu; ++c) { const float d = s_xu[c * LD + b] - cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
+            const float w = expf(lw[k]);
+            s_phi[k * LD + b] = expf(-0.5f * d2 / (w * w));
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
+    {
+        const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
+        const int ntile = (n + 15) >> 4;
+        float v2 = 0.f;
+        // tiles in descending cost, dealt to the 4 wavefronts in a snake so that the triangular work balances
+        for (int r = 0;; ++r) {
+            const int idx = (r & 1) ? r * 4 + 3 - wave : r * 4 + wave;
+            if (idx >= ntile) { if (r * 4 >= ntile) break; else continue; }
+            const int t = ntile - 1 - idx, j0 = t * 16;
+            const int K = tri ? min(n, j0 + 16) : n;
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile(acc, Wc, n, n, j0, s_phi, K, lane);
+            v2 = fmaf(acc[0], acc[0], fmaf(acc[1], acc[1], fmaf(acc[2], acc[2], fmaf(acc[3], acc[3], v2))));
+        }
+        v2 += __shfl_xor(v2, 16, 64);
+        v2 += __shfl_xor(v2, 32, 64);
+        if (lane < 16) s_red[wave * 16 + lane] = v2;
+        // mean tiles, dealt from the last wavefront backwards (it has the lightest variance share)
+        const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
+        const int mt = (dz + 15) >> 4;
+        for (int t = 3 - wave; t < mt; t += 4) {
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile(acc, Wm, dz, dz, t * 16, s_phi, n, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = t * 16 + 4 * (lane >> 4) + r, b = lane & 15;
+                if (j < dz) s_pm[j * LD + b] = s_xu[j * LD + b] + acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 16) s_plv[tid] = logf(((s_red[tid] + s_red[16 + tid]) + s_red[32 + tid]) + s_red[48 + tid]);
+
+    // ---- stage 3: recognition forward (recognition.py:31-42)
+    {
+        const float* xin = s_in;
+        int kin = din, aoff = 0;
+        for (int l = 0; l < P.L; ++l) {
+            const float* WT = AA.aux + P.aux_recT[l];                  // (kin, hl)
+            const float* bias = S + P.off[VJF_SLOT_REC_B0 + 2 * l];
+            float* out = s_act + aoff * LD;
+            const int hl = P.h[l], mt = (hl + 15) >> 4;
+            for (int t = wave; t < mt; t += 4) {
+                vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                mma_tile(acc, WT, hl, hl, t * 16, xin, kin, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = t * 16 + 4 * (lane >> 4) + r;
+                    if (f < hl) out[f * LD + (lane & 15)] = tanhf(acc[r] + bias[f]);
+                }
+            }
+            __syncthreads();
+            xin = out; kin = hl; aoff += hl;
+        }
+        const float* HT = AA.aux + P.aux_headT;                        // (hL, 2dz): mean rows then logvar rows
+        const float* bl = S + P.off[VJF_SLOT_LV_B];
+        const int mt = (2 * dz + 15) >> 4;
+        for (int t = wave; t < mt; t += 4) {
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile(acc, HT, 2 * dz, 2 * dz, t * 16, xin, kin, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = t * 16 + 4 * (lane >> 4) + r;
+                if (f < 2 * dz) s_mu[f * LD + (lane & 15)] = acc[r] + (f >= dz ? bl[f - dz] : 0.f);   // rows dz.. land in s_lv
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 4: xt, posterior outputs, py = xt C^T + d (model.py:28-30)
+    for (int e = tid; e < 16 * dz; e += 256) {
+        const int j = e >> 4, b = e & 15;
+        s_xt[j * LD + b] = fmaf(s_e2[j * LD + b], expf(0.5f * s_lv[j * LD + b]), s_mu[j * LD + b]);
+    }
+    for (int e = tid; e < nb * dz; e += 256) {                          // coalesced posterior stores
+        const int b = e / dz, j = e - b * dz;
+        A.mu_t[(size_t)(b0 + b) * dz + j] = s_mu[j * LD + b];
+        A.lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
+    }
+    __syncthreads();
+    {
+        const float* CT = AA.aux + P.aux_decT;                         // (dz, dy)
+        const float* d = S + P.off[VJF_SLOT_DEC_B];
+        const int mt = (dy + 15) >> 4;
+        for (int t = wave; t < mt; t += 4) {
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile(acc, CT, dy, dy, t * 16, s_xt, dz, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = t * 16 + 4 * (lane >> 4) + r;
+                if (f < dy) s_py[f * LD + (lane & 15)] = acc[r] + d[f];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
+    {
+        const int b = tid >> 4, s = tid & 15;
+        const float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
+        const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
+        float lrec = 0.f, ssey = 0.f;
+        if (P.lik == VJF_LIK_GAUSSIAN) {                               // likelihood.py:19-26, functional.py:54-73
+            const float p = expf(-0.5f * rho), e = expf(-rho);
+            for (int i = s; i < dy; i += 16) {
+                const float yv = s_in[i * LD + b], pv = s_py[i * LD + b];
+                const float r = pv - yv, dsc = yv * p - pv * p;
+                lrec += 0.5f * (dsc * dsc + rho);
+                ssey = fmaf(r, r, ssey);
+                s_dpy[i * LD + b] = e * r;
+            }
+        } else {                                                       // likelihood.py:51-62
+            for (int i = s; i < dy; i += 16) {
+                const float yv = s_in[i * LD + b], pv = s_py[i * LD + b];
+                const float eta = fminf(pv, 10.f), ex = expf(eta);
+                lrec += ex - yv * eta;
+                const float r = pv - yv;
+                ssey = fmaf(r, r, ssey);
+                s_dpy[i * LD + b] = (pv <= 10.f) ? (ex - yv) : 0.f;
+            }
+        }
+        lrec = group_sum<16>(lrec);
+        ssey = group_sum<16>(ssey);
+        float ldyn = 0.f, ent = 0.f, sdx2 = 0.f;
+        {
+            const float p = expf(-0.5f * sig), e = expf(-sig), plv = s_plv[b];
+            for (int j = s; j < dz; j += 16) {                         // model.py:390-391, functional.py:62-75
+                const float mp = s_pm[j * LD + b], mu = s_mu[j * LD + b], lv = s_lv[j * LD + b];
+                const float dsc = mp * p - mu * p;
+                const float tr = expf(plv + lv - sig);
+                ldyn += 0.5f * (dsc * dsc + sig) + 0.5f * tr;
+                ent += 0.5f * lv;                                      // functional.py:25-29
+                const float dx = s_xt[j * LD + b] - s_xu[j * LD + b];
+                sdx2 = fmaf(dx, dx, sdx2);
+                float dmu = 0.f, dlv = -0.5f;
+                if (!warm) { dmu = -e * (mp - mu); dlv += 0.5f * tr; }
+                s_dmu[j * LD + b] = dmu;
+                s_dlv[j * LD + b] = dlv;
+            }
+        }
+        ldyn = group_sum<16>(ldyn);
+        ent = group_sum<16>(ent);
+        sdx2 = group_sum<16>(sdx2);
+        if (s == 0) {
+            const bool ok = b < nb;
+            s_sc[b * RS_N + RS_LRECON] = ok ? lrec : 0.f;
+            s_sc[b * RS_N + RS_LDYN] = ok ? ldyn : 0.f;
+            s_sc[b * RS_N + RS_ENT] = ok ? ent : 0.f;
+            s_sc[b * RS_N + RS_SSEY] = ok ? ssey : 0.f;
+            s_sc[b * RS_N + RS_SDX2] = ok ? sdx2 : 0.f;
+        }
+    }
+    __syncthreads();
+    if (tid < RS_N) {
+        float v = 0.f;
+        if (tid <= RS_SDX2) for (int b = 0; b < 16; ++b) v += s_sc[b * RS_N + tid];
+        A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
+    }
+
+    // ---- stage 6: backward.  dxt = dpy C ; dmu += dxt ; dlv += dxt eps_t exp(lv/2)/2
+    {
+        const float* C = S + P.off[VJF_SLOT_DEC_W];                    // (dy, dz): k-major for this product
+        const int mt = (dz + 15) >> 4;
+        for (int t = wave; t < mt; t += 4) {
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile(acc, C, dz, dz, t * 16, s_dpy, dy, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = t * 16 + 4 * (lane >> 4) + r, b = lane & 15;
+                if (j < dz) {
+                    s_dmu[j * LD + b] += acc[r];
+                    s_dlv[j * LD + b] = fmaf(acc[r] * s_e2[j * LD + b], 0.5f * expf(0.5f * s_lv[j * LD + b]), s_dlv[j * LD + b]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int hL = P.h[P.L - 1];
+        const float* Wm = S + P.off[VJF_SLOT_MEAN_W];                  // (dz, hL): k-major for dh = dmu Wm + dlv Wl
+        const float* Wl = S + P.off[VJF_SLOT_LV_W];
+        const float* hact = s_act + (P.hsum - hL) * LD;
+        int mt = (hL + 15) >> 4;
+        for (int t = wave; t < mt; t += 4) {
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile(acc, Wm, hL, hL, t * 16, s_dmu, dz, lane);
+            mma_tile(acc, Wl, hL, hL, t * 16, s_dlv, dz, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = t * 16 + 4 * (lane >> 4) + r, b = lane & 15;
+                if (k < hL) { const float hv = hact[k * LD + b]; s_d0[k * LD + b] = acc[r] * (1.f - hv * hv); }
+            }
+        }
+        __syncthreads();
+        int aoff = P.hsum - hL;
+        float* cur = s_d0; float* nxt = s_d1;
+        for (int l = P.L - 1; l >= 0; --l) {
+            const int hl = P.h[l];
+            for (int e = tid; e < nb * hl; e += 256) {                  // da_l -> DEL, coalesced over k
+                const int b = e / hl, k = e - b * hl;
+                A.DEL[(size_t)(b0 + b) * P.ldD + P.colD_da[l] + k] = cur[k * LD + b];
+            }
+            if (l > 0) {
+                const int hp = P.h[l - 1];
+                const float* W = S + P.off[VJF_SLOT_REC_W0 + 2 * l];   // (hl, hp): k-major for dh_{l-1} = da_l W
+                const float* hprev = s_act + (aoff - hp) * LD;
+                mt = (hp + 15) >> 4;
+                for (int t = wave; t < mt; t += 4) {
+                    vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    mma_tile(acc, W, hp, hp, t * 16, cur, hl, lane);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = t * 16 + 4 * (lane >> 4) + r, b = lane & 15;
+                        if (k < hp) { const float hv = hprev[k * LD + b]; nxt[k * LD + b] = acc[r] * (1.f - hv * hv); }
+                    }
+                }
+                __syncthreads();
+                float* tmp = cur; cur = nxt; nxt = tmp;
+                aoff -= hp;
+            }
+        }
+    }
+
+    // ---- stage 7: rows of E = [Phi | dx | 0], ACT = [in|1|h_1|1|..|h_L|1|xt|1|0], DEL = [.. | dmu | dlv | dpy]
+    for (int e = tid; e < nb * P.ldE; e += 256) {
+        const int b = e / P.ldE, c = e - b * P.ldE;
+        float v = 0.f;
+        if (c < n) v = s_phi[c * LD + b];
+        else if (c < n + dz) v = s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b];
+        A.E[(size_t)(b0 + b) * P.ldE + c] = v;
+    }
+    for (int e = tid; e < nb * P.ldA; e += 256) {
+        const int b = e / P.ldA, c = e - b * P.ldA;
+        float v = 0.f;
+        if (c < din) v = s_in[c * LD + b];
+        else if (c == din) v = 1.f;
+        else if (c >= P.colA_xt) { const int j = c - P.colA_xt; v = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f); }
+        else {
+            int l = 0, aoff = 0;
+            while (l + 1 < P.L && c >= P.colA_act[l + 2]) { aoff += P.h[l]; ++l; }
+            const int k = c - P.colA_act[l + 1];
+            v = k < P.h[l] ? s_act[(aoff + k) * LD + b] : 1.f;
+        }
+        A.ACT[(size_t)(b0 + b) * P.ldA + c] = v;
+    }
+    for (int e = tid; e < nb * (2 * dz + dy); e += 256) {
+        const int w = 2 * dz + dy, b = e / w, c = e - b * w;
+        float v;
+        if (c < 2 * dz) v = s_dmu[c * LD + b];                          // s_dlv follows s_dmu
+        else v = s_dpy[(c - 2 * dz) * LD + b];
+        A.DEL[(size_t)(b0 + b) * P.ldD + P.colD_dmu + c] = v;
+    }
+}
+
+// Refresh the transposed weight copies from the canonical tensors (run at the start of an API call:
+// the caller may have written the state blob; within a sequence vjf_prep_kernel keeps them in step).
+__global__ void vjf_aux_kernel(VjfPlan P, const float* state, float* aux) {
+    for (int t = 0; t < P.n_train; ++t) {
+        if (P.tr_aux[t] < 0) continue;
+        const int rows = P.tr_rows[t], cols = P.tr_cols[t];
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows * cols; e += gridDim.x * blockDim.x) {
+            const int r = e / cols, c = e - r * cols;
+            aux[P.tr_aux[t] + (size_t)c * P.tr_auxld[t] + P.tr_auxcol[t] + r] = state[P.tr_off[t] + e];
+        }
+    }
+}
