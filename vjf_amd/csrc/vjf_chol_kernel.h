@@ -176,25 +176,28 @@ __device__ __forceinline__ void blk_mma(vjf_f32x16& acc, const float* Ab, const 
 // Nothing but the dependent chain sits inside the column loop; the LDS stores follow it.
 __device__ __forceinline__ bool potrf_inv_chain(vjf_f32x16& acc, float* out, float* inv, int lane) {
     const int c = lane & 31, h = lane >> 5;
-    bool ok = true;
     float lcol[32], xrow[32];
+    float dmin = 3.0e38f, slast = 1.f;
     vjf_f32x16 racc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) racc[r] = (vrow(r, h) == c) ? 1.f : 0.f;
+    // Per column: readlane(pivot) -> rsq -> two scaled rows -> two MFMAs that share the A operand -l.
+    // (The inverse's update also clears its own row j -- R[j] -= L[j][j] X[j] = 0 -- which is never read again.)
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const int rj = (j & 3) + 4 * (j >> 3), hj = (j >> 2) & 1;      // vrow(rj, hj) == j
         const float d = vrl(acc[rj], j + 32 * hj);
-        if (!(d > 0.f) || !(d < 3.0e38f)) ok = false;
         const float s = __builtin_amdgcn_rsqf(d);
+        dmin = fminf(dmin, d);
+        slast = s;
         const bool on = (h == hj);
         const float l = (on && (c >= j)) ? acc[rj] * s : 0.f;           // l[c] = L[c][j]
         const float x = on ? racc[rj] * s : 0.f;                        // x[c] = Linv[j][c]
-        const float lo = (on && (c > j)) ? -l : 0.f;                    // strictly below the pivot
+        const float nl = -l;
         lcol[j] = l;
         xrow[j] = x;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-l, l, acc, 0, 0, 0);
-        racc = __builtin_amdgcn_mfma_f32_32x32x2f32(lo, x, racc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nl, l, acc, 0, 0, 0);
+        racc = __builtin_amdgcn_mfma_f32_32x32x2f32(nl, x, racc, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
@@ -204,7 +207,7 @@ __device__ __forceinline__ bool potrf_inv_chain(vjf_f32x16& acc, float* out, flo
             inv[vsw(j, c)] = (c <= j) ? xrow[j] : 0.f;
         }
     }
-    return ok;
+    return (dmin > 0.f) && (slast == slast) && (fabsf(slast) < 3.0e38f);   // positive pivots, no NaN / inf came through
 }
 
 struct VjfCholArgs {
@@ -479,9 +482,13 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                 for (int j = 0; j < DZP; ++j) acc[j] = 0.f;
                 if (r < npad) {
                     const int br = r >> 5, rr = r & 31;
-                    for (int c = part; c < npad; c += 2) {
-                        const float x = (c <= r) ? s_blk[(size_t)vtri(br, min(c >> 5, br)) * 1024 + vsw(rr, c & 31)] : 0.f;
-                        axpy_row<DZP>(acc, x, s_g + c * DZP);
+                    for (int cb = 0; cb <= br; ++cb) {                  // block (br, cb) of X, 16 columns of this parity
+                        const float* xb = s_blk + (size_t)vtri(br, cb) * 1024;
+                        float xv[16];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) xv[q] = xb[vsw(rr, 2 * q + part)];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) axpy_row<DZP>(acc, xv[q], s_g + (cb * 32 + 2 * q + part) * DZP);
                     }
                 }
                 float* dst = part ? s_aux : s_y;     // s_aux (Dinv) is free now (copied into the diagonal slots)
@@ -496,9 +503,13 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                 for (int j = 0; j < DZP; ++j) acc[j] = 0.f;
                 if (r < npad) {
                     const int bk = r >> 5, kk = r & 31;                 // r plays the role of the column k of X
-                    for (int q = part; q < npad; q += 2) {
-                        const float x = (q >= r) ? s_blk[(size_t)vtri(max(q >> 5, bk), bk) * 1024 + vsw(q & 31, kk)] : 0.f;
-                        axpy_row<DZP>(acc, x, s_y + q * DZP);
+                    for (int rb = bk; rb < nbl; ++rb) {                 // block (rb, bk) of X, 16 rows of this parity
+                        const float* xb = s_blk + (size_t)vtri(rb, bk) * 1024;
+                        float xv[16];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) xv[q] = xb[vsw(2 * q + part, kk)];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) axpy_row<DZP>(acc, xv[q], s_y + (rb * 32 + 2 * q + part) * DZP);
                     }
                 }
                 dst = part ? s_aux : s_g;

@@ -55,7 +55,17 @@ __device__ __forceinline__ void mma_tile(vjf_f32x4& acc, const float* __restrict
 struct VjfTrialMfmaArgs {
     VjfTrialArgs t;
     const float* aux;      // transposed weights (VjfPlan::aux_*)
+    unsigned long long* stamps;   // diagnostic only (null in normal runs)
 };
+
+#define VJF_K1_STAMP(i)                                                                     \
+    do {                                                                                    \
+        if (AA.stamps && blockIdx.x == 0 && threadIdx.x == 0) {                             \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+            AA.stamps[i] = t_;                                                              \
+        }                                                                                   \
+    } while (0)
 
 static inline size_t vjf_trial_mfma_lds_floats(const VjfPlan& P) {
     const size_t feat = (size_t)P.din + P.dxu + P.n + P.hsum + 2 * (size_t)P.hmax + 8 * (size_t)P.dz + 2 * (size_t)P.dy;
@@ -96,6 +106,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     float* s_red = s_sc + 16 * RS_N;             // 4 x 16 variance partials
     float* s_plv = s_red + 64;                   // 16 pt.logvar
 
+    VJF_K1_STAMP(22);
     // ---- stage 0: inputs (coalesced global reads, transposed LDS writes), eps_t, xs
     for (int e = tid; e < 16 * din; e += 256) {
         const int b = e / din, c = e - b * din;
@@ -124,6 +135,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     }
     __syncthreads();
 
+    VJF_K1_STAMP(23);
     // ---- stage 1: RBF features (functional.py:11-22); lanes walk the trial index
     {
         const float* cen = S + P.off[VJF_SLOT_CENTROID];
@@ -138,6 +150,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     }
     __syncthreads();
 
+    VJF_K1_STAMP(24);
     // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
     {
         const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
@@ -172,6 +185,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     __syncthreads();
     if (tid < 16) s_plv[tid] = logf(((s_red[tid] + s_red[16 + tid]) + s_red[32 + tid]) + s_red[48 + tid]);
 
+    VJF_K1_STAMP(25);
     // ---- stage 3: recognition forward (recognition.py:31-42)
     {
         const float* xin = s_in;
@@ -208,6 +222,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     }
     __syncthreads();
 
+    VJF_K1_STAMP(26);
     // ---- stage 4: xt, posterior outputs, py = xt C^T + d (model.py:28-30)
     for (int e = tid; e < 16 * dz; e += 256) {
         const int j = e >> 4, b = e & 15;
@@ -235,6 +250,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     }
     __syncthreads();
 
+    VJF_K1_STAMP(27);
     // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
     {
         const int b = tid >> 4, s = tid & 15;
@@ -298,6 +314,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
     }
 
+    VJF_K1_STAMP(28);
     // ---- stage 6: backward.  dxt = dpy C ; dmu += dxt ; dlv += dxt eps_t exp(lv/2)/2
     {
         const float* C = S + P.off[VJF_SLOT_DEC_W];                    // (dy, dz): k-major for this product
@@ -362,6 +379,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         }
     }
 
+    VJF_K1_STAMP(29);
     // ---- stage 7: rows of E = [Phi | dx | 0], ACT = [in|1|h_1|1|..|h_L|1|xt|1|0], DEL = [.. | dmu | dlv | dpy]
     for (int e = tid; e < nb * P.ldE; e += 256) {
         const int b = e / P.ldE, c = e - b * P.ldE;
@@ -391,6 +409,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         else v = s_dpy[(c - 2 * dz) * LD + b];
         A.DEL[(size_t)(b0 + b) * P.ldD + P.colD_dmu + c] = v;
     }
+    VJF_K1_STAMP(30);
 }
 
 // Refresh the transposed weight copies from the canonical tensors (run at the start of an API call:
