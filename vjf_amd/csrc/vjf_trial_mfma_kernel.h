@@ -108,17 +108,19 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
 
     VJF_K1_STAMP(22);
     // ---- stage 0: inputs (coalesced global reads, transposed LDS writes), eps_t, xs
-    for (int e = tid; e < 16 * din; e += 256) {
-        const int b = e / din, c = e - b * din;
-        float v = 0.f;
-        if (b < nb) {
-            const size_t g = (size_t)(b0 + b);
-            if (c < dy) v = A.y[g * dy + c];
-            else if (c < dy + du) v = A.u[g * du + (c - dy)];
-            else if (c < dy + du + dz) { const int j = c - dy - du; v = prior ? S[P.off[VJF_SLOT_PRIOR_MEAN] + j] : A.mu_s[g * dz + j]; }
-            else { const int j = c - dy - du - dz; v = prior ? S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j] : A.lv_s[g * dz + j]; }
+    for (int b = wave; b < 16; b += 4) {            // wavefront w stages trials w, w+4, ..; the lane walks the columns
+        const bool ok = b < nb;
+        const size_t g = (size_t)(b0 + b);
+        for (int c = lane; c < din; c += 64) {
+            float v = 0.f;
+            if (ok) {
+                if (c < dy) v = A.y[g * dy + c];
+                else if (c < dy + du) v = A.u[g * du + (c - dy)];
+                else if (c < dy + du + dz) { const int j = c - dy - du; v = prior ? S[P.off[VJF_SLOT_PRIOR_MEAN] + j] : A.mu_s[g * dz + j]; }
+                else { const int j = c - dy - du - dz; v = prior ? S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j] : A.lv_s[g * dz + j]; }
+            }
+            s_in[c * LD + b] = v;
         }
-        s_in[c * LD + b] = v;
     }
     for (int e = tid; e < 16 * dz; e += 256) {
         const int b = e / dz, j = e - b * dz;
@@ -138,14 +140,28 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     VJF_K1_STAMP(23);
     // ---- stage 1: RBF features (functional.py:11-22); lanes walk the trial index
     {
+        // centroids and -1/(2 w^2) staged in LDS (the delta buffers are free until the backward pass)
         const float* cen = S + P.off[VJF_SLOT_CENTROID];
         const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
+        float* s_cen = s_d0;                       // n * dxu + n floats needed; available: 2 * hmax * 17
+        float* s_iw = s_cen + n * dxu;
+        const bool stage_c = (n * dxu + n) <= 2 * P.hmax * LD;
+        if (stage_c) {
+            for (int e = tid; e < n * dxu; e += 256) s_cen[e] = cen[e];
+            for (int e = tid; e < n; e += 256) { const float w = expf(lw[e]); s_iw[e] = -0.5f / (w * w); }
+            __syncthreads();
+        }
         for (int e = tid; e < 16 * n; e += 256) {
             const int k = e >> 4, b = e & 15;
             float d2 = 0.f;
-            for (int c = 0; c < dxu; ++c) { const float d = s_xu[c * LD + b] - cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
-            const float w = expf(lw[k]);
-            s_phi[k * LD + b] = expf(-0.5f * d2 / (w * w));
+            if (stage_c) {
+                for (int c = 0; c < dxu; ++c) { const float d = s_xu[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
+                s_phi[k * LD + b] = expf(d2 * s_iw[k]);
+            } else {
+                for (int c = 0; c < dxu; ++c) { const float d = s_xu[c * LD + b] - cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
+                const float w = expf(lw[k]);
+                s_phi[k * LD + b] = expf(-0.5f * d2 / (w * w));
+            }
         }
     }
     __syncthreads();
@@ -380,34 +396,27 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     }
 
     VJF_K1_STAMP(29);
-    // ---- stage 7: rows of E = [Phi | dx | 0], ACT = [in|1|h_1|1|..|h_L|1|xt|1|0], DEL = [.. | dmu | dlv | dpy]
-    for (int e = tid; e < nb * P.ldE; e += 256) {
-        const int b = e / P.ldE, c = e - b * P.ldE;
-        float v = 0.f;
-        if (c < n) v = s_phi[c * LD + b];
-        else if (c < n + dz) v = s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b];
-        A.E[(size_t)(b0 + b) * P.ldE + c] = v;
-    }
-    for (int e = tid; e < nb * P.ldA; e += 256) {
-        const int b = e / P.ldA, c = e - b * P.ldA;
-        float v = 0.f;
-        if (c < din) v = s_in[c * LD + b];
-        else if (c == din) v = 1.f;
-        else if (c >= P.colA_xt) { const int j = c - P.colA_xt; v = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f); }
-        else {
-            int l = 0, aoff = 0;
-            while (l + 1 < P.L && c >= P.colA_act[l + 2]) { aoff += P.h[l]; ++l; }
-            const int k = c - P.colA_act[l + 1];
-            v = k < P.h[l] ? s_act[(aoff + k) * LD + b] : 1.f;
+    // ---- stage 7: rows of E = [Phi | dx | 0], ACT = [in|1|h_1|1|..|h_L|1|xt|1|0], DEL = [.. | dmu | dlv | dpy].
+    //      wavefront w writes the rows of trials w, w+4, ...; the lane walks the columns (coalesced, no divisions)
+    for (int b = wave; b < nb; b += 4) {
+        float* erow = A.E + (size_t)(b0 + b) * P.ldE;
+        for (int c = lane; c < P.ldE; c += 64) {
+            float v = 0.f;
+            if (c < n) v = s_phi[c * LD + b];
+            else if (c < n + dz) v = s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b];
+            erow[c] = v;
         }
-        A.ACT[(size_t)(b0 + b) * P.ldA + c] = v;
-    }
-    for (int e = tid; e < nb * (2 * dz + dy); e += 256) {
-        const int w = 2 * dz + dy, b = e / w, c = e - b * w;
-        float v;
-        if (c < 2 * dz) v = s_dmu[c * LD + b];                          // s_dlv follows s_dmu
-        else v = s_dpy[(c - 2 * dz) * LD + b];
-        A.DEL[(size_t)(b0 + b) * P.ldD + P.colD_dmu + c] = v;
+        float* arow = A.ACT + (size_t)(b0 + b) * P.ldA;
+        for (int c = lane; c <= din; c += 64) arow[c] = c < din ? s_in[c * LD + b] : 1.f;
+        int aoff = 0;
+        for (int l = 0; l < P.L; ++l) {
+            const int hl = P.h[l], c0 = P.colA_act[l + 1];
+            for (int k = lane; k <= hl; k += 64) arow[c0 + k] = k < hl ? s_act[(aoff + k) * LD + b] : 1.f;
+            aoff += hl;
+        }
+        for (int j = lane; P.colA_xt + j < P.ldA; j += 64) arow[P.colA_xt + j] = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f);
+        float* drow = A.DEL + (size_t)(b0 + b) * P.ldD + P.colD_dmu;
+        for (int c = lane; c < 2 * dz + dy; c += 64) drow[c] = c < 2 * dz ? s_dmu[c * LD + b] : s_dpy[(c - 2 * dz) * LD + b];   // s_dlv follows s_dmu
     }
     VJF_K1_STAMP(30);
 }
