@@ -136,8 +136,10 @@ def init_state(ydim, xdim, udim, n_rbf, hidden, likelihood, rng: np.random.Gener
 # --------------------------------------------------------------------------- operators
 def rbf(x: np.ndarray, c: np.ndarray, w: np.ndarray) -> np.ndarray:
     """Gaussian radial basis features  exp(-1/2 (|x-c|/w)^2)   (vjf/functional.py:11-22)."""
-    diff = x[:, None, :] - c[None, :, :]
-    d2 = np.sum(diff * diff, axis=-1)
+    d2 = np.zeros((x.shape[0], c.shape[0]), x.dtype)
+    for j in range(x.shape[1]):                  # one (batch, basis) pass per input dimension: no 3-D temporary
+        diff = x[:, j:j + 1] - c[None, :, j]
+        d2 += diff * diff
     return np.exp(-0.5 * d2 / (w * w)[None, :]).astype(x.dtype)
 
 

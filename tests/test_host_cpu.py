@@ -1,0 +1,155 @@
+"""CPU-only tests of the boundary and the host side of vjf_amd (no GPU, no compute through HIP):
+the library loads and exports the header's symbols, the memory plan is sane, compute fails loudly
+without a device, seeded construction reproduces the reference's parameters, and -- with the
+oracle-backed stand-in of tests/fake_backend.py behind the same C ABI -- the host logic of filter /
+filter_sequence / fit / forecast reproduces the golden vectors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests import fake_backend
+from tests import goldenio as gio
+from tests.helpers import load_fixture_state, state_close
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def close(a, b, **kw):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), **kw)
+
+
+def test_library_exports_every_declared_symbol():
+    from vjf_amd import _native as N
+    hdr = open(os.path.join(ROOT, "include", "vjf_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(vjf_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 20
+    lib = C.CDLL(N.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/vjf_hip.h but not exported"
+    assert declared == set(N.SIGNATURES) | {"vjf_last_error"}, declared ^ (set(N.SIGNATURES) | {"vjf_last_error"})
+    assert lib.vjf_abi_version() == N.ABI_VERSION
+
+
+def test_memory_plan_config_b():
+    from vjf_amd import _native as N
+    cfg = N.make_config(50, 10, 0, 200, [128], N.LIK_GAUSSIAN, 4096)
+    n, off, size = N.state_layout(cfg)
+    assert size[N.SLOT_CENTROID] == 2000 and size[N.SLOT_W_CHOL] == 40000 and size[N.SLOT_REC_W0] == 128 * 70
+    assert all(o % 4 == 0 for o in off)
+    used = sorted((o, s) for o, s in zip(off, size) if s)
+    assert all(a[0] + a[1] <= b[0] for a, b in zip(used, used[1:]))          # slots do not overlap
+    assert used[-1][0] + used[-1][1] <= n
+    assert 1 << 20 < N.workspace_size(cfg) < 1 << 28
+    bad = N.make_config(50, 10, 0, 200, [128], N.LIK_GAUSSIAN, 4096)
+    bad.n_hidden = 0
+    out = C.c_int64()
+    assert N.lib().vjf_state_size(C.byref(bad), C.byref(out)) < 0
+    assert b"invalid config" in N.lib().vjf_last_error()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_compute_fails_loudly_without_gpu():
+    import vjf_amd
+    from vjf_amd._native import VjfError
+    m = vjf_amd.VJF.make_model(10, 3, 0, 16, [8], likelihood="gaussian")
+    with pytest.raises(VjfError):
+        m.filter(torch.randn(4, 10))
+    with pytest.raises(VjfError):
+        vjf_amd.functional.rbf(torch.randn(4, 3), torch.randn(5, 3), torch.ones(5))
+
+
+def test_seeded_construction_matches_reference():
+    """Same construction (RNG consumption) order as vjf/model.py:309-319: bit-identical parameters."""
+    import vjf_amd
+    z = gio.load("g5_seeded_f32")
+    torch.manual_seed(int(z["seeds"][0]))
+    m = vjf_amd.VJF.make_model(10, 3, 2, 16, [8], likelihood="gaussian")
+    state_close(m, z, prefix="s0", rtol=0, atol=0)
+    assert list(m.state_dict().keys()) == [
+        "mean", "logvar", "likelihood.logvar", "transition.logvar", "transition.velocity.feature.centroid",
+        "transition.velocity.feature.logwidth", "recognition.mlp.0.weight", "recognition.mlp.0.bias",
+        "recognition.mean.weight", "recognition.logvar.weight", "recognition.logvar.bias", "decoder.decode.weight",
+        "decoder.decode.bias"]
+    assert m.likelihood.n_sample == 0 and m.transition.n_sample == 0
+    assert [g["lr"] for g in m.optimizer.param_groups] == [1e-4] * 4
+    m.scheduler.step()
+    assert [g["lr"] for g in m.optimizer.param_groups] == [1e-4 * 0.9] * 4
+
+
+@pytest.fixture
+def fake():
+    undo = fake_backend.install()
+    yield
+    undo()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the stand-in backend works on CPU tensors")
+@pytest.mark.parametrize("name", ["g5_gaussian_du2_wu0_f64", "g5_poisson_du0_wu1_f64", "g5_gaussian_h5x5_f64", "g5_gaussian_lr1e-2_f64"])
+def test_host_filter_logic_golden(fake, name):
+    """vjf_amd.VJF.filter -> C ABI (stand-in) : argument coercion, prior / posterior chaining, flags, counters, lr."""
+    import vjf_amd
+    z, info, _ = gio.traj_case(name)
+    m = vjf_amd.VJF.make_model(info["dy"], info["dz"], info["du"], info["n"], info["hidden"], likelihood=info["lik"])
+    load_fixture_state(m, z, "s0")
+    u = z["u"] if info["du"] else None
+    q = None
+    for t in range(info["T"]):
+        q, loss, *comp = m.filter(z["y"][t], None if u is None else u[t], q, verbose=True, warm_up=info["warm_up"],
+                                  eps=(z["eps"][t, 0], z["eps"][t, 1]))
+        close(q.mean, z["out.mu"][t], rtol=1e-4, atol=1e-5)
+        close(torch.stack([loss, *comp]), z["out.loss"][t], rtol=1e-4, atol=1e-5)
+        assert m.transition.n_sample == int(z["out.n_tr"][t])
+    state_close(m, z, prefix="sT", rtol=1e-3, atol=1e-5)
+    assert m.feed.__func__ is m.filter.__func__
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the stand-in backend works on CPU tensors")
+def test_host_fit_harness_golden(fake):
+    """fit(): epochs, warm-up exit, decoder freeze, RBFDS.initialize (CPU-generator draws in the reference's
+    order), convergence break, lr decay; then forecast with the strided randn_like draw."""
+    import vjf_amd
+    z = gio.load("g8_fit")
+    T, B, dy, dz, du, n = [int(v) for v in z["meta"][:6]]
+    hid = [int(v) for v in z["meta"][6:]]
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        m = vjf_amd.VJF.make_model(dy, dz, du, n, hid, likelihood="gaussian")
+        load_fixture_state(m, z, "s0")
+        torch.manual_seed(int(z["fit_seed"]))
+        mu, lv, epoch_loss = m.fit(torch.tensor(z["y"]), max_iter=3, rtol=10.0)
+        close(mu, z["mu"], rtol=1e-3, atol=1e-4)
+        close(epoch_loss, z["epoch_loss"], rtol=1e-4)
+        assert bool(m._scalars[6].item())                                   # decoder frozen after warm-up
+        close([g["lr"] for g in m.optimizer.param_groups], z["sT.lr"], rtol=1e-12)
+        state_close(m, z, prefix="sT", rtol=2e-3, atol=1e-4, rls_atol=1e-3)
+        torch.manual_seed(int(z["fc_seed"]))
+        x, yf = m.forecast(torch.tensor(z["fc_x0"]), n_step=z["fc_wnoise"].shape[0])
+        close(x, z["fc_x"], rtol=1e-3, atol=1e-3)
+    finally:
+        torch.set_default_dtype(old)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the stand-in backend works on CPU tensors")
+def test_host_sequence_and_reference_noise_order(fake):
+    """filter_sequence draws the noise like T filter calls do (xs then xt per step, CPU generator)."""
+    import vjf_amd
+    torch.manual_seed(3)
+    m1 = vjf_amd.VJF.make_model(6, 2, 0, 8, [5], likelihood="gaussian")
+    torch.manual_seed(3)
+    m2 = vjf_amd.VJF.make_model(6, 2, 0, 8, [5], likelihood="gaussian")
+    y = torch.randn(5, 7, 6)
+    torch.manual_seed(11)
+    mu, lv, loss = m1.filter_sequence(y)
+    torch.manual_seed(11)
+    q = None
+    for t in range(5):
+        q, l = m2.filter(y[t], qs=q)
+        close(q.mean, mu[t], rtol=1e-6, atol=1e-7)
+        close(l, loss[t, 0], rtol=1e-6)
+    close(m1._blob, m2._blob, rtol=1e-6, atol=1e-7)

@@ -1,6 +1,6 @@
 """Diagnostic: phase stamps of the serial kernel at the bench configuration (not a benchmark)."""
 import ctypes, sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vjf_amd
 from vjf_amd import _native as N
 torch.manual_seed(0)
