@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 CFG = dict(B=4096, dz=10, dy=50, du=0, n=200, hidden=[128], lik="gaussian")
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 vector == f32 MFMA peak
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic_current.json")   # tools/pmc_traffic.sh on this build
 
 
 def algorithmic_work(c):
@@ -191,6 +192,11 @@ def main():
         step_s = dev_s / K
         ach_tf = (flops * c["B"] + serial_flops) / step_s / 1e12
         ach_gbs = (b_trial * c["B"] + b_shared) / step_s / 1e9
+        traffic = None
+        try:                                                    # HBM bytes per step from the committed PMC run of this build
+            traffic = float(json.load(open(TRAFFIC_FILE))["bytes_per_step_corrected"])
+        except Exception:
+            pass
         out = {
             "metric": "trial-timesteps/sec", "value": value, "unit": "trial-timesteps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": wall_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -200,7 +206,10 @@ def main():
                        "global_batch": c["B"] * world, "trials_per_gpu": c["B"], "parallelism": f"trial-shard x{world}"},
             "elbo": elbo, "status_bits": status,
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per step: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, "
+                                         "summed over the kernels of a step (profiles/pmc_traffic_current.json); algorithmic bytes "
+                                         "per step = bytes_per_trial_step x trials",
                          "kernel": "one filter step = vjf_trial_kernel + vjf_gram_kernel + vjf_gram_reduce_kernel + "
                                    "vjf_serial_kernel (HIP events around the timed region / steps)",
                          "flops_per_trial_step": flops, "serial_flops_per_step": serial_flops,

@@ -1,0 +1,36 @@
+#!/bin/bash
+# HBM traffic per filter step from the L2 fabric counters (MI355X_MICROARCH.md §HBM):
+# two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only; FETCH_SIZE is doubled
+# (gfx950 reports half the bytes of wide coalesced reads), WRITE_SIZE is taken as is.  Units: KB.
+set -o pipefail
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/pmc_$c
+  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --breakdown-steps 0 > gpurun_out/pmc_$c.json 2> gpurun_out/pmc_$c.err
+  echo "pmc $c exit $?"
+done
+python - <<'PY'
+import csv, glob, json, collections
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True)
+    if not f:
+        print("no counter file for", c); continue
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if r.get("Counter_Name") == c and "vjf_" in r["Kernel_Name"]:
+            per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    out[c] = {k: {"dispatches": len(v), "avg_KB": sum(v) / len(v)} for k, v in per.items()}
+step_kernels = ["vjf_trial_mfma_kernel", "vjf_gram_kernel", "vjf_gram_reduce_kernel", "vjf_prep_kernel", "void vjf_chol_lds_kernel<12>"]
+tot = 0.0
+for k in step_kernels:
+    fe = out.get("FETCH_SIZE", {}).get(k, {}).get("avg_KB", 0.0) * 2.0     # gfx950 correction
+    wr = out.get("WRITE_SIZE", {}).get(k, {}).get("avg_KB", 0.0)
+    print(f"{k:36s} fetch(corrected) {fe:10.1f} KB  write {wr:10.1f} KB")
+    tot += fe + wr
+out["bytes_per_step_corrected"] = tot * 1024
+print("HBM bytes per step (corrected):", tot * 1024)
+json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
+PY
+find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +5M -delete

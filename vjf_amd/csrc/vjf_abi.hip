@@ -301,7 +301,7 @@ int launch_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const fl
     g.slabs = (float*)(c->ws + c->cv.slabs);
     g.B = B; g.nsplit = nsplit;
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
-    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c->njobs, nsplit), dim3(256), 0, c->stream, P, g);
+    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c->njobs * nsplit), dim3(256), 0, c->stream, P, g);
     VJF_HIP(hipGetLastError());
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = a.partial; r.red = (float*)(c->ws + c->cv.red);
@@ -614,7 +614,7 @@ int vjf_blr_rls(const float* x, const float* target, const float* v, float shrin
     VjfGramArgs g{};
     g.jobs = (const VjfJob*)(ws + c.jobs); g.E = E; g.ACT = E; g.DEL = E; g.slabs = (float*)(ws + c.slabs);
     g.B = B; g.nsplit = c.nsplit; g.rows_per_split = ((B + c.nsplit - 1) / c.nsplit + 7) / 8 * 8;
-    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c.njobs, c.nsplit), dim3(256), 0, s, P, g);
+    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c.njobs * c.nsplit), dim3(256), 0, s, P, g);
     VJF_HIP(hipGetLastError());
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(ws + c.partial); r.red = (float*)(ws + c.red);

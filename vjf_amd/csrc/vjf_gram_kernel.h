@@ -23,8 +23,10 @@ struct VjfGramArgs {
 
 __global__ __launch_bounds__(256) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A) {
     __shared__ float s_acc[3 * 1024];
-    const VjfJob job = A.jobs[blockIdx.x];
-    const int split = blockIdx.y;
+    // linear id = job * nsplit + split: workgroups are dealt round-robin over the 8 XCDs, so with nsplit a
+    // multiple of 8 every job of one trial range lands on the same XCD and re-reads its rows from that L2
+    const int split = blockIdx.x % A.nsplit, jobid = blockIdx.x / A.nsplit;
+    const VjfJob job = A.jobs[jobid];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, kh = lane >> 5;
     const float* X; const float* Y; int ldx, ldy;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A)
     }
     __syncthreads();
     if (wave == 0) {
-        float* slab = A.slabs + ((size_t)blockIdx.x * A.nsplit + split) * 1024;
+        float* slab = A.slabs + ((size_t)jobid * A.nsplit + split) * 1024;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float v = ((acc[i] + s_acc[i * 64 + lane]) + s_acc[1024 + i * 64 + lane]) + s_acc[2048 + i * 64 + lane];
