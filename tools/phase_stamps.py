@@ -18,10 +18,10 @@ for i, nm in enumerate(names):
     print(f"{nm:16s} {(t[i+1]-t[i]):8d} cycles(100MHz ticks?)")
 print("total", t[8]-t[0])
 T=list(out)
-print("k=0: potrf", T[9]-T[1], "panel", T[10]-T[9], "trailing", T[11]-T[10])
 
 
-print("k=1: blk_load", T[17]-T[16], "chain+stores", T[18]-T[17], "barrier", T[19]-T[18], "panel", T[20]-T[19], "trailing", T[21]-T[20])
+
+
 
 names1 = ["stage0 inputs", "stage1 rbf", "stage2 var+mean", "stage3 recognition", "stage4 xt+decoder", "stage5 losses", "stage6 backward", "stage7 rows out"]
 for i, nm in enumerate(names1):

@@ -323,20 +323,25 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
         __syncthreads();
         VJF_STAMP(1);
 
-        // ---- blocked right-looking Cholesky
+        // ---- blocked right-looking Cholesky with look-ahead: while wavefronts 1..7 finish the trailing update of
+        //      step k, wavefront 0 updates block (k+1,k+1) first and runs the next diagonal chain
+        auto diag_chain = [&](int k) {                                  // L_kk and L_kk^-1 in one chain (one wavefront)
+            float* dk = s_blk + (size_t)vtri(k, k) * 1024;
+            vjf_f32x16 acc;
+            blk_load(acc, dk, lane);
+            if (!potrf_inv_chain(acc, dk, s_aux + (size_t)k * 1024, lane) && lane == 0) s_flag[0] = 0;
+        };
+        auto trail = [&](int k, int t) {                                // A_ij -= L_ik L_jk^T for the t-th lower block
+            const int bi = k + 1 + s_bi[t], bj = k + 1 + s_bj[t];
+            float* cb = s_blk + (size_t)vtri(bi, bj) * 1024;
+            vjf_f32x16 acc;
+            blk_load(acc, cb, lane);
+            blk_mma<true>(acc, s_blk + (size_t)vtri(bi, k) * 1024, s_blk + (size_t)vtri(bj, k) * 1024, -1.f, lane);
+            blk_store(acc, cb, lane);
+        };
+        if (wave == 0) diag_chain(0);
+        __syncthreads();
         for (int k = 0; k < nbl; ++k) {
-            if (wave == 0) {                                           // diagonal block: L_kk and L_kk^-1 in one chain
-                float* dk = s_blk + (size_t)vtri(k, k) * 1024;
-                vjf_f32x16 acc;
-                if (k == 1) VJF_STAMP(16);
-                blk_load(acc, dk, lane);
-                if (k == 1) VJF_STAMP(17);
-                if (!potrf_inv_chain(acc, dk, s_aux + (size_t)k * 1024, lane) && lane == 0) s_flag[0] = 0;
-                if (k == 1) VJF_STAMP(18);
-            }
-            __syncthreads();
-            if (k == 1) VJF_STAMP(19);
-            if (k == 0) VJF_STAMP(9);
             if (!s_flag[0]) break;
             {                                                          // panel: L_ik = A_ik L_kk^-T, a plain block product
                 const float* ik = s_aux + (size_t)k * 1024;
@@ -350,22 +355,15 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                 }
             }
             __syncthreads();
-            if (k == 1) VJF_STAMP(20);
-            if (k == 0) VJF_STAMP(10);
-            {                                                          // trailing update A_ij -= L_ik L_jk^T
+            {
                 const int m = nbl - 1 - k, nt = m * (m + 1) / 2;
-                for (int t = wave; t < nt; t += VJF_CHOL_THREADS / 64) {
-                    const int bi = k + 1 + s_bi[t], bj = k + 1 + s_bj[t];
-                    float* cb = s_blk + (size_t)vtri(bi, bj) * 1024;
-                    vjf_f32x16 acc;
-                    blk_load(acc, cb, lane);
-                    blk_mma<true>(acc, s_blk + (size_t)vtri(bi, k) * 1024, s_blk + (size_t)vtri(bj, k) * 1024, -1.f, lane);
-                    blk_store(acc, cb, lane);
+                if (wave == 0) {
+                    if (nt > 0) { trail(k, 0); diag_chain(k + 1); }    // block (k+1,k+1), then the next chain
+                } else {
+                    for (int t = wave; t < nt; t += VJF_CHOL_THREADS / 64 - 1) trail(k, t);
                 }
             }
             __syncthreads();
-            if (k == 1) VJF_STAMP(21);
-            if (k == 0) VJF_STAMP(11);
         }
         const bool ok = s_flag[0] != 0;
         VJF_STAMP(2);
