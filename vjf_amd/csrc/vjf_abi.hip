@@ -284,7 +284,7 @@ int launch_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const fl
         m.t = a; m.aux = (const float*)(c->ws + c->cv.aux);
         m.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
         nblk = (B + 15) / 16;
-        hipLaunchKernelGGL(vjf_trial_mfma_kernel, dim3(nblk), dim3(256), c->lds_k1m, c->stream, P, m);
+        hipLaunchKernelGGL(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, c->stream, P, m);
     } else {
         nblk = (B + c->TB - 1) / c->TB;
         switch (c->TB) {

@@ -17,6 +17,8 @@
 #include "vjf_trial_kernel.h"      // VjfTrialArgs, group_sum
 
 #define VJF_LDT 17
+#define VJF_K1M_WAVES 16           // wavefronts per workgroup (two per SIMD: one hides the other's L2 operand latency)
+#define VJF_K1M_THREADS (64 * VJF_K1M_WAVES)
 typedef float vjf_f32x4 __attribute__((ext_vector_type(4)));
 
 // acc(row = 4*(lane>>4)+r, col = lane&15) += sum_{k<K} Ag[k*lda + m0 + row] * Xs[k*17 + col]
@@ -69,10 +71,10 @@ struct VjfTrialMfmaArgs {
 
 static inline size_t vjf_trial_mfma_lds_floats(const VjfPlan& P) {
     const size_t feat = (size_t)P.din + P.dxu + P.n + P.hsum + 2 * (size_t)P.hmax + 8 * (size_t)P.dz + 2 * (size_t)P.dy;
-    return feat * VJF_LDT + 16 * RS_N + 4 * 16 + 16 + 64;
+    return feat * VJF_LDT + 16 * RS_N + VJF_K1M_WAVES * 16 + 16 + 64;
 }
 
-__global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrialMfmaArgs AA) {
+__global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrialMfmaArgs AA) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const VjfTrialArgs& A = AA.t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     const bool warm = (A.flags & VJF_FLAG_WARM_UP) != 0;
     const bool tri = S[P.off[VJF_SLOT_SCALARS] + VJF_SC_TRI_CLEAN] != 0.f;   // w_chol known upper triangular
     constexpr int LD = VJF_LDT;
+    constexpr int NW = VJF_K1M_WAVES;
 
     // ---- LDS carve: feature-major [feature][17] matrices
     float* s_in = smem;                          // din   [y | u | mu_s | lv_s]
@@ -104,11 +107,11 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     float* s_dpy = s_py + dy * LD;               // dy
     float* s_sc = s_dpy + dy * LD;               // 16 x RS_N per-trial scalars
     float* s_red = s_sc + 16 * RS_N;             // 4 x 16 variance partials
-    float* s_plv = s_red + 64;                   // 16 pt.logvar
+    float* s_plv = s_red + 16 * NW;              // 16 pt.logvar
 
     VJF_K1_STAMP(22);
     // ---- stage 0: inputs (coalesced global reads, transposed LDS writes), eps_t, xs
-    for (int b = wave; b < 16; b += 4) {            // wavefront w stages trials w, w+4, ..; the lane walks the columns
+    for (int b = wave; b < 16; b += NW) {            // wavefront w stages trials w, w+4, ..; the lane walks the columns
         const bool ok = b < nb;
         const size_t g = (size_t)(b0 + b);
         for (int c = lane; c < din; c += 64) {
@@ -122,13 +125,13 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
             s_in[c * LD + b] = v;
         }
     }
-    for (int e = tid; e < 16 * dz; e += 256) {
+    for (int e = tid; e < 16 * dz; e += VJF_K1M_THREADS) {
         const int b = e / dz, j = e - b * dz;
         s_e2[j * LD + b] = (b < nb) ? A.eps_t[(size_t)(b0 + b) * dz + j] : 0.f;
         s_xt[j * LD + b] = (b < nb) ? A.eps_s[(size_t)(b0 + b) * dz + j] : 0.f;      // eps_s parked in s_xt
     }
     __syncthreads();
-    for (int e = tid; e < 16 * dxu; e += 256) {
+    for (int e = tid; e < 16 * dxu; e += VJF_K1M_THREADS) {
         const int c = e >> 4, b = e & 15;
         float v;
         if (c < dz) v = fmaf(s_xt[c * LD + b], expf(0.5f * s_in[(dy + du + dz + c) * LD + b]), s_in[(dy + du + c) * LD + b]);
@@ -147,11 +150,11 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         float* s_iw = s_cen + n * dxu;
         const bool stage_c = (n * dxu + n) <= 2 * P.hmax * LD;
         if (stage_c) {
-            for (int e = tid; e < n * dxu; e += 256) s_cen[e] = cen[e];
-            for (int e = tid; e < n; e += 256) { const float w = expf(lw[e]); s_iw[e] = -0.5f / (w * w); }
+            for (int e = tid; e < n * dxu; e += VJF_K1M_THREADS) s_cen[e] = cen[e];
+            for (int e = tid; e < n; e += VJF_K1M_THREADS) { const float w = expf(lw[e]); s_iw[e] = -0.5f / (w * w); }
             __syncthreads();
         }
-        for (int e = tid; e < 16 * n; e += 256) {
+        for (int e = tid; e < 16 * n; e += VJF_K1M_THREADS) {
             const int k = e >> 4, b = e & 15;
             float d2 = 0.f;
             if (stage_c) {
@@ -174,8 +177,8 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         float v2 = 0.f;
         // tiles in descending cost, dealt to the 4 wavefronts in a snake so that the triangular work balances
         for (int r = 0;; ++r) {
-            const int idx = (r & 1) ? r * 4 + 3 - wave : r * 4 + wave;
-            if (idx >= ntile) { if (r * 4 >= ntile) break; else continue; }
+            const int idx = (r & 1) ? r * NW + NW - 1 - wave : r * NW + wave;
+            if (idx >= ntile) { if (r * NW >= ntile) break; else continue; }
             const int t = ntile - 1 - idx, j0 = t * 16;
             const int K = tri ? min(n, j0 + 16) : n;
             vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         // mean tiles, dealt from the last wavefront backwards (it has the lightest variance share)
         const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
         const int mt = (dz + 15) >> 4;
-        for (int t = 3 - wave; t < mt; t += 4) {
+        for (int t = NW - 1 - wave; t < mt; t += NW) {
             vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             mma_tile(acc, Wm, dz, dz, t * 16, s_phi, n, lane);
 #pragma unroll
@@ -199,7 +202,11 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         }
     }
     __syncthreads();
-    if (tid < 16) s_plv[tid] = logf(((s_red[tid] + s_red[16 + tid]) + s_red[32 + tid]) + s_red[48 + tid]);
+    if (tid < 16) {
+        float v = 0.f;
+        for (int w = 0; w < NW; ++w) v += s_red[w * 16 + tid];
+        s_plv[tid] = logf(v);
+    }
 
     VJF_K1_STAMP(25);
     // ---- stage 3: recognition forward (recognition.py:31-42)
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
             const float* bias = S + P.off[VJF_SLOT_REC_B0 + 2 * l];
             float* out = s_act + aoff * LD;
             const int hl = P.h[l], mt = (hl + 15) >> 4;
-            for (int t = wave; t < mt; t += 4) {
+            for (int t = wave; t < mt; t += NW) {
                 vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 mma_tile(acc, WT, hl, hl, t * 16, xin, kin, lane);
 #pragma unroll
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         const float* HT = AA.aux + P.aux_headT;                        // (hL, 2dz): mean rows then logvar rows
         const float* bl = S + P.off[VJF_SLOT_LV_B];
         const int mt = (2 * dz + 15) >> 4;
-        for (int t = wave; t < mt; t += 4) {
+        for (int t = wave; t < mt; t += NW) {
             vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             mma_tile(acc, HT, 2 * dz, 2 * dz, t * 16, xin, kin, lane);
 #pragma unroll
@@ -240,11 +247,11 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
 
     VJF_K1_STAMP(26);
     // ---- stage 4: xt, posterior outputs, py = xt C^T + d (model.py:28-30)
-    for (int e = tid; e < 16 * dz; e += 256) {
+    for (int e = tid; e < 16 * dz; e += VJF_K1M_THREADS) {
         const int j = e >> 4, b = e & 15;
         s_xt[j * LD + b] = fmaf(s_e2[j * LD + b], expf(0.5f * s_lv[j * LD + b]), s_mu[j * LD + b]);
     }
-    for (int e = tid; e < nb * dz; e += 256) {                          // coalesced posterior stores
+    for (int e = tid; e < nb * dz; e += VJF_K1M_THREADS) {                          // coalesced posterior stores
         const int b = e / dz, j = e - b * dz;
         A.mu_t[(size_t)(b0 + b) * dz + j] = s_mu[j * LD + b];
         A.lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         const float* CT = AA.aux + P.aux_decT;                         // (dz, dy)
         const float* d = S + P.off[VJF_SLOT_DEC_B];
         const int mt = (dy + 15) >> 4;
-        for (int t = wave; t < mt; t += 4) {
+        for (int t = wave; t < mt; t += NW) {
             vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             mma_tile(acc, CT, dy, dy, t * 16, s_xt, dz, lane);
 #pragma unroll
@@ -269,13 +276,14 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     VJF_K1_STAMP(27);
     // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
     {
-        const int b = tid >> 4, s = tid & 15;
+        constexpr int LPT = VJF_K1M_THREADS / 16;          // lanes per trial
+        const int b = tid / LPT, s = tid % LPT;
         const float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
         const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
         float lrec = 0.f, ssey = 0.f;
         if (P.lik == VJF_LIK_GAUSSIAN) {                               // likelihood.py:19-26, functional.py:54-73
             const float p = expf(-0.5f * rho), e = expf(-rho);
-            for (int i = s; i < dy; i += 16) {
+            for (int i = s; i < dy; i += LPT) {
                 const float yv = s_in[i * LD + b], pv = s_py[i * LD + b];
                 const float r = pv - yv, dsc = yv * p - pv * p;
                 lrec += 0.5f * (dsc * dsc + rho);
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
                 s_dpy[i * LD + b] = e * r;
             }
         } else {                                                       // likelihood.py:51-62
-            for (int i = s; i < dy; i += 16) {
+            for (int i = s; i < dy; i += LPT) {
                 const float yv = s_in[i * LD + b], pv = s_py[i * LD + b];
                 const float eta = fminf(pv, 10.f), ex = expf(eta);
                 lrec += ex - yv * eta;
@@ -292,12 +300,12 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
                 s_dpy[i * LD + b] = (pv <= 10.f) ? (ex - yv) : 0.f;
             }
         }
-        lrec = group_sum<16>(lrec);
-        ssey = group_sum<16>(ssey);
+        lrec = group_sum<LPT>(lrec);
+        ssey = group_sum<LPT>(ssey);
         float ldyn = 0.f, ent = 0.f, sdx2 = 0.f;
         {
             const float p = expf(-0.5f * sig), e = expf(-sig), plv = s_plv[b];
-            for (int j = s; j < dz; j += 16) {                         // model.py:390-391, functional.py:62-75
+            for (int j = s; j < dz; j += LPT) {                         // model.py:390-391, functional.py:62-75
                 const float mp = s_pm[j * LD + b], mu = s_mu[j * LD + b], lv = s_lv[j * LD + b];
                 const float dsc = mp * p - mu * p;
                 const float tr = expf(plv + lv - sig);
@@ -311,9 +319,9 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
                 s_dlv[j * LD + b] = dlv;
             }
         }
-        ldyn = group_sum<16>(ldyn);
-        ent = group_sum<16>(ent);
-        sdx2 = group_sum<16>(sdx2);
+        ldyn = group_sum<LPT>(ldyn);
+        ent = group_sum<LPT>(ent);
+        sdx2 = group_sum<LPT>(sdx2);
         if (s == 0) {
             const bool ok = b < nb;
             s_sc[b * RS_N + RS_LRECON] = ok ? lrec : 0.f;
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     {
         const float* C = S + P.off[VJF_SLOT_DEC_W];                    // (dy, dz): k-major for this product
         const int mt = (dz + 15) >> 4;
-        for (int t = wave; t < mt; t += 4) {
+        for (int t = wave; t < mt; t += NW) {
             vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             mma_tile(acc, C, dz, dz, t * 16, s_dpy, dy, lane);
 #pragma unroll
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         const float* Wl = S + P.off[VJF_SLOT_LV_W];
         const float* hact = s_act + (P.hsum - hL) * LD;
         int mt = (hL + 15) >> 4;
-        for (int t = wave; t < mt; t += 4) {
+        for (int t = wave; t < mt; t += NW) {
             vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             mma_tile(acc, Wm, hL, hL, t * 16, s_dmu, dz, lane);
             mma_tile(acc, Wl, hL, hL, t * 16, s_dlv, dz, lane);
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
         float* cur = s_d0; float* nxt = s_d1;
         for (int l = P.L - 1; l >= 0; --l) {
             const int hl = P.h[l];
-            for (int e = tid; e < nb * hl; e += 256) {                  // da_l -> DEL, coalesced over k
+            for (int e = tid; e < nb * hl; e += VJF_K1M_THREADS) {                  // da_l -> DEL, coalesced over k
                 const int b = e / hl, k = e - b * hl;
                 A.DEL[(size_t)(b0 + b) * P.ldD + P.colD_da[l] + k] = cur[k * LD + b];
             }
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
                 const float* W = S + P.off[VJF_SLOT_REC_W0 + 2 * l];   // (hl, hp): k-major for dh_{l-1} = da_l W
                 const float* hprev = s_act + (aoff - hp) * LD;
                 mt = (hp + 15) >> 4;
-                for (int t = wave; t < mt; t += 4) {
+                for (int t = wave; t < mt; t += NW) {
                     vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                     mma_tile(acc, W, hp, hp, t * 16, cur, hl, lane);
 #pragma unroll
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(256) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrial
     VJF_K1_STAMP(29);
     // ---- stage 7: rows of E = [Phi | dx | 0], ACT = [in|1|h_1|1|..|h_L|1|xt|1|0], DEL = [.. | dmu | dlv | dpy].
     //      wavefront w writes the rows of trials w, w+4, ...; the lane walks the columns (coalesced, no divisions)
-    for (int b = wave; b < nb; b += 4) {
+    for (int b = wave; b < nb; b += NW) {
         float* erow = A.E + (size_t)(b0 + b) * P.ldE;
         for (int c = lane; c < P.ldE; c += 64) {
             float v = 0.f;
