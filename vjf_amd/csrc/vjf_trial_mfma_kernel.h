@@ -31,15 +31,28 @@ __device__ __forceinline__ void mma_tile(vjf_f32x4& acc, const float* __restrict
     const float* xp = Xs + kk * VJF_LDT + i;
     const int K4 = K & ~3, K32 = K & ~31;
     int k0 = 0;
-    for (; k0 < K32; k0 += 32) {                       // 8 steps: all 16 operand loads are issued before the first MFMA
-        float a[8], x[8];
+    if (K32 > 0) {                                     // batches of 8 steps, the next batch's 16 operand loads in flight
+        float a0[8], x0[8], a1[8], x1[8];              // while the current batch's MFMAs issue
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            a[q] = rv ? ap[(size_t)(k0 + 4 * q) * lda] : 0.f;
-            x[q] = xp[(k0 + 4 * q) * VJF_LDT];
+        for (int q = 0; q < 8; ++q) { a0[q] = rv ? ap[(size_t)(4 * q) * lda] : 0.f; x0[q] = xp[(4 * q) * VJF_LDT]; }
+        for (; k0 < K32; k0 += 64) {
+            const bool more1 = k0 + 32 < K32;
+            if (more1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { a1[q] = rv ? ap[(size_t)(k0 + 32 + 4 * q) * lda] : 0.f; x1[q] = xp[(k0 + 32 + 4 * q) * VJF_LDT]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], x0[q], acc, 0, 0, 0);
+            if (!more1) { k0 += 32; break; }
+            const bool more0 = k0 + 64 < K32;
+            if (more0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { a0[q] = rv ? ap[(size_t)(k0 + 64 + 4 * q) * lda] : 0.f; x0[q] = xp[(k0 + 64 + 4 * q) * VJF_LDT]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], x1[q], acc, 0, 0, 0);
+            if (!more0) { k0 += 64; break; }
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], x[q], acc, 0, 0, 0);
     }
     for (; k0 < K4; k0 += 4) {
         const float a = rv ? ap[(size_t)k0 * lda] : 0.f;
