@@ -160,13 +160,32 @@ __device__ __forceinline__ void blk_store(const vjf_f32x16& acc, float* blk, int
 template <bool Bt>
 __device__ __forceinline__ void blk_mma(vjf_f32x16& acc, const float* Ab, const float* Bb, float sign, int lane) {
     const int c = lane & 31, h = lane >> 5;
+    float a[16], b[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {                   // all 32 operand reads first ...
+        const int m = 2 * t + h;
+        a[t] = Ab[vsw(c, m)];
+        b[t] = Bt ? Bb[vsw(c, m)] : Bb[vsw(m, c)];
+    }
+    __builtin_amdgcn_sched_barrier(0);               // ... so the 16 MFMAs issue back to back
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sign * a[t], b[t], acc, 0, 0, 0);
+}
+
+// acc += A * B with operands given by functors: fa(i, m) = A[i][m], fb(m, j) = B[m][j]  (i, j = lane & 31)
+template <class FA, class FB>
+__device__ __forceinline__ void blk_mma_f(vjf_f32x16& acc, int lane, FA fa, FB fb) {
+    const int c = lane & 31, h = lane >> 5;
+    float a[16], b[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int m = 2 * t + h;
-        const float a = sign * Ab[vsw(c, m)];
-        const float b = Bt ? Bb[vsw(c, m)] : Bb[vsw(m, c)];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        a[t] = fa(c, m);
+        b[t] = fb(m, c);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
 }
 
 // Cholesky of the symmetric tile held in `acc` (one wavefront) together with the inverse of its
@@ -421,9 +440,12 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) xacc[r] = 0.f;
+                    float da[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-di[vsw(c, vrow(r, h))], t[r], xacc, 0, 0, 0);
+                    for (int r = 0; r < 16; ++r) da[r] = -di[vsw(c, vrow(r, h))];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[r], t[r], xacc, 0, 0, 0);
                 }
                 __syncthreads();                                       // every reader of row bi of L is done
                 if (bj < bi) blk_store(xacc, s_blk + (size_t)vtri(bi, bj) * 1024, lane);
@@ -471,59 +493,57 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                 if (tid == 0) SC[VJF_SC_TRI_CLEAN] = 1.f;
             }
             VJF_STAMP(6);
-            // ---- y = X g ; W = X^T y  (cholesky_solve, module.py:101).  Thread (row, part): the part-th half of the
-            //      sum by column parity, so every lane of a wavefront walks the same column (broadcast reads of g / y).
+            // ---- y = X g ; W = X^T y  (cholesky_solve, module.py:101) as block products on the matrix cores.
+            //      Block row br of y sums br+1 products; wavefront w takes the even-offset products of row w and the
+            //      odd-offset products of row nbl-1-w (<= ceil((nbl+1)/2) products each), partial tiles meet in LDS.
             {
-                const int r = tid & 255, part = tid >> 8;
-                float acc[DZP];
+                float* s_pe = s_aux;                          // even partials, npad x DZP   (s_aux = Dinv is free now)
+                float* s_po = s_aux + (size_t)npad * DZP;     // odd partials
+                const int c = lane & 31, h = lane >> 5;
+                auto store_part = [&](const vjf_f32x16& acc, float* dst, int blk) {
+                    if (c < DZP) {
 #pragma unroll
-                for (int j = 0; j < DZP; ++j) acc[j] = 0.f;
-                if (r < npad) {
-                    const int br = r >> 5, rr = r & 31;
-                    for (int cb = 0; cb <= br; ++cb) {                  // block (br, cb) of X, 16 columns of this parity
-                        const float* xb = s_blk + (size_t)vtri(br, cb) * 1024;
-                        float xv[16];
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) xv[q] = xb[vsw(rr, 2 * q + part)];
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) axpy_row<DZP>(acc, xv[q], s_g + (cb * 32 + 2 * q + part) * DZP);
+                        for (int r = 0; r < 16; ++r) dst[(blk * 32 + vrow(r, h)) * DZP + c] = acc[r];
                     }
-                }
-                float* dst = part ? s_aux : s_y;     // s_aux (Dinv) is free now (copied into the diagonal slots)
-                if (r < npad) {
+                };
+                for (int pass = 0; pass < 2; ++pass) {                      // pass 0: y = X g ; pass 1: W = X^T y
+                    const float* src = s_g;                                 // g, then y
+                    for (int par = 0; par < 2; ++par) {
+                        const int row = par == 0 ? wave : nbl - 1 - wave;   // block row of the output
+                        if (wave < nbl && row >= 0 && row < nbl) {
+                            vjf_f32x16 acc;
 #pragma unroll
-                    for (int j = 0; j < DZP; ++j) dst[r * DZP + j] = acc[j];
-                }
-                __syncthreads();
-                for (int e = tid; e < npad * DZP; e += VJF_CHOL_THREADS) s_y[e] += s_aux[e];
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < DZP; ++j) acc[j] = 0.f;
-                if (r < npad) {
-                    const int bk = r >> 5, kk = r & 31;                 // r plays the role of the column k of X
-                    for (int rb = bk; rb < nbl; ++rb) {                 // block (rb, bk) of X, 16 rows of this parity
-                        const float* xb = s_blk + (size_t)vtri(rb, bk) * 1024;
-                        float xv[16];
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) xv[q] = xb[vsw(2 * q + part, kk)];
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) axpy_row<DZP>(acc, xv[q], s_y + (rb * 32 + 2 * q + part) * DZP);
+                            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                            // pass 0: column blocks cb = row - par, row - par - 2, ... >= 0 of X(row, cb)
+                            // pass 1: row blocks    rb = row + par, row + par + 2, ... < nbl of X(rb, row)^T
+                            for (int o = par; pass == 0 ? (row - o >= 0) : (row + o < nbl); o += 2) {
+                                const int ob = pass == 0 ? row - o : row + o;
+                                const float* xb = s_blk + (size_t)(pass == 0 ? vtri(row, ob) : vtri(ob, row)) * 1024;
+                                const float* sb = src + (size_t)ob * 32 * DZP;
+                                if (pass == 0)
+                                    blk_mma_f(acc, lane, [&](int i, int m) { return xb[vsw(i, m)]; },
+                                              [&](int m, int j) { return j < DZP ? sb[m * DZP + j] : 0.f; });
+                                else
+                                    blk_mma_f(acc, lane, [&](int i, int m) { return xb[vsw(m, i)]; },
+                                              [&](int m, int j) { return j < DZP ? sb[m * DZP + j] : 0.f; });
+                            }
+                            store_part(acc, par == 0 ? s_pe : s_po, row);
+                        } else if (par == 1 && wave < nbl) {
+                            // (no odd partner row)
+                        }
                     }
+                    // rows whose odd partial was not produced (nbl-1-w out of range never happens for w < nbl) are all covered
+                    __syncthreads();
+                    for (int e = tid; e < npad * DZP; e += VJF_CHOL_THREADS) {
+                        const float v = s_pe[e] + s_po[e];
+                        s_g[e] = v;                                         // y after pass 0, W after pass 1
+                        if (pass == 1) {
+                            const int rw = e / DZP, j = e - rw * DZP;
+                            if (rw < n && j < dz) Wm[(size_t)rw * dz + j] = v;
+                        }
+                    }
+                    __syncthreads();
                 }
-                dst = part ? s_aux : s_g;
-                __syncthreads();
-                if (r < npad) {
-#pragma unroll
-                    for (int j = 0; j < DZP; ++j) dst[r * DZP + j] = acc[j];
-                }
-                __syncthreads();
-                for (int e = tid; e < npad * DZP; e += VJF_CHOL_THREADS) {
-                    const int rw = e / DZP, j = e - rw * DZP;
-                    const float w = s_g[e] + s_aux[e];
-                    s_g[e] = w;
-                    if (rw < n && j < dz) Wm[(size_t)rw * dz + j] = w;
-                }
-                __syncthreads();
             }
         }
     }
