@@ -13,6 +13,7 @@
 #include "vjf_gram_kernel.h"
 #include "vjf_ops_kernels.h"
 #include "vjf_plan.h"
+#include "vjf_post_kernel.h"
 #include "vjf_serial_kernel.h"
 #include "vjf_trial_kernel.h"
 #include "vjf_trial_mfma_kernel.h"
@@ -89,7 +90,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t E, ACT, DEL, partial, slabs, red, work, jobs, aux, total;
+    size_t E, ACT, DEL, partial, slabs, red, work, jobs, aux, post, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -103,6 +104,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.slabs = take((size_t)njobs * split_for(max_batch) * 1024 * 4);
     c.red = take((size_t)P.red_len * 4);
     c.work = take(vjf_serial_work_floats(P) * 4 + 256);   // + 32 u64 diagnostic stamps
+    c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
     c.total = o;
@@ -130,6 +132,8 @@ struct vjf_ctx {
     int njobs;
     int TB;
     size_t lds_k1, lds_k2;
+    bool post_kernels;     // RLS tail (inverse, solve, residual) on many CUs after the Cholesky kernel
+    size_t lds_post;
     bool mfma_trial;       // 16 trials' working set fits LDS: matrix-core trial kernel
     size_t lds_k1m;
     bool stamps;           // diagnostic: record s_memtime phase stamps in the serial kernel
@@ -200,6 +204,8 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->stream = (hipStream_t)stream; c->cv = cv; c->njobs = (int)jobs.size(); c->TB = TB;
     c->lds_k1 = vjf_trial_lds_floats(P, TB) * 4; c->lds_k2 = lds_k2;
     c->fast_chol = fast_chol; c->lds_chol = vjf_chol_lds_bytes(P); c->stamps = false;
+    c->lds_post = vjf_post_lds_bytes(P);
+    c->post_kernels = fast_chol && P.dz <= 16 && c->lds_post <= kMaxLds - 1024;
     c->lds_k1m = vjf_trial_mfma_lds_floats(P) * 4;
     c->mfma_trial = c->lds_k1m <= kMaxLds - 1024;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
@@ -208,6 +214,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
     allow_lds(vjf_trial_kernel<16>, c->lds_k1); allow_lds(vjf_trial_kernel<8>, c->lds_k1); allow_lds(vjf_trial_kernel<4>, c->lds_k1);
     allow_lds(vjf_serial_kernel, c->lds_k2);
+    allow_lds(vjf_rls_post_kernel, c->lds_post);
     if (c->mfma_trial) allow_lds(vjf_trial_mfma_kernel, c->lds_k1m);
     allow_lds(vjf_chol_lds_kernel<4>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<8>, c->lds_chol);
     allow_lds(vjf_chol_lds_kernel<12>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<16>, c->lds_chol);
@@ -335,6 +342,11 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
             VjfCholArgs a{};
             a.state = c->state; a.red = p.red; a.gbuf = p.gbuf; a.B_total = B_total; a.flags = flags;
             a.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
+            const int nbl = (P.n + 31) / 32;
+            float* dinv = (float*)(c->ws + c->cv.post);
+            double* rpart = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
+            int* okflag = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
+            a.post = c->post_kernels ? 1 : 0; a.dinv_out = dinv; a.ok_out = okflag;
             switch (vjf_chol_dzp(P.dz)) {
                 case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
                 case 8: hipLaunchKernelGGL(vjf_chol_lds_kernel<8>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
@@ -343,6 +355,20 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
                 default: hipLaunchKernelGGL(vjf_chol_lds_kernel<32>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
             }
             VJF_HIP(hipGetLastError());
+            if (c->post_kernels) {
+                const bool rls = !(flags & VJF_FLAG_WARM_UP);
+                if (rls) {
+                    VjfPostArgs pa{};
+                    pa.state = c->state; pa.dinv = dinv; pa.gbuf = p.gbuf; pa.ok = okflag;
+                    hipLaunchKernelGGL(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, c->stream, P, pa);
+                    VJF_HIP(hipGetLastError());
+                }
+                VjfResidArgs ra{};
+                ra.state = c->state; ra.red = p.red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
+                hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, c->stream, P, ra);
+                hipLaunchKernelGGL(vjf_sigma_kernel, dim3(1), dim3(64), 0, c->stream, P, ra, rls ? (const int*)okflag : (const int*)nullptr);
+                VJF_HIP(hipGetLastError());
+            }
         }
         return 0;
     }

@@ -236,6 +236,9 @@ struct VjfCholArgs {
     int B_total;
     unsigned flags;
     unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memtime at phase boundaries
+    float* dinv_out;       // post mode: nbl blocks (32x32 row-major) of inverted diagonal blocks for vjf_rls_post_kernel
+    int* ok_out;           // post mode: 1 = factor valid
+    int post;              // 1: stop after L and the inverted diagonal blocks; the many-CU post kernels do the rest
 };
 
 #define VJF_STAMP(i)                                                                        \
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
     float* SC = S + P.off[VJF_SLOT_SCALARS];
     const bool do_upd = A.flags & VJF_FLAG_UPDATE, warm = A.flags & VJF_FLAG_WARM_UP;
     if (!do_upd) return;
+    if (A.post && warm) return;                      // no RLS in warm-up; the residual / sigma kernels run on their own
     float* s_blk = lds;                               // ntri blocks: lower block triangle of P -> L -> L^-1
     float* s_aux = s_blk + (size_t)ntri * 1024;       // nbl blocks: inverted diagonal blocks of L; later scratch
     float* s_g = s_aux + (size_t)nbl * 1024;          // npad x DZP  g, later W
@@ -392,6 +396,10 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
             st |= VJF_STATUS_RLS_FAILED;
             const float inv_v = expf(-sig);
             for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) Pm[e] = Pm[e] - G[e] * inv_v;
+            if (A.post) {
+                if (tid == 0) { A.ok_out[0] = 0; SC[VJF_SC_STATUS] = (float)((unsigned)SC[VJF_SC_STATUS] | st); }
+                return;
+            }
         } else {
             // ---- w_pchol = L (lower, module.py:99-100)
             {
@@ -420,6 +428,24 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                 }
             }
             VJF_STAMP(3);
+            if (A.post) {
+                // inverted diagonal blocks for the post kernels; one-time clearing of the zero halves; done
+                for (int e = tid; e < nbl * 1024; e += VJF_CHOL_THREADS) {
+                    const int b = e >> 10, r = (e >> 5) & 31, c = e & 31;
+                    A.dinv_out[e] = s_aux[(size_t)b * 1024 + vsw(r, c)];
+                }
+                if (SC[VJF_SC_TRI_CLEAN] == 0.f) {
+                    for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) {
+                        const int i = e / n, j = e - i * n;
+                        if ((i >> 5) < (j >> 5)) Lm[e] = 0.f;
+                        if ((i >> 5) > (j >> 5)) Wc[e] = 0.f;
+                    }
+                    __syncthreads();
+                    if (tid == 0) SC[VJF_SC_TRI_CLEAN] = 1.f;
+                }
+                if (tid == 0) A.ok_out[0] = 1;
+                return;
+            }
             VJF_STAMP(4);
             // ---- X = L^-1, block row by block row, in place over L:
             //      X_ij = -Dinv_i * sum_{k=j}^{i-1} L_ik X_kj   (X_jj = Dinv_j)
