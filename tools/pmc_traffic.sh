@@ -22,9 +22,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if r.get("Counter_Name") == c and "vjf_" in r["Kernel_Name"]:
             per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     out[c] = {k: {"dispatches": len(v), "avg_KB": sum(v) / len(v)} for k, v in per.items()}
-step_kernels = ["vjf_trial_mfma_kernel", "vjf_gram_kernel", "vjf_gram_reduce_kernel", "vjf_prep_kernel", "void vjf_chol_lds_kernel<12>"]
+names = sorted(set(out.get("FETCH_SIZE", {})) | set(out.get("WRITE_SIZE", {})))
 tot = 0.0
-for k in step_kernels:
+for k in names:
+    if "vjf_aux_kernel" in k:
+        continue                      # runs once per API call, not per step
     fe = out.get("FETCH_SIZE", {}).get(k, {}).get("avg_KB", 0.0) * 2.0     # gfx950 correction
     wr = out.get("WRITE_SIZE", {}).get(k, {}).get("avg_KB", 0.0)
     print(f"{k:36s} fetch(corrected) {fe:10.1f} KB  write {wr:10.1f} KB")

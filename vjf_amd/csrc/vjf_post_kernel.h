@@ -15,7 +15,8 @@
 #include "vjf_plan.h"
 #include "vjf_trial_mfma_kernel.h"   // vjf_f32x4
 
-#define VJF_POST_THREADS 256
+#define VJF_POST_THREADS 512
+#define VJF_POST_KPAR 4                // wavefronts = 2 row tiles x 4 interleaved block sums
 #define VJF_POST_LDB 33               // padded leading dimension of a 32x32 block in LDS
 #define VJF_POST_LDX 17               // right-hand sides: [row][16 columns + 1 pad]
 #define VJF_RESID_BLOCKS 64
@@ -29,7 +30,7 @@ struct VjfPostArgs {
 
 static inline size_t vjf_post_lds_bytes(const VjfPlan& P) {
     const int nbl = (P.n + 31) / 32;
-    return ((size_t)(nbl * (nbl - 1) / 2 + nbl) * 32 * VJF_POST_LDB + (size_t)nbl * 32 * VJF_POST_LDX + 2 * 32 * VJF_POST_LDX + 16) * 4;
+    return ((size_t)(nbl * (nbl - 1) / 2 + nbl) * 32 * VJF_POST_LDB + (size_t)nbl * 32 * VJF_POST_LDX + VJF_POST_KPAR * 32 * VJF_POST_LDX + 16) * 4;
 }
 
 // acc(row = 4*(lane>>4)+r of the 16-row tile, col = lane&15) += sum_m A(tile row, m) * B[m][col], m < 32
@@ -40,8 +41,13 @@ __device__ __forceinline__ void post_mma32(vjf_f32x4& acc, const float* Bs, int 
 #pragma unroll
     for (int s = 0; s < 8; ++s) { a[s] = fa(i, 4 * s + kk); b[s] = Bs[(4 * s + kk) * VJF_POST_LDX + i]; }
     __builtin_amdgcn_sched_barrier(0);
+    vjf_f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};                     // two independent chains: the MFMAs issue back to back
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+    for (int s = 0; s < 8; s += 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
+    }
+    acc += acc1;
 }
 
 __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan P, VjfPostArgs A) {
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     float* s_L = lds;                                          // strictly-lower blocks [32][33] of L (bi > bj)
     float* s_D = s_L + (size_t)(ntri - nbl) * 32 * LB;         // nbl blocks [32][33]: inverted diagonal blocks
     float* s_x = s_D + (size_t)nbl * 32 * LB;                  // [npad][17] right-hand sides -> solution
-    float* s_t = s_x + (size_t)nbl * 32 * LX;                  // 2 x [32][17] partial sums
+    float* s_t = s_x + (size_t)nbl * 32 * LX;                  // VJF_POST_KPAR x [32][17] partial sums
     const float* S = A.state;
     const float* Lm = S + P.off[VJF_SLOT_W_PCHOL];
     const bool solve = (int)blockIdx.x == 2 * nbl;             // the y / W workgroup
@@ -105,11 +111,12 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     }
     __syncthreads();
 
-    const int tile = wave & 1, kpar = wave >> 1;               // 16-row tile of the block row, parity of the summed blocks
+    const int tile = wave & 1, kpar = wave >> 1;               // 16-row tile of the block row; blocks k = first + kpar, + KPAR, ..
+    constexpr int KP = VJF_POST_KPAR;
     // ---- forward substitution  Y_i = Dinv_i (R_i - sum_{k<i} L_ik Y_k),  i = j0 .. nbl-1, in place in s_x
     for (int bi = j0; bi < nbl; ++bi) {
         vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k = j0 + kpar; k < bi; k += 2) {
+        for (int k = j0 + kpar; k < bi; k += KP) {
             const float* Lb = s_L + (size_t)tri(bi, k) * 32 * LB;
             post_mma32(acc, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Lb[(16 * tile + i) * LB + m]; });
         }
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         __syncthreads();
         for (int e = tid; e < 32 * 16; e += VJF_POST_THREADS) {                // T = R_i - T0 - T1  (into s_t[0])
             const int r = e >> 4, c = e & 15;
-            s_t[r * LX + c] = s_x[(bi * 32 + r) * LX + c] - (s_t[r * LX + c] + s_t[(32 + r) * LX + c]);
+            s_t[r * LX + c] = s_x[(bi * 32 + r) * LX + c] - ((s_t[r * LX + c] + s_t[(32 + r) * LX + c]) + (s_t[(64 + r) * LX + c] + s_t[(96 + r) * LX + c]));
         }
         __syncthreads();
         if (wave < 2) {
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     // ---- backward substitution  W_i = Dinv_i^T (Y_i - sum_{k>i} L_ki^T W_k),  i = nbl-1 .. 0  (module.py:101)
     for (int bi = nbl - 1; bi >= 0; --bi) {
         vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k = bi + 1 + kpar; k < nbl; k += 2) {
+        for (int k = bi + 1 + kpar; k < nbl; k += KP) {
             const float* Lb = s_L + (size_t)tri(k, bi) * 32 * LB;
             post_mma32(acc, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Lb[m * LB + 16 * tile + i]; });
         }
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         __syncthreads();
         for (int e = tid; e < 32 * 16; e += VJF_POST_THREADS) {
             const int r = e >> 4, c = e & 15;
-            s_t[r * LX + c] = s_x[(bi * 32 + r) * LX + c] - (s_t[r * LX + c] + s_t[(32 + r) * LX + c]);
+            s_t[r * LX + c] = s_x[(bi * 32 + r) * LX + c] - ((s_t[r * LX + c] + s_t[(32 + r) * LX + c]) + (s_t[(64 + r) * LX + c] + s_t[(96 + r) * LX + c]));
         }
         __syncthreads();
         if (wave < 2) {
