@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown-steps", type=int, default=20)
+    ap.add_argument("--no-overlap", action="store_true", help="one-stream order inside filter_sequence (A/B of the schedule)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,6 +133,8 @@ def main():
     T = W + K
     torch.manual_seed(0)                                       # identical parameters on every rank
     model = vjf_amd.VJF.make_model(c["dy"], c["dz"], c["du"], c["n"], c["hidden"], likelihood=c["lik"], noise="device")
+    if a.no_overlap:
+        model.set_overlap(False)
     y = synth_data(c, T, 1234 + rank, dev)                      # each rank filters its own trials
     eps = torch.randn(T, 2, c["B"], c["dz"], device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + rank))
 

@@ -114,6 +114,11 @@ int vjf_set_stream(vjf_ctx* ctx, void* stream);
 /* Synchronises the stream, returns and clears the sticky status bits. */
 int vjf_get_status(vjf_ctx* ctx, uint32_t* status);
 
+/* vjf_filter_seq runs the RLS chain of a step on a second (internal, non-blocking) stream beside the trial / SGD
+ * chain when the fast kernels apply (default on; results are bit-identical either way).  enable = 0 forces the
+ * one-stream order.  Returns the resulting setting (1 / 0), or a negative error code. */
+int vjf_set_overlap(vjf_ctx* ctx, int enable);
+
 /* Diagnostic: enable/disable s_memtime phase stamps in the serial kernel and (out32 != NULL) copy the
  * 32 stamp words of the last step to the host.  Not part of the reference surface. */
 int vjf_debug_stamps(vjf_ctx* ctx, int enable, uint64_t* out32);

@@ -66,6 +66,7 @@ class FakeLib:
         return 0
 
     def vjf_set_stream(self, ctx, stream): return 0
+    def vjf_set_overlap(self, ctx, enable): return 0
 
     def vjf_get_status(self, ctx, out):
         c = self.ctxs[ctx.value]

@@ -138,6 +138,27 @@ def test_filter_sequence_equals_steps(vjf):
     close(mu, z["out.mu"], **POST)
 
 
+def test_filter_sequence_two_stream_equals_one_stream(vjf):
+    """vjf_filter_seq's two-stream schedule (RLS chain beside the trial / SGD chain) is a re-ordering of independent
+    kernels only: every output and the whole state blob match the one-stream order bit for bit."""
+    z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
+    m1, m2 = _model_for(vjf, info), _model_for(vjf, info)
+    load_fixture_state(m1, z, "s0")
+    load_fixture_state(m2, z, "s0")
+    m2.set_overlap(False)
+    u = torch.tensor(z["u"]) if info["du"] else None
+    for rep in range(2):                       # second call: starts from a posterior, TRI_CLEAN already set
+        q1 = q2 = None
+        if rep:
+            q1, q2 = vjf.Gaussian(o1[0][-1], o1[1][-1]), vjf.Gaussian(o2[0][-1], o2[1][-1])
+        o1 = m1.filter_sequence(torch.tensor(z["y"]), u, q1, eps=torch.tensor(z["eps"]))
+        o2 = m2.filter_sequence(torch.tensor(z["y"]), u, q2, eps=torch.tensor(z["eps"]))
+        for a, b in zip(o1, o2):
+            assert torch.equal(a, b)
+        assert torch.equal(m1._blob, m2._blob)
+    assert m1.status() == 0 and m2.status() == 0
+
+
 def test_seeded_drop_in(vjf):
     """make_model under torch.manual_seed + noise drawn from the CPU generator in the reference's
     order reproduce the reference's un-patched trajectory."""

@@ -90,7 +90,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t E, ACT, DEL, partial, slabs, red, work, jobs, aux, post, total;
+    size_t E, ACT, DEL, partial, slabs, red, red2, work, jobs, aux, post, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -103,6 +103,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.partial = take(((size_t)max_batch / 4 + 2) * RS_N * 4);
     c.slabs = take((size_t)njobs * split_for(max_batch) * 1024 * 4);
     c.red = take((size_t)P.red_len * 4);
+    c.red2 = take((size_t)P.red_len * 4);                  // odd steps' RLS statistics in the two-stream sequence
     c.work = take(vjf_serial_work_floats(P) * 4 + 256);   // + 32 u64 diagnostic stamps
     c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
@@ -139,6 +140,10 @@ struct vjf_ctx {
     bool stamps;           // diagnostic: record s_memtime phase stamps in the serial kernel
     bool fast_chol;        // n_rbf <= 224: prep kernel + LDS-resident MFMA Cholesky; else the generic serial kernel
     size_t lds_chol;
+    int n_ejobs;           // jobs [0, n_ejobs) are the E^T E tiles, the rest gradient tiles
+    bool overlap;          // vjf_filter_seq: RLS chain on a second stream beside the trial / SGD chain
+    hipStream_t stream2;
+    hipEvent_t ev_e, ev_b, ev_s;
 };
 
 extern "C" {
@@ -208,8 +213,13 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->post_kernels = fast_chol && P.dz <= 16 && c->lds_post <= kMaxLds - 1024;
     c->lds_k1m = vjf_trial_mfma_lds_floats(P) * 4;
     c->mfma_trial = c->lds_k1m <= kMaxLds - 1024;
+    c->n_ejobs = 0;
+    for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
+    c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
+    c->stream2 = nullptr; c->ev_e = c->ev_b = c->ev_s = nullptr;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red2, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs` (host) must outlive the copy
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
     allow_lds(vjf_trial_kernel<16>, c->lds_k1); allow_lds(vjf_trial_kernel<8>, c->lds_k1); allow_lds(vjf_trial_kernel<4>, c->lds_k1);
@@ -224,8 +234,19 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
 }
 
 int vjf_ctx_destroy(vjf_ctx* ctx) {
+    if (ctx && ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipEventDestroy(ctx->ev_e); (void)hipEventDestroy(ctx->ev_b); (void)hipEventDestroy(ctx->ev_s);
+        (void)hipStreamDestroy(ctx->stream2);
+    }
     delete ctx;
     return 0;
+}
+
+int vjf_set_overlap(vjf_ctx* ctx, int enable) {
+    if (!ctx) return fail(-1, "vjf_set_overlap: null context");
+    ctx->overlap = enable != 0 && ctx->fast_chol && ctx->post_kernels && ctx->mfma_trial;
+    return ctx->overlap ? 1 : 0;
 }
 
 int vjf_set_stream(vjf_ctx* ctx, void* stream) {
@@ -270,51 +291,193 @@ int refresh_aux(vjf_ctx* c) {
     return 0;
 }
 
-// K1 + Gram + slab reduce.  `aux_fresh`: the transposed weight copies are known to match the state blob.
-int launch_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
-                 const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags, bool aux_fresh) {
+constexpr unsigned kScAll = (1u << RS_N) - 1u;
+constexpr unsigned kScRls = 1u << RS_SDX2;                 // the one loss sum the RLS chain reads
+
+int check_step_args(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
+                    const float* eps_s, const float* eps_t, float* mu_t, float* lv_t) {
     if (B < 1 || B > c->cfg.max_batch) return fail(-20, "vjf_filter: B=%d outside [1, max_batch=%d]", B, c->cfg.max_batch);
     if (!y || !eps_s || !eps_t || !mu_t || !lv_t) return fail(-1, "vjf_filter: null tensor");
     if (c->plan.du > 0 && !u) return fail(-21, "vjf_filter: u is required when udim > 0");
     if ((mu_s == nullptr) != (lv_s == nullptr)) return fail(-22, "vjf_filter: mu_s and lv_s must both be given or both be null");
-    const VjfPlan& P = c->plan;
+    return 0;
+}
+
+VjfTrialArgs trial_args(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
+                        const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags) {
     VjfTrialArgs a{};
     a.y = y; a.u = u; a.mu_s = mu_s; a.lv_s = lv_s; a.eps_s = eps_s; a.eps_t = eps_t; a.mu_t = mu_t; a.lv_t = lv_t;
     a.state = c->state;
     a.E = (float*)(c->ws + c->cv.E); a.ACT = (float*)(c->ws + c->cv.ACT); a.DEL = (float*)(c->ws + c->cv.DEL);
     a.partial = (float*)(c->ws + c->cv.partial);
     a.B = B; a.flags = flags;
-    int nblk;
+    return a;
+}
+
+int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16 : (B + c->TB - 1) / c->TB; }
+
+// K1.  part: 0 whole step, 1 forward half, 2 backward half (matrix-core kernel only)
+int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st) {
+    const VjfPlan& P = c->plan;
+    const int nblk = trial_blocks(c, a.B);
     if (c->mfma_trial) {
-        if (!aux_fresh) { int rc = refresh_aux(c); if (rc) return rc; }
         VjfTrialMfmaArgs m{};
-        m.t = a; m.aux = (const float*)(c->ws + c->cv.aux);
+        m.t = a; m.aux = (const float*)(c->ws + c->cv.aux); m.part = part;
         m.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
-        nblk = (B + 15) / 16;
-        hipLaunchKernelGGL(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, c->stream, P, m);
+        hipLaunchKernelGGL(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, P, m);
     } else {
-        nblk = (B + c->TB - 1) / c->TB;
         switch (c->TB) {
-            case 16: hipLaunchKernelGGL(vjf_trial_kernel<16>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
-            case 8: hipLaunchKernelGGL(vjf_trial_kernel<8>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
-            default: hipLaunchKernelGGL(vjf_trial_kernel<4>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, c->stream, P, a); break;
+            case 16: hipLaunchKernelGGL(vjf_trial_kernel<16>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, st, P, a); break;
+            case 8: hipLaunchKernelGGL(vjf_trial_kernel<8>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, st, P, a); break;
+            default: hipLaunchKernelGGL(vjf_trial_kernel<4>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, st, P, a); break;
         }
     }
     VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+// Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
+int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st) {
+    const VjfPlan& P = c->plan;
     const int nsplit = split_for(B);
     VjfGramArgs g{};
     g.jobs = (const VjfJob*)(c->ws + c->cv.jobs);
-    g.E = a.E; g.ACT = a.ACT; g.DEL = a.DEL;
+    g.E = (const float*)(c->ws + c->cv.E); g.ACT = (const float*)(c->ws + c->cv.ACT); g.DEL = (const float*)(c->ws + c->cv.DEL);
     g.slabs = (float*)(c->ws + c->cv.slabs);
-    g.B = B; g.nsplit = nsplit;
+    g.B = B; g.nsplit = nsplit; g.job0 = job0;
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
-    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c->njobs * nsplit), dim3(256), 0, c->stream, P, g);
+    hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(256), 0, st, P, g);
     VJF_HIP(hipGetLastError());
     VjfReduceArgs r{};
-    r.jobs = g.jobs; r.slabs = g.slabs; r.partial = a.partial; r.red = (float*)(c->ws + c->cv.red);
-    r.njobs = c->njobs; r.nsplit = nsplit; r.nblocks_k1 = nblk;
-    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c->njobs + 1), dim3(256), 0, c->stream, P, r);
+    r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + c->cv.partial); r.red = red;
+    r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask;
+    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(256), 0, st, P, r);
     VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+// which: 0 whole prep grid, 1 RLS operand rows only, 2 SGD + scalars only
+int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const float* red, int which, hipStream_t st) {
+    const VjfPlan& P = c->plan;
+    VjfPrepArgs p{};
+    p.state = c->state; p.red = red; p.gbuf = (float*)(c->ws + c->cv.work);
+    p.aux = (float*)(c->ws + c->cv.aux);
+    p.loss4 = loss4; p.B_total = B_total; p.flags = flags;
+    p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
+    p.n_sgdblk = (P.train_len + 1023) / 1024;
+    p.bid0 = which == 2 ? p.n_rowblk : 0;
+    const int grid = which == 0 ? p.n_rowblk + p.n_sgdblk + 1 : which == 1 ? p.n_rowblk : p.n_sgdblk + 1;
+    hipLaunchKernelGGL(vjf_prep_kernel, dim3(grid), dim3(256), 0, st, P, p);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+// Cholesky + RLS tail + state-noise update.  `before_chol` / `before_post`: events the stream waits for first (or null).
+int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, hipEvent_t before_chol,
+               hipEvent_t before_post) {
+    const VjfPlan& P = c->plan;
+    if (!(flags & VJF_FLAG_UPDATE)) return 0;
+    VjfCholArgs a{};
+    a.state = c->state; a.red = red; a.gbuf = (const float*)(c->ws + c->cv.work); a.B_total = B_total; a.flags = flags;
+    a.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
+    const int nbl = (P.n + 31) / 32;
+    float* dinv = (float*)(c->ws + c->cv.post);
+    double* rpart = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
+    int* okflag = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
+    a.post = c->post_kernels ? 1 : 0; a.dinv_out = dinv; a.ok_out = okflag;
+    if (before_chol) VJF_HIP(hipStreamWaitEvent(st, before_chol, 0));
+    switch (vjf_chol_dzp(P.dz)) {
+        case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+        case 8: hipLaunchKernelGGL(vjf_chol_lds_kernel<8>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+        case 12: hipLaunchKernelGGL(vjf_chol_lds_kernel<12>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+        case 16: hipLaunchKernelGGL(vjf_chol_lds_kernel<16>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+        default: hipLaunchKernelGGL(vjf_chol_lds_kernel<32>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+    }
+    VJF_HIP(hipGetLastError());
+    if (before_post) VJF_HIP(hipStreamWaitEvent(st, before_post, 0));
+    if (c->post_kernels) {
+        const bool rls = !(flags & VJF_FLAG_WARM_UP);
+        if (rls) {
+            VjfPostArgs pa{};
+            pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.ok = okflag;
+            hipLaunchKernelGGL(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st, P, pa);
+            VJF_HIP(hipGetLastError());
+        }
+        VjfResidArgs ra{};
+        ra.state = c->state; ra.red = red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
+        hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra);
+        hipLaunchKernelGGL(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, P, ra, rls ? (const int*)okflag : (const int*)nullptr);
+        VJF_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// K1 + Gram + slab reduce.  `aux_fresh`: the transposed weight copies are known to match the state blob.
+int launch_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
+                 const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags, bool aux_fresh) {
+    int rc = check_step_args(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t);
+    if (rc) return rc;
+    if (c->mfma_trial && !aux_fresh) { rc = refresh_aux(c); if (rc) return rc; }
+    rc = launch_trial(c, trial_args(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags), 0, c->stream);
+    if (rc) return rc;
+    return launch_gram(c, B, 0, c->njobs, kScAll, (float*)(c->ws + c->cv.red), c->stream);
+}
+
+int ensure_stream2(vjf_ctx* c) {
+    if (c->stream2) return 0;
+    VJF_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    VJF_HIP(hipEventCreateWithFlags(&c->ev_e, hipEventDisableTiming));
+    VJF_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+    VJF_HIP(hipEventCreateWithFlags(&c->ev_s, hipEventDisableTiming));
+    return 0;
+}
+
+// The sequence on two streams.  Step t's work splits into
+//   chain A (caller's stream): K1 backward half(t) -> gradient Gram -> clip + SGD -> K1 forward half(t+1) -> E^T E Gram(t+1)
+//   chain B (second stream):   P += G/v, g -> Cholesky -> [K1 backward half(t) done] -> W, w_chol -> residual -> sigma
+// K1's backward half(t+1) needs W, w_chol, sigma of step t, nothing else on chain A does; chain B(t+1) needs only the
+// forward half's E rows.  So chain A of step t runs beside chain B of step t, and a step costs max(A, B) instead of A + B.
+// Results are those of the one-stream order bit for bit (same kernels, same sums).  RLS statistics alternate between two
+// reduce buffers so that chain A may produce step t+1's while chain B still reads step t's.
+int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
+                       const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
+    int rc = ensure_stream2(c);
+    if (rc) return rc;
+    const VjfPlan& P = c->plan;
+    const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
+    hipStream_t sa = c->stream, sb = c->stream2;
+    float* red[2] = {(float*)(c->ws + c->cv.red), (float*)(c->ws + c->cv.red2)};
+    auto args = [&](int t) {
+        return trial_args(c, B, y + t * sy, u ? u + t * su : nullptr, t ? mu + (t - 1) * sz : mu0, t ? lv + (t - 1) * sz : lv0,
+                          eps + (size_t)t * 2 * sz, eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags);
+    };
+    rc = check_step_args(c, B, y, u, mu0, lv0, eps, eps + sz, mu, lv);
+    if (rc) return rc;
+    rc = refresh_aux(c);
+    if (rc) return rc;
+    const int ne = c->n_ejobs, ng = c->njobs - ne;
+    // prologue: forward half and RLS statistics of step 0
+    if ((rc = launch_trial(c, args(0), 1, sa))) return rc;
+    if ((rc = launch_gram(c, B, 0, ne, kScRls, red[0], sa))) return rc;
+    VJF_HIP(hipEventRecord(c->ev_e, sa));
+    for (int t = 0; t < T; ++t) {
+        VJF_HIP(hipStreamWaitEvent(sb, c->ev_e, 0));                       // chain B(t) <- E^T E(t)
+        if (t > 0) VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));            // backward half(t) <- W, w_chol, sigma of t-1
+        if ((rc = launch_trial(c, args(t), 2, sa))) return rc;
+        VJF_HIP(hipEventRecord(c->ev_b, sa));
+        if ((rc = launch_prep(c, B, nullptr, flags, red[t & 1], 1, sb))) return rc;
+        // the first Cholesky of a blob clears w_chol's zero half in place (VJF_SC_TRI_CLEAN): keep it behind the reader
+        if ((rc = launch_rls(c, B, flags, red[t & 1], sb, t == 0 ? c->ev_b : nullptr, c->ev_b))) return rc;
+        VJF_HIP(hipEventRecord(c->ev_s, sb));
+        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, red[0], sa))) return rc;
+        if ((rc = launch_prep(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags, red[0], 2, sa))) return rc;
+        if (t + 1 < T) {
+            if ((rc = launch_trial(c, args(t + 1), 1, sa))) return rc;
+            if ((rc = launch_gram(c, B, 0, ne, kScRls, red[(t + 1) & 1], sa))) return rc;
+            VJF_HIP(hipEventRecord(c->ev_e, sa));
+        }
+    }
+    VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                           // join: the caller's stream sees the final state
     return 0;
 }
 }  // namespace
@@ -329,48 +492,10 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
     if (!c) return fail(-1, "vjf_filter_global: null context");
     if (B_total < 1) return fail(-20, "vjf_filter_global: B_total=%d", B_total);
     if (c->fast_chol) {
-        const VjfPlan& P = c->plan;
-        VjfPrepArgs p{};
-        p.state = c->state; p.red = (const float*)(c->ws + c->cv.red); p.gbuf = (float*)(c->ws + c->cv.work);
-        p.aux = (float*)(c->ws + c->cv.aux);
-        p.loss4 = loss4; p.B_total = B_total; p.flags = flags;
-        p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
-        p.n_sgdblk = (P.train_len + 1023) / 1024;
-        hipLaunchKernelGGL(vjf_prep_kernel, dim3(p.n_rowblk + p.n_sgdblk + 1), dim3(256), 0, c->stream, P, p);
-        VJF_HIP(hipGetLastError());
-        if (flags & VJF_FLAG_UPDATE) {
-            VjfCholArgs a{};
-            a.state = c->state; a.red = p.red; a.gbuf = p.gbuf; a.B_total = B_total; a.flags = flags;
-            a.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
-            const int nbl = (P.n + 31) / 32;
-            float* dinv = (float*)(c->ws + c->cv.post);
-            double* rpart = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
-            int* okflag = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
-            a.post = c->post_kernels ? 1 : 0; a.dinv_out = dinv; a.ok_out = okflag;
-            switch (vjf_chol_dzp(P.dz)) {
-                case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
-                case 8: hipLaunchKernelGGL(vjf_chol_lds_kernel<8>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
-                case 12: hipLaunchKernelGGL(vjf_chol_lds_kernel<12>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
-                case 16: hipLaunchKernelGGL(vjf_chol_lds_kernel<16>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
-                default: hipLaunchKernelGGL(vjf_chol_lds_kernel<32>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, c->stream, P, a); break;
-            }
-            VJF_HIP(hipGetLastError());
-            if (c->post_kernels) {
-                const bool rls = !(flags & VJF_FLAG_WARM_UP);
-                if (rls) {
-                    VjfPostArgs pa{};
-                    pa.state = c->state; pa.dinv = dinv; pa.gbuf = p.gbuf; pa.ok = okflag;
-                    hipLaunchKernelGGL(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, c->stream, P, pa);
-                    VJF_HIP(hipGetLastError());
-                }
-                VjfResidArgs ra{};
-                ra.state = c->state; ra.red = p.red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
-                hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, c->stream, P, ra);
-                hipLaunchKernelGGL(vjf_sigma_kernel, dim3(1), dim3(64), 0, c->stream, P, ra, rls ? (const int*)okflag : (const int*)nullptr);
-                VJF_HIP(hipGetLastError());
-            }
-        }
-        return 0;
+        const float* red = (const float*)(c->ws + c->cv.red);
+        int rc = launch_prep(c, B_total, loss4, flags, red, 0, c->stream);
+        if (rc) return rc;
+        return launch_rls(c, B_total, flags, red, c->stream, nullptr, nullptr);
     }
     VjfSerialArgs s{};
     s.state = c->state; s.red = (const float*)(c->ws + c->cv.red); s.work = (float*)(c->ws + c->cv.work);
@@ -392,6 +517,8 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
     if (!c) return fail(-1, "vjf_filter_seq: null context");
     if (T < 1) return fail(-23, "vjf_filter_seq: T=%d", T);
     if (!y || !eps || !mu || !lv) return fail(-1, "vjf_filter_seq: null tensor");
+    if (c->overlap && !c->stamps && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP))
+        return filter_seq_overlap(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
     const VjfPlan& P = c->plan;
     const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
     const float* ms = mu0; const float* ls = lv0;
@@ -645,7 +772,7 @@ int vjf_blr_rls(const float* x, const float* target, const float* v, float shrin
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(ws + c.partial); r.red = (float*)(ws + c.red);
     r.njobs = c.njobs; r.nsplit = c.nsplit; r.nblocks_k1 = 1;
-    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c.njobs + 1), dim3(256), 0, s, P, r);
+    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c.njobs), dim3(256), 0, s, P, r);   // sc_mask = 0: no loss sums here
     VJF_HIP(hipGetLastError());
     allow_lds(vjf_rls_kernel, lds);
     VjfRlsArgs a{};

@@ -33,11 +33,13 @@ struct VjfPrepArgs {
     int B_total;
     unsigned flags;
     int n_rowblk, n_sgdblk;
+    int bid0;             // first logical workgroup of this launch: 0 (whole grid, or the RLS-operand rows only)
+                          // or n_rowblk (SGD + scalars only) -- the two halves run on different streams in vjf_filter_seq
 };
 
-// grid = n_rowblk + n_sgdblk + 1
+// logical grid = n_rowblk + n_sgdblk + 1
 __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A) {
-    const int tid = threadIdx.x, bid = blockIdx.x;
+    const int tid = threadIdx.x, bid = blockIdx.x + A.bid0;
     float* S = A.state;
     float* SC = S + P.off[VJF_SLOT_SCALARS];
     const float* RSC = A.red + P.red_SC;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
         if (A.loss4) { A.loss4[0] = loss; A.loss4[1] = -l_recon; A.loss4[2] = -l_dyn; A.loss4[3] = ent; }
         const unsigned st = (ok_r ? 0u : VJF_STATUS_NONFINITE_RECON) | (ok_d ? 0u : VJF_STATUS_NONFINITE_DYN) |
                             (ok_h ? 0u : VJF_STATUS_NONFINITE_ENT);
-        if (st) SC[VJF_SC_STATUS] = (float)((unsigned)SC[VJF_SC_STATUS] | st);
+        if (st) vjf_status_or(SC + VJF_SC_STATUS, st);
         if (P.lik == VJF_LIK_GAUSSIAN) {
             const float sse_y = RSC[RS_SSEY];
             float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
             const float inv_v = expf(-sig);
             for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) Pm[e] = Pm[e] - G[e] * inv_v;
             if (A.post) {
-                if (tid == 0) { A.ok_out[0] = 0; SC[VJF_SC_STATUS] = (float)((unsigned)SC[VJF_SC_STATUS] | st); }
+                if (tid == 0) { A.ok_out[0] = 0; vjf_status_or(SC + VJF_SC_STATUS, st); }
                 return;
             }
         } else {
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
         const float acc = fminf(SC[VJF_SC_N_TR], 500.f), tot = acc + Bf;   // running_var, size_cap=500 (model.py:375)
         S[P.off[VJF_SLOT_TR_LOGVAR]] = logf((acc / tot) * expf(sig) + (Bf / tot) * mse);
         SC[VJF_SC_N_TR] = tot;
-        if (st) SC[VJF_SC_STATUS] = (float)((unsigned)SC[VJF_SC_STATUS] | st);
+        if (st) vjf_status_or(SC + VJF_SC_STATUS, st);
     }
     VJF_STAMP(8);
 }

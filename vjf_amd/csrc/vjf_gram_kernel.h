@@ -19,13 +19,14 @@ struct VjfGramArgs {
     const float* E; const float* ACT; const float* DEL;
     float* slabs;            // (njobs, nsplit, 1024)
     int B, nsplit, rows_per_split;
+    int job0;                // first job of this launch (the grid covers a contiguous job range)
 };
 
 __global__ __launch_bounds__(256) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A) {
     __shared__ float s_acc[3 * 1024];
     // linear id = job * nsplit + split: workgroups are dealt round-robin over the 8 XCDs, so with nsplit a
     // multiple of 8 every job of one trial range lands on the same XCD and re-reads its rows from that L2
-    const int split = blockIdx.x % A.nsplit, jobid = blockIdx.x / A.nsplit;
+    const int split = blockIdx.x % A.nsplit, jobid = A.job0 + blockIdx.x / A.nsplit;
     const VjfJob job = A.jobs[jobid];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, kh = lane >> 5;
@@ -83,9 +84,11 @@ struct VjfReduceArgs {
     const float* partial;     // (nblocks_k1, RS_N) per-workgroup loss sums from K1
     float* red;               // reduce buffer
     int njobs, nsplit, nblocks_k1;
+    int job0;                 // first job of this launch; njobs = jobs in this launch
+    unsigned sc_mask;         // which of K1's loss sums the extra workgroup reduces (bit per RS_* index)
 };
 
-// grid = njobs + 1 workgroups of 256 threads; the extra workgroup sums K1's loss partials.
+// grid = njobs + 1 workgroups of 256 threads; the extra workgroup sums K1's loss partials (sc_mask == 0: grid = njobs).
 __global__ __launch_bounds__(256) void vjf_gram_reduce_kernel(VjfPlan P, VjfReduceArgs A) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x == A.njobs) {
@@ -96,15 +99,15 @@ __global__ __launch_bounds__(256) void vjf_gram_reduce_kernel(VjfPlan P, VjfRedu
         for (int b = l; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
         s_part[tid] = v;
         __syncthreads();
-        if (l == 0) {
+        if (l == 0 && ((A.sc_mask >> sc) & 1u)) {
             double t = 0.0;
             for (int i = 0; i < 32; ++i) t += s_part[sc * 32 + i];
             A.red[P.red_SC + sc] = (float)t;
         }
         return;
     }
-    const VjfJob job = A.jobs[blockIdx.x];
-    const float* slab = A.slabs + (size_t)blockIdx.x * A.nsplit * 1024;
+    const VjfJob job = A.jobs[A.job0 + blockIdx.x];
+    const float* slab = A.slabs + (size_t)(A.job0 + blockIdx.x) * A.nsplit * 1024;
     for (int e = tid; e < 1024; e += 256) {
         float v = 0.f;
         int s = 0;

@@ -163,3 +163,15 @@ struct VjfJob {
     int dst_b;         // kind 1: offset in the grad region of the bias (-1: none)
     int row_skip;      // kind 1: first row_skip... unused, 0
 };
+
+// OR status bits into the status scalar (a float holding a small integer).  Kernels of one step may run on two
+// streams (vjf_filter_seq), so the read-modify-write is a compare-and-swap loop.
+__device__ __forceinline__ void vjf_status_or(float* p, unsigned bits) {
+    unsigned* u = reinterpret_cast<unsigned*>(p);
+    unsigned old = *u, assumed;
+    do {
+        assumed = old;
+        const float nv = (float)((unsigned)__uint_as_float(assumed) | bits);
+        old = atomicCAS(u, assumed, __float_as_uint(nv));
+    } while (old != assumed);
+}

@@ -229,5 +229,5 @@ __global__ __launch_bounds__(64) void vjf_sigma_kernel(VjfPlan P, VjfResidArgs A
     const float acc = fminf(SC[VJF_SC_N_TR], 500.f), tot = acc + Bf;           // running_var, size_cap=500 (model.py:375)
     S[P.off[VJF_SLOT_TR_LOGVAR]] = logf((acc / tot) * expf(sig) + (Bf / tot) * mse);
     SC[VJF_SC_N_TR] = tot;
-    if (ok && ok[0] == 0) SC[VJF_SC_STATUS] = (float)((unsigned)SC[VJF_SC_STATUS] | VJF_STATUS_RLS_FAILED);
+    if (ok && ok[0] == 0) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
 }

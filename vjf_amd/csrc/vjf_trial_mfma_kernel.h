@@ -71,6 +71,10 @@ struct VjfTrialMfmaArgs {
     VjfTrialArgs t;
     const float* aux;      // transposed weights (VjfPlan::aux_*)
     unsigned long long* stamps;   // diagnostic only (null in normal runs)
+    int part;              // 0: whole step; 1: forward half (features, recognition, E / ACT rows, posterior);
+                           // 2: backward half (predictive mean / variance, losses, backward, DEL rows) -- reloads the
+                           //    forward half's rows, so that it can run after the RLS update of the previous step while
+                           //    the forward half of this step ran beside it (vjf_filter_seq, two streams)
 };
 
 #define VJF_K1_STAMP(i)                                                                     \
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
     const bool prior = (A.mu_s == nullptr);
     const bool warm = (A.flags & VJF_FLAG_WARM_UP) != 0;
     const bool tri = S[P.off[VJF_SLOT_SCALARS] + VJF_SC_TRI_CLEAN] != 0.f;   // w_chol known upper triangular
+    const bool fwd = AA.part != 2, bwd = AA.part != 1;
     constexpr int LD = VJF_LDT;
     constexpr int NW = VJF_K1M_WAVES;
 
@@ -155,7 +160,10 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
 
     VJF_K1_STAMP(23);
     // ---- stage 1: RBF features (functional.py:11-22); lanes walk the trial index
-    {
+    if (!fwd) {                                   // backward half: the forward half left Phi in the E rows
+        for (int b = wave; b < 16; b += NW)
+            for (int c = lane; c < n; c += 64) s_phi[c * LD + b] = b < nb ? A.E[(size_t)(b0 + b) * P.ldE + c] : 0.f;
+    } else {
         // centroids and -1/(2 w^2) staged in LDS (the delta buffers are free until the backward pass)
         const float* cen = S + P.off[VJF_SLOT_CENTROID];
         const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
 
     VJF_K1_STAMP(24);
     // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
-    {
+    if (bwd) {
         const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
         const int ntile = (n + 15) >> 4;
         float v2 = 0.f;
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
         }
     }
     __syncthreads();
-    if (tid < 16) {
+    if (bwd && tid < 16) {
         float v = 0.f;
         for (int w = 0; w < NW; ++w) v += s_red[w * 16 + tid];
         s_plv[tid] = logf(v);
@@ -223,7 +231,20 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
 
     VJF_K1_STAMP(25);
     // ---- stage 3: recognition forward (recognition.py:31-42)
-    {
+    if (!fwd) {                                   // backward half: hidden activations from the ACT rows, posterior from the outputs
+        for (int b = wave; b < 16; b += NW) {
+            int aoff = 0;
+            for (int l = 0; l < P.L; ++l) {
+                const int hl = P.h[l], c0 = P.colA_act[l + 1];
+                for (int k = lane; k < hl; k += 64) s_act[(aoff + k) * LD + b] = b < nb ? A.ACT[(size_t)(b0 + b) * P.ldA + c0 + k] : 0.f;
+                aoff += hl;
+            }
+            for (int j = lane; j < dz; j += 64) {
+                s_mu[j * LD + b] = b < nb ? A.mu_t[(size_t)(b0 + b) * dz + j] : 0.f;
+                s_lv[j * LD + b] = b < nb ? A.lv_t[(size_t)(b0 + b) * dz + j] : 0.f;
+            }
+        }
+    } else {
         const float* xin = s_in;
         int kin = din, aoff = 0;
         for (int l = 0; l < P.L; ++l) {
@@ -264,13 +285,13 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
         const int j = e >> 4, b = e & 15;
         s_xt[j * LD + b] = fmaf(s_e2[j * LD + b], expf(0.5f * s_lv[j * LD + b]), s_mu[j * LD + b]);
     }
-    for (int e = tid; e < nb * dz; e += VJF_K1M_THREADS) {                          // coalesced posterior stores
+    if (fwd) for (int e = tid; e < nb * dz; e += VJF_K1M_THREADS) {                 // coalesced posterior stores
         const int b = e / dz, j = e - b * dz;
         A.mu_t[(size_t)(b0 + b) * dz + j] = s_mu[j * LD + b];
         A.lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
     }
     __syncthreads();
-    {
+    if (bwd) {
         const float* CT = AA.aux + P.aux_decT;                         // (dz, dy)
         const float* d = S + P.off[VJF_SLOT_DEC_B];
         const int mt = (dy + 15) >> 4;
@@ -287,8 +308,27 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
     __syncthreads();
 
     VJF_K1_STAMP(27);
+    if (!bwd) {
+        // forward half: of the loss scalars only sum |dx|^2 (the RLS chain's residual identity needs it), summed
+        // exactly as stage 5 does; then the E and ACT rows
+        constexpr int LPT = VJF_K1M_THREADS / 16;
+        const int b = tid / LPT, s = tid % LPT;
+        float sdx2 = 0.f;
+        for (int j = s; j < dz; j += LPT) {
+            const float dx = s_xt[j * LD + b] - s_xu[j * LD + b];
+            sdx2 = fmaf(dx, dx, sdx2);
+        }
+        sdx2 = group_sum<LPT>(sdx2);
+        if (s == 0) s_sc[b * RS_N + RS_SDX2] = b < nb ? sdx2 : 0.f;
+        __syncthreads();
+        if (tid == RS_SDX2) {
+            float v = 0.f;
+            for (int bb = 0; bb < 16; ++bb) v += s_sc[bb * RS_N + tid];
+            A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
+        }
+    }
     // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
-    {
+    if (bwd) {
         constexpr int LPT = VJF_K1M_THREADS / 16;          // lanes per trial
         const int b = tid / LPT, s = tid % LPT;
         const float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
@@ -345,7 +385,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
         }
     }
     __syncthreads();
-    if (tid < RS_N) {
+    if (bwd && tid < RS_N && (fwd || tid != RS_SDX2)) {           // (the forward half owns sum |dx|^2)
         float v = 0.f;
         if (tid <= RS_SDX2) for (int b = 0; b < 16; ++b) v += s_sc[b * RS_N + tid];
         A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
@@ -353,7 +393,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
 
     VJF_K1_STAMP(28);
     // ---- stage 6: backward.  dxt = dpy C ; dmu += dxt ; dlv += dxt eps_t exp(lv/2)/2
-    {
+    if (bwd) {
         const float* C = S + P.off[VJF_SLOT_DEC_W];                    // (dy, dz): k-major for this product
         const int mt = (dz + 15) >> 4;
         for (int t = wave; t < mt; t += NW) {
@@ -370,7 +410,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
         }
     }
     __syncthreads();
-    {
+    if (bwd) {
         const int hL = P.h[P.L - 1];
         const float* Wm = S + P.off[VJF_SLOT_MEAN_W];                  // (dz, hL): k-major for dh = dmu Wm + dlv Wl
         const float* Wl = S + P.off[VJF_SLOT_LV_W];
@@ -420,22 +460,25 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
     // ---- stage 7: rows of E = [Phi | dx | 0], ACT = [in|1|h_1|1|..|h_L|1|xt|1|0], DEL = [.. | dmu | dlv | dpy].
     //      wavefront w writes the rows of trials w, w+4, ...; the lane walks the columns (coalesced, no divisions)
     for (int b = wave; b < nb; b += NW) {
-        float* erow = A.E + (size_t)(b0 + b) * P.ldE;
-        for (int c = lane; c < P.ldE; c += 64) {
-            float v = 0.f;
-            if (c < n) v = s_phi[c * LD + b];
-            else if (c < n + dz) v = s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b];
-            erow[c] = v;
+        if (fwd) {
+            float* erow = A.E + (size_t)(b0 + b) * P.ldE;
+            for (int c = lane; c < P.ldE; c += 64) {
+                float v = 0.f;
+                if (c < n) v = s_phi[c * LD + b];
+                else if (c < n + dz) v = s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b];
+                erow[c] = v;
+            }
+            float* arow = A.ACT + (size_t)(b0 + b) * P.ldA;
+            for (int c = lane; c <= din; c += 64) arow[c] = c < din ? s_in[c * LD + b] : 1.f;
+            int aoff = 0;
+            for (int l = 0; l < P.L; ++l) {
+                const int hl = P.h[l], c0 = P.colA_act[l + 1];
+                for (int k = lane; k <= hl; k += 64) arow[c0 + k] = k < hl ? s_act[(aoff + k) * LD + b] : 1.f;
+                aoff += hl;
+            }
+            for (int j = lane; P.colA_xt + j < P.ldA; j += 64) arow[P.colA_xt + j] = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f);
         }
-        float* arow = A.ACT + (size_t)(b0 + b) * P.ldA;
-        for (int c = lane; c <= din; c += 64) arow[c] = c < din ? s_in[c * LD + b] : 1.f;
-        int aoff = 0;
-        for (int l = 0; l < P.L; ++l) {
-            const int hl = P.h[l], c0 = P.colA_act[l + 1];
-            for (int k = lane; k <= hl; k += 64) arow[c0 + k] = k < hl ? s_act[(aoff + k) * LD + b] : 1.f;
-            aoff += hl;
-        }
-        for (int j = lane; P.colA_xt + j < P.ldA; j += 64) arow[P.colA_xt + j] = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f);
+        if (!bwd) continue;
         float* drow = A.DEL + (size_t)(b0 + b) * P.ldD + P.colD_dmu;
         for (int c = lane; c < 2 * dz + dy; c += 64) drow[c] = c < 2 * dz ? s_dmu[c * LD + b] : s_dpy[(c - 2 * dz) * LD + b];   // s_dlv follows s_dmu
     }

@@ -282,6 +282,13 @@ class VJF(Module):
         """decoder.requires_grad_(False) of the reference (vjf/model.py:283)."""
         self._scalars[N.SC_FREEZE_DEC] = 1.0 if frozen else 0.0
 
+    def set_overlap(self, enable: bool = True):
+        """filter_sequence runs a step's RLS chain on a second stream beside the trial / SGD chain (default);
+        False forces the one-stream order.  Results are bit-identical either way."""
+        self._overlap = bool(enable)
+        if self._ctx is not None:
+            N.check(self._backend().vjf_set_overlap(self._ctx, int(self._overlap)), "vjf_set_overlap")
+
     def status(self) -> int:
         """Sticky VJF_STATUS_* bits raised by the device since the last call (clears them)."""
         if self._ctx is None:
@@ -306,6 +313,8 @@ class VJF(Module):
         N.check(L.vjf_ctx_create(ctypes.byref(cfg), N.ptr(self._blob), N.ptr(self._workspace), nbytes.value, stream_ptr(),
                                  ctypes.byref(ctx)), "vjf_ctx_create")
         self._ctx, self._ctx_batch = ctx, B
+        if not getattr(self, "_overlap", True):
+            N.check(L.vjf_set_overlap(ctx, 0), "vjf_set_overlap")
         p, n = ctypes.c_void_p(), ctypes.c_int64()
         N.check(L.vjf_reduce_buffer(ctx, ctypes.byref(p), ctypes.byref(n)), "vjf_reduce_buffer")
         o = p.value - self._workspace.data_ptr()
