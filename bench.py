@@ -152,6 +152,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     mu, lv, loss = model.filter_sequence(y[W:], qs=q, eps=eps[W:])
+    enq = time.perf_counter() - t0                             # host time to enqueue the K steps (asynchronous launches)
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
@@ -216,7 +217,7 @@ def main():
                          "kernel": "one filter step = vjf_trial_kernel + vjf_gram_kernel + vjf_gram_reduce_kernel + "
                                    "vjf_serial_kernel (HIP events around the timed region / steps)",
                          "flops_per_trial_step": flops, "serial_flops_per_step": serial_flops,
-                         "step_us": step_s * 1e6, "trial_half_us": loc, "serial_half_us": glob,
+                         "step_us": step_s * 1e6, "host_enqueue_us_per_step": enq / K * 1e6, "trial_half_us": loc, "serial_half_us": glob,
                          "hbm_achieved_GBs": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
                          "bytes_per_trial_step": b_trial + b_shared / c["B"]},
         }

@@ -18,11 +18,12 @@ for i, nm in enumerate(names):
     print(f"{nm:16s} {(t[i+1]-t[i]):8d} cycles(100MHz ticks?)")
 print("total", t[8]-t[0])
 T=list(out)
-
-
-
-
-
+prev = T[1]
+for k in range(7):
+    print(f'chol column {k}: {T[9 + k] - prev:7d}')
+    prev = T[9 + k]
+for i, nm in enumerate(["prefetch+stage", "forward", "backward", "W store", "sigma tail"]):
+    print(f'post y/W workgroup {nm:16s} {T[17 + i] - T[16 + i]:7d}')
 names1 = ["stage0 inputs", "stage1 rbf", "stage2 var+mean", "stage3 recognition", "stage4 xt+decoder", "stage5 losses", "stage6 backward", "stage7 rows out"]
 for i, nm in enumerate(names1):
     print(f"K1 {nm:20s} {T[23+i]-T[22+i]:8d}")

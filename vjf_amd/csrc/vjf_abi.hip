@@ -1,5 +1,6 @@
 // vjf_abi.hip -- extern "C" entry points declared in include/vjf_hip.h.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -36,6 +37,13 @@ int fail(int code, const char* fmt, ...) {
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \
         if (e_ != hipSuccess) return fail(-100, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// Launch; with `stop` non-null the event rides on the kernel's own completion signal (no marker packet behind it)
+#define VJF_LAUNCH(kernel, grid, block, lds, st, stop, ...)                                             \
+    do {                                                                                               \
+        if (stop) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)(lds), st, nullptr, stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                            \
     } while (0)
 
 constexpr size_t kMaxLds = 160 * 1024;
@@ -317,14 +325,14 @@ VjfTrialArgs trial_args(vjf_ctx* c, int32_t B, const float* y, const float* u, c
 int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16 : (B + c->TB - 1) / c->TB; }
 
 // K1.  part: 0 whole step, 1 forward half, 2 backward half (matrix-core kernel only)
-int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st) {
+int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hipEvent_t stop = nullptr) {
     const VjfPlan& P = c->plan;
     const int nblk = trial_blocks(c, a.B);
     if (c->mfma_trial) {
         VjfTrialMfmaArgs m{};
         m.t = a; m.aux = (const float*)(c->ws + c->cv.aux); m.part = part;
         m.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
-        hipLaunchKernelGGL(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, P, m);
+        VJF_LAUNCH(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, stop, P, m);
     } else {
         switch (c->TB) {
             case 16: hipLaunchKernelGGL(vjf_trial_kernel<16>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, st, P, a); break;
@@ -337,7 +345,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st) {
 }
 
 // Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
-int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st) {
+int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, hipEvent_t stop = nullptr) {
     const VjfPlan& P = c->plan;
     const int nsplit = split_for(B);
     VjfGramArgs g{};
@@ -351,7 +359,7 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + c->cv.partial); r.red = red;
     r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask;
-    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(256), 0, st, P, r);
+    VJF_LAUNCH(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(256), 0, st, stop, P, r);
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -374,7 +382,7 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
 
 // Cholesky + RLS tail + state-noise update.  `before_chol` / `before_post`: events the stream waits for first (or null).
 int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, hipEvent_t before_chol,
-               hipEvent_t before_post) {
+               hipEvent_t before_post, hipEvent_t stop = nullptr) {
     const VjfPlan& P = c->plan;
     if (!(flags & VJF_FLAG_UPDATE)) return 0;
     VjfCholArgs a{};
@@ -398,16 +406,19 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
     if (c->post_kernels) {
         const bool rls = !(flags & VJF_FLAG_WARM_UP);
         if (rls) {
+            // inverse column halves + the y / W workgroup, which also carries the state-noise update
             VjfPostArgs pa{};
             pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.ok = okflag;
-            hipLaunchKernelGGL(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st, P, pa);
+            pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
+            VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st, stop, P, pa);
+            VJF_HIP(hipGetLastError());
+        } else {
+            VjfResidArgs ra{};
+            ra.state = c->state; ra.red = red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
+            hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra);
+            VJF_LAUNCH(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, stop, P, ra, (const int*)nullptr);
             VJF_HIP(hipGetLastError());
         }
-        VjfResidArgs ra{};
-        ra.state = c->state; ra.red = red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
-        hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra);
-        hipLaunchKernelGGL(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, P, ra, rls ? (const int*)okflag : (const int*)nullptr);
-        VJF_HIP(hipGetLastError());
     }
     return 0;
 }
@@ -426,9 +437,9 @@ int launch_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const fl
 int ensure_stream2(vjf_ctx* c) {
     if (c->stream2) return 0;
     VJF_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    VJF_HIP(hipEventCreateWithFlags(&c->ev_e, hipEventDisableTiming));
-    VJF_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
-    VJF_HIP(hipEventCreateWithFlags(&c->ev_s, hipEventDisableTiming));
+    VJF_HIP(hipEventCreate(&c->ev_e));          // (default flags: the events are attached to kernel launches)
+    VJF_HIP(hipEventCreate(&c->ev_b));
+    VJF_HIP(hipEventCreate(&c->ev_s));
     return 0;
 }
 
@@ -458,23 +469,19 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     const int ne = c->n_ejobs, ng = c->njobs - ne;
     // prologue: forward half and RLS statistics of step 0
     if ((rc = launch_trial(c, args(0), 1, sa))) return rc;
-    if ((rc = launch_gram(c, B, 0, ne, kScRls, red[0], sa))) return rc;
-    VJF_HIP(hipEventRecord(c->ev_e, sa));
+    if ((rc = launch_gram(c, B, 0, ne, kScRls, red[0], sa, c->ev_e))) return rc;
     for (int t = 0; t < T; ++t) {
         VJF_HIP(hipStreamWaitEvent(sb, c->ev_e, 0));                       // chain B(t) <- E^T E(t)
         if (t > 0) VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));            // backward half(t) <- W, w_chol, sigma of t-1
-        if ((rc = launch_trial(c, args(t), 2, sa))) return rc;
-        VJF_HIP(hipEventRecord(c->ev_b, sa));
+        if ((rc = launch_trial(c, args(t), 2, sa, c->ev_b))) return rc;
         if ((rc = launch_prep(c, B, nullptr, flags, red[t & 1], 1, sb))) return rc;
         // the first Cholesky of a blob clears w_chol's zero half in place (VJF_SC_TRI_CLEAN): keep it behind the reader
-        if ((rc = launch_rls(c, B, flags, red[t & 1], sb, t == 0 ? c->ev_b : nullptr, c->ev_b))) return rc;
-        VJF_HIP(hipEventRecord(c->ev_s, sb));
+        if ((rc = launch_rls(c, B, flags, red[t & 1], sb, t == 0 ? c->ev_b : nullptr, c->ev_b, c->ev_s))) return rc;
         if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, red[0], sa))) return rc;
         if ((rc = launch_prep(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags, red[0], 2, sa))) return rc;
         if (t + 1 < T) {
             if ((rc = launch_trial(c, args(t + 1), 1, sa))) return rc;
-            if ((rc = launch_gram(c, B, 0, ne, kScRls, red[(t + 1) & 1], sa))) return rc;
-            VJF_HIP(hipEventRecord(c->ev_e, sa));
+            if ((rc = launch_gram(c, B, 0, ne, kScRls, red[(t + 1) & 1], sa, c->ev_e))) return rc;
         }
     }
     VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                           // join: the caller's stream sees the final state

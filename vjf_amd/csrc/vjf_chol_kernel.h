@@ -211,10 +211,12 @@ __device__ __forceinline__ bool potrf_inv_chain(vjf_f32x16& acc, float* out, flo
         const float s = __builtin_amdgcn_rsqf(d);
         dmin = fminf(dmin, d);
         slast = s;
-        const bool on = (h == hj);
-        const float l = (on && (c >= j)) ? acc[rj] * s : 0.f;           // l[c] = L[c][j]
-        const float x = on ? racc[rj] * s : 0.f;                        // x[c] = Linv[j][c]
-        const float nl = -l;
+        // No per-column lane masks inside the chain: the A operand alone is zeroed on the other k half (which kills that
+        // k slot of both products), and entries left of the pivot -- rounding residue of earlier eliminations -- only
+        // reach rows / columns < j of the tiles, which are never read again.  The stores below mask.
+        const float l = acc[rj] * s;                                    // l[c] = L[c][j] for c >= j on half hj
+        const float x = racc[rj] * s;                                   // x[c] = Linv[j][c] on half hj
+        const float nl = (h == hj) ? -l : 0.f;
         lcol[j] = l;
         xrow[j] = x;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nl, l, acc, 0, 0, 0);
@@ -229,6 +231,95 @@ __device__ __forceinline__ bool potrf_inv_chain(vjf_f32x16& acc, float* out, flo
         }
     }
     return (dmin > 0.f) && (slast == slast) && (fabsf(slast) < 3.0e38f);   // positive pivots, no NaN / inf came through
+}
+
+// The same column chain split in three, so that each is a pure one-MFMA-per-step dependent chain (the merged chain
+// above pays the compiler's MFMA->VALU wait states twice per step: ~290 cycles/step against ~127 + ~94 + ~94 here)
+// and the inverse / the panel solves run on other wavefronts beside it.
+//   potrf_chain : L = chol(tile) -> out (lower part), pivot scales 1 / L[j][j] -> piv[0..32)
+//   inv_chain   : L^-1 (lower) -> inv, from L and the pivot scales (same arithmetic as the merged chain)
+//   trsm_chain  : in place  A_ik -> L_ik = A_ik L_kk^-T  by forward substitution on the transposed tile
+__device__ __forceinline__ bool potrf_chain(vjf_f32x16& acc, float* out, float* piv, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+    float lcol[32], sv[32];
+    float dmin = 3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int rj = (j & 3) + 4 * (j >> 3), hj = (j >> 2) & 1;      // vrow(rj, hj) == j
+        const float d = vrl(acc[rj], j + 32 * hj);
+        const float s = __builtin_amdgcn_rsqf(d);
+        dmin = fminf(dmin, d);
+        sv[j] = s;
+        const float l = acc[rj] * s;                                    // l[c] = L[c][j] for c >= j on half hj
+        const float nl = (h == hj) ? -l : 0.f;                          // (see potrf_inv_chain on the missing masks)
+        lcol[j] = l;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nl, l, acc, 0, 0, 0);
+    }
+    float pv = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int hj = (j >> 2) & 1;
+        if (h == hj && c >= j) out[vsw(c, j)] = lcol[j];
+        pv = (lane == j) ? sv[j] : pv;
+    }
+    if (lane < 32) piv[lane] = pv;
+    const float slast = sv[31];
+    return (dmin > 0.f) && (slast == slast) && (fabsf(slast) < 3.0e38f);   // positive pivots, no NaN / inf came through
+}
+
+__device__ __forceinline__ void inv_chain(const float* Lk, const float* piv, float* inv, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+    float la[32], sv[32], xrow[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int hj = (j >> 2) & 1;
+        const float l = Lk[vsw(c, j)];
+        la[j] = ((h == hj) && (c >= j)) ? -l : 0.f;
+        sv[j] = piv[j];
+    }
+    vjf_f32x16 racc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) racc[r] = (vrow(r, h) == c) ? 1.f : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int rj = (j & 3) + 4 * (j >> 3), hj = (j >> 2) & 1;
+        const float x = racc[rj] * sv[j];                               // x[c] = Linv[j][c] on half hj (la is 0 on the other)
+        xrow[j] = x;
+        racc = __builtin_amdgcn_mfma_f32_32x32x2f32(la[j], x, racc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int hj = (j >> 2) & 1;
+        if (h == hj) inv[vsw(j, c)] = (c <= j) ? xrow[j] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void trsm_chain(float* pb, const float* Lk, const float* piv, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+    float la[32], sv[32], lrow[32];
+    vjf_f32x16 acc;
+    blk_load_t(acc, pb, lane);                                          // acc = A_ik^T: row j of it is column j of A_ik
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int hj = (j >> 2) & 1;
+        const float l = Lk[vsw(c, j)];
+        la[j] = ((h == hj) && (c > j)) ? -l : 0.f;
+        sv[j] = piv[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int rj = (j & 3) + 4 * (j >> 3), hj = (j >> 2) & 1;
+        const float b = acc[rj] * sv[j];                                // b[c] = L_ik[c][j] on half hj (la is 0 on the other)
+        lrow[j] = b;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(la[j], b, acc, 0, 0, 0);   // A_ik^T[i][:] -= L_kk[i][j] L_ik[:][j], i > j
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int hj = (j >> 2) & 1;
+        if (h == hj) pb[vsw(c, j)] = lrow[j];
+    }
 }
 
 struct VjfCholArgs {
@@ -389,6 +480,7 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                 }
             }
             __syncthreads();
+            if (k < 7) VJF_STAMP(9 + k);
         }
         const bool ok = s_flag[0] != 0;
         VJF_STAMP(2);

@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vjf_plan.h"
+#include "vjf_chol_kernel.h"         // VJF_CHOL_MAXBLK, vjf_f32x16
 #include "vjf_trial_mfma_kernel.h"   // vjf_f32x4
 
 #define VJF_POST_THREADS 512
@@ -26,11 +27,25 @@ struct VjfPostArgs {
     const float* dinv;      // nbl blocks (32x32 row-major) of inverted diagonal blocks, from vjf_chol_lds_kernel
     const float* gbuf;      // (n, dz) g
     const int* ok;          // device flag written by the Cholesky kernel: 1 = factor valid
+    const float* red;       // reduce buffer (G, FDX, sum|dx|^2) of this step
+    int B_total;
+    int fold_sigma;         // 1: the y / W workgroup goes on to the state-noise update (no vjf_resid / vjf_sigma launch)
+    unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memtime of the y / W workgroup, slots 16..21
 };
+
+#define VJF_POST_STAMP(i)                                                                   \
+    do {                                                                                    \
+        if (A.stamps && solve && tid == 0) {                                                \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+            A.stamps[i] = t_;                                                               \
+        }                                                                                   \
+    } while (0)
 
 static inline size_t vjf_post_lds_bytes(const VjfPlan& P) {
     const int nbl = (P.n + 31) / 32;
-    return ((size_t)(nbl * (nbl - 1) / 2 + nbl) * 32 * VJF_POST_LDB + (size_t)nbl * 32 * VJF_POST_LDX + VJF_POST_KPAR * 32 * VJF_POST_LDX + 16) * 4;
+    // L blocks + Dinv blocks | solution | block just solved | block table
+    return ((size_t)(nbl * (nbl - 1) / 2 + nbl) * 32 * VJF_POST_LDB + (size_t)nbl * 32 * VJF_POST_LDX + 32 * VJF_POST_LDX + 64 + 16) * 4;
 }
 
 // acc(row = 4*(lane>>4)+r of the 16-row tile, col = lane&15) += sum_m A(tile row, m) * B[m][col], m < 32
@@ -52,131 +67,274 @@ __device__ __forceinline__ void post_mma32(vjf_f32x4& acc, const float* Bs, int 
 
 __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan P, VjfPostArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (A.ok[0] == 0) return;                                  // factorisation failed: RLS state stays as it was
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = P.n, dz = P.dz, nbl = (n + 31) / 32, ntri = nbl * (nbl + 1) / 2;
+    const int n = P.n, dz = P.dz, nbl = (n + 31) / 32, ntri = nbl * (nbl + 1) / 2, nlow = ntri - nbl;
+    const bool solve = (int)blockIdx.x == 2 * nbl;             // the y / W workgroup
+    const bool failed = A.ok[0] == 0;                          // factorisation failed: RLS state stays as it was
+    if (failed && !(solve && A.fold_sigma)) return;
     constexpr int LB = VJF_POST_LDB, LX = VJF_POST_LDX;
     float* s_L = lds;                                          // strictly-lower blocks [32][33] of L (bi > bj)
-    float* s_D = s_L + (size_t)(ntri - nbl) * 32 * LB;         // nbl blocks [32][33]: inverted diagonal blocks
+    float* s_D = s_L + (size_t)nlow * 32 * LB;                 // nbl blocks [32][33]: inverted diagonal blocks
     float* s_x = s_D + (size_t)nbl * 32 * LB;                  // [npad][17] right-hand sides -> solution
-    float* s_t = s_x + (size_t)nbl * 32 * LX;                  // VJF_POST_KPAR x [32][17] partial sums
+    float* s_y = s_x + (size_t)nbl * 32 * LX;                  // [32][17] the block just solved, for the eager updates
+    int* s_tab = reinterpret_cast<int*>(s_y + 32 * LX);        // block -> (bi << 8) | bj: strictly lower, then diagonal
     const float* S = A.state;
     const float* Lm = S + P.off[VJF_SLOT_W_PCHOL];
-    const bool solve = (int)blockIdx.x == 2 * nbl;             // the y / W workgroup
     const int j0 = solve ? 0 : (int)blockIdx.x >> 1;           // first block row of the substitution
     const int c0 = solve ? 0 : 16 * ((int)blockIdx.x & 1);
     auto tri = [](int bi, int bj) { return bi * (bi - 1) / 2 + bj; };       // strictly lower: bi > bj
 
-    // ---- stage L (blocks with row > col >= j0) and the inverted diagonal blocks: 8 float4 loads in flight per thread
-    {
-        const int nlow = ntri - nbl;                                           // strictly-lower blocks, index tri(bi, bj)
-        const int nchunk = (nlow + nbl) * 256;                                 // then the nbl Dinv blocks
-        for (int e0 = tid; e0 < nchunk; e0 += 8 * VJF_POST_THREADS) {
-            float4 v[8];
-            float* dst[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = e0 + q * VJF_POST_THREADS;
-                dst[q] = nullptr;
-                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < nchunk) {
-                    const int b = e >> 8, r = (e >> 3) & 31, c4 = (e & 7) * 4;
-                    if (b < nlow) {
-                        int bi = 1;
-                        while ((bi + 1) * bi / 2 <= b) ++bi;                   // tri(bi, 0) <= b < tri(bi + 1, 0)
-                        const int bj = b - bi * (bi - 1) / 2;
-                        if (bj >= j0) {
-                            const int gi = bi * 32 + r, gj = bj * 32 + c4;
-                            if (gi < n && gj < n) v[q] = *reinterpret_cast<const float4*>(Lm + (size_t)gi * n + gj);
-                            dst[q] = s_L + ((size_t)b * 32 + r) * LB + c4;
-                        }
-                    } else if (b - nlow >= j0) {
-                        v[q] = *reinterpret_cast<const float4*>(A.dinv + (size_t)(b - nlow) * 1024 + r * 32 + c4);
-                        dst[q] = s_D + ((size_t)(b - nlow) * 32 + r) * LB + c4;
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (dst[q]) { dst[q][0] = v[q].x; dst[q][1] = v[q].y; dst[q][2] = v[q].z; dst[q][3] = v[q].w; }
-        }
+    // scalars of the state-noise update, fetched now so that the tail does not wait for them
+    float pre_sdx2 = 0.f, pre_old = 0.f, pre_tot = 1.f;         // sum|dx|^2, old share of the running variance, new count
+    double pre_scale = 0.0;                                     // mse -> new share of the running variance
+    if (solve && A.fold_sigma) {
+        pre_sdx2 = A.red[P.red_SC + RS_SDX2];
+        const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
+        const float Bf = (float)A.B_total;
+        const float acc = fminf(S[P.off[VJF_SLOT_SCALARS] + VJF_SC_N_TR], 500.f);   // running_var, size_cap=500 (model.py:375)
+        pre_tot = acc + Bf;
+        pre_old = (acc / pre_tot) * expf(sig);
+        pre_scale = 1.0 / ((double)Bf * (double)P.dz);
     }
-    // right-hand side: 16 columns of the identity (inverse) or g padded to 16 columns (solve)
-    for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
-        const int r = e >> 4, c = e & 15;
-        float v;
-        if (solve) v = (r < n && c < dz) ? A.gbuf[(size_t)r * dz + c] : 0.f;
-        else v = (r == j0 * 32 + c0 + c) ? 1.f : 0.f;
-        s_x[r * LX + c] = v;
+    VJF_POST_STAMP(16);
+    if (tid < nlow) {
+        int bi = 1;
+        while ((bi + 1) * bi / 2 <= tid) ++bi;                 // tri(bi, 0) <= tid < tri(bi + 1, 0)
+        s_tab[tid] = (bi << 8) | (tid - bi * (bi - 1) / 2);
+    } else if (tid < ntri) s_tab[tid] = ((tid - nlow) << 8) | (tid - nlow);
+    if (tid >= 64 && tid < 64 + ntri) {                        // lower tiles, diagonal included: t = bi (bi + 1) / 2 + bj
+        const int t = tid - 64;
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        s_tab[32 + t] = (bi << 8) | (t - bi * (bi + 1) / 2);
     }
     __syncthreads();
 
-    const int tile = wave & 1, kpar = wave >> 1;               // 16-row tile of the block row; blocks k = first + kpar, + KPAR, ..
-    constexpr int KP = VJF_POST_KPAR;
-    // ---- forward substitution  Y_i = Dinv_i (R_i - sum_{k<i} L_ik Y_k),  i = j0 .. nbl-1, in place in s_x
-    for (int bi = j0; bi < nbl; ++bi) {
-        vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k = j0 + kpar; k < bi; k += KP) {
-            const float* Lb = s_L + (size_t)tri(bi, k) * 32 * LB;
-            post_mma32(acc, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Lb[(16 * tile + i) * LB + m]; });
+    // ---- stage L (blocks with row > col >= j0) and the inverted diagonal blocks: straight-line code, every load of a
+    //      thread (<= 14 float4: 28 blocks x 256 chunks / 512 threads) in flight before the first LDS store
+    float gpre[4][16], fpre[8];
+    if (!failed) {
+        constexpr int NQ = (VJF_CHOL_MAXBLK * (VJF_CHOL_MAXBLK + 1) / 2 * 256 + VJF_POST_THREADS - 1) / VJF_POST_THREADS;
+        // chunk e = tid + 512 q of block b = 2 q + (tid >> 8): row and column of the chunk inside its block do not depend on q
+        const int bh = tid >> 8, r = (tid >> 3) & 31, c4 = (tid & 7) * 4;
+        float4 v[NQ];
+        unsigned need = 0, put = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int b = 2 * q + bh;
+            const int code = s_tab[min(b, ntri - 1)], bi = code >> 8, bj = code & 255;
+            const int gi = bi * 32 + r, gj = bj * 32 + c4;
+            const bool isl = b < nlow;
+            const bool wanted = b < ntri && bj >= j0;                          // this workgroup's substitution reads it
+            const bool real = wanted && (!isl || (gi < n && gj < n));          // (padding rows / columns of L are zero)
+            const float* src = isl ? Lm + (size_t)gi * n + gj : A.dinv + (size_t)bj * 1024 + r * 32 + c4;
+            v[q] = *reinterpret_cast<const float4*>(real ? src : A.dinv);
+            need |= (real ? 1u : 0u) << q;
+            put |= (wanted ? 1u : 0u) << q;
+        }
+        // the y / W workgroup prefetches what its tail needs (behind the staging loads: vmcnt retires in order):
+        // wavefront w the lower 32x32 tiles w, w + 8, .. of G in the matrix-core accumulator layout, and FDX
+        if (solve && A.fold_sigma) {
+            const float* G = A.red + P.red_G;
+            const float* FDX = A.red + P.red_FDX;
+            const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                      // plain loads from clamped addresses: the
+                const int code = s_tab[32 + min(wave + 8 * q, ntri - 1)];      // tail masks what lies outside the matrix
+                const int bi = code >> 8, bj = code & 255;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gi = min(bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n - 1), gj = min(bj * 32 + c, n - 1);
+                    gpre[q][r] = G[(size_t)gi * n + gj];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {                                      // W's [row][16] grid: 224 * 16 <= 8 * 512
+                const int e = tid + q * VJF_POST_THREADS, r = min(e >> 4, n - 1), cc = min(e & 15, dz - 1);
+                fpre[q] = FDX[r * dz + cc];
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_t[(kpar * 32 + 16 * tile + 4 * (lane >> 4) + r) * LX + (lane & 15)] = acc[r];
-        __syncthreads();
-        for (int e = tid; e < 32 * 16; e += VJF_POST_THREADS) {                // T = R_i - T0 - T1  (into s_t[0])
+        for (int q = 0; q < NQ; ++q) {
+            if (!((put >> q) & 1u)) continue;
+            const int b = 2 * q + bh;
+            float* dst = (b < nlow ? s_L + ((size_t)b * 32 + r) * LB : s_D + ((size_t)(b - nlow) * 32 + r) * LB) + c4;
+            const bool real = (need >> q) & 1u;
+            dst[0] = real ? v[q].x : 0.f; dst[1] = real ? v[q].y : 0.f; dst[2] = real ? v[q].z : 0.f; dst[3] = real ? v[q].w : 0.f;
+        }
+        // right-hand side: 16 columns of the identity (inverse) or g padded to 16 columns (solve)
+        for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
             const int r = e >> 4, c = e & 15;
-            s_t[r * LX + c] = s_x[(bi * 32 + r) * LX + c] - ((s_t[r * LX + c] + s_t[(32 + r) * LX + c]) + (s_t[(64 + r) * LX + c] + s_t[(96 + r) * LX + c]));
+            float v0;
+            if (solve) v0 = (r < n && c < dz) ? A.gbuf[(size_t)r * dz + c] : 0.f;
+            else v0 = (r == j0 * 32 + c0 + c) ? 1.f : 0.f;
+            s_x[r * LX + c] = v0;
         }
         __syncthreads();
-        if (wave < 2) {
-            const float* Db = s_D + (size_t)bi * 32 * LB;
-            vjf_f32x4 y = {0.f, 0.f, 0.f, 0.f};
-            post_mma32(y, s_t, lane, [&](int i, int m) { return Db[(16 * wave + i) * LB + m]; });
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_x[(bi * 32 + 16 * wave + 4 * (lane >> 4) + r) * LX + (lane & 15)] = y[r];
-        }
-        __syncthreads();
-    }
+        VJF_POST_STAMP(17);
 
-    if (!solve) {
-        // ---- w_chol[(j0*32 + c0 + c)][i] = X[i][c]: rows of w_chol, contiguous over i  (module.py:102)
-        float* Wc = A.state + P.off[VJF_SLOT_W_CHOL];
-        const int first = j0 * 32;
-        for (int c = wave; c < 16; c += VJF_POST_THREADS / 64) {
-            const int gc = j0 * 32 + c0 + c;
-            if (gc >= n) continue;
-            for (int i = first + lane; i < n; i += 64) Wc[(size_t)gc * n + i] = s_x[i * LX + c];
-        }
-        return;
-    }
-    // ---- backward substitution  W_i = Dinv_i^T (Y_i - sum_{k>i} L_ki^T W_k),  i = nbl-1 .. 0  (module.py:101)
-    for (int bi = nbl - 1; bi >= 0; --bi) {
-        vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k = bi + 1 + kpar; k < nbl; k += KP) {
-            const float* Lb = s_L + (size_t)tri(k, bi) * 32 * LB;
-            post_mma32(acc, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Lb[m * LB + 16 * tile + i]; });
-        }
+        // Both substitutions run eagerly: as soon as block k of the solution exists (two wavefronts, one 16-row tile each),
+        // every wavefront subtracts its contribution from the 16-row tiles of the later blocks it owns, in place in s_x.
+        // Two barriers and two dependent block products per block row.
+        const int tile = wave & 1, grp = wave >> 1;            // owner of tile `tile` of blocks first + grp, first + grp + 4, ..
+        const int xr = 4 * (lane >> 4), xc = lane & 15;        // accumulator element (row xr + r, column xc) of a 16x16 tile
+        // ---- forward  Y_k = Dinv_k R_k ;  R_i -= L_ik Y_k  (i > k),   k = j0 .. nbl-1
+        for (int k = j0; k < nbl; ++k) {
+            vjf_f32x4 y = {0.f, 0.f, 0.f, 0.f};
+            if (wave < 2) {
+                const float* Db = s_D + (size_t)k * 32 * LB;
+                post_mma32(y, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Db[(16 * wave + i) * LB + m]; });
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_t[(kpar * 32 + 16 * tile + 4 * (lane >> 4) + r) * LX + (lane & 15)] = acc[r];
-        __syncthreads();
-        for (int e = tid; e < 32 * 16; e += VJF_POST_THREADS) {
-            const int r = e >> 4, c = e & 15;
-            s_t[r * LX + c] = s_x[(bi * 32 + r) * LX + c] - ((s_t[r * LX + c] + s_t[(32 + r) * LX + c]) + (s_t[(64 + r) * LX + c] + s_t[(96 + r) * LX + c]));
+                for (int r = 0; r < 4; ++r) s_y[(16 * wave + xr + r) * LX + xc] = y[r];
+            }
+            __syncthreads();
+            if (wave < 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_x[(k * 32 + 16 * wave + xr + r) * LX + xc] = y[r];
+            }
+            for (int i = k + 1 + grp; i < nbl; i += VJF_POST_THREADS / 128) {
+                const float* Lb = s_L + (size_t)tri(i, k) * 32 * LB;
+                float* xt = s_x + ((size_t)i * 32 + 16 * tile + xr) * LX + xc;
+                vjf_f32x4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = xt[r * LX];
+                post_mma32(acc, s_y, lane, [&](int ii, int m) { return -Lb[(16 * tile + ii) * LB + m]; });
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xt[r * LX] = acc[r];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (wave < 2) {
-            const float* Db = s_D + (size_t)bi * 32 * LB;
+        VJF_POST_STAMP(18);
+
+        if (!solve) {
+            // ---- w_chol[(j0*32 + c0 + c)][i] = X[i][c]: rows of w_chol, contiguous over i  (module.py:102)
+            float* Wc = A.state + P.off[VJF_SLOT_W_CHOL];
+            const int first = j0 * 32;
+            for (int c = wave; c < 16; c += VJF_POST_THREADS / 64) {
+                const int gc = j0 * 32 + c0 + c;
+                if (gc >= n) continue;
+                for (int i = first + lane; i < n; i += 64) Wc[(size_t)gc * n + i] = s_x[i * LX + c];
+            }
+            return;
+        }
+        // ---- backward  W_k = Dinv_k^T R_k ;  R_i -= L_ki^T W_k  (i < k),   k = nbl-1 .. 0   (module.py:101)
+        for (int k = nbl - 1; k >= 0; --k) {
             vjf_f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            post_mma32(w, s_t, lane, [&](int i, int m) { return Db[m * LB + 16 * wave + i]; });
+            if (wave < 2) {
+                const float* Db = s_D + (size_t)k * 32 * LB;
+                post_mma32(w, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Db[m * LB + 16 * wave + i]; });
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_x[(bi * 32 + 16 * wave + 4 * (lane >> 4) + r) * LX + (lane & 15)] = w[r];
+                for (int r = 0; r < 4; ++r) s_y[(16 * wave + xr + r) * LX + xc] = w[r];
+            }
+            __syncthreads();
+            if (wave < 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_x[(k * 32 + 16 * wave + xr + r) * LX + xc] = w[r];
+            }
+            for (int i = k - 1 - grp; i >= 0; i -= VJF_POST_THREADS / 128) {
+                const float* Lb = s_L + (size_t)tri(k, i) * 32 * LB;
+                float* xt = s_x + ((size_t)i * 32 + 16 * tile + xr) * LX + xc;
+                vjf_f32x4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = xt[r * LX];
+                post_mma32(acc, s_y, lane, [&](int ii, int m) { return -Lb[m * LB + 16 * tile + ii]; });
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xt[r * LX] = acc[r];
+            }
+            __syncthreads();
+        }
+        VJF_POST_STAMP(19);
+        float* Wm = A.state + P.off[VJF_SLOT_W_MEAN];
+        for (int e = tid; e < n * 16; e += VJF_POST_THREADS) {
+            const int r = e >> 4, c = e & 15;
+            if (c < dz) Wm[r * dz + c] = s_x[r * LX + c];
+        }
+    }   // !failed
+    if (!A.fold_sigma) return;
+    // ---- state-noise update on the new W (model.py:373-377):  q = sum|dx|^2 - 2 tr(W^T FDX) + tr(W^T G W)  over the batch.
+    //      tr(W^T G W) = sum_ij G_ij (W W^T)_ij: wavefront w forms the lower 32x32 tiles t = w, w + 8, .. of W W^T on the
+    //      f32 matrix cores and contracts them with the tiles of G it prefetched at kernel start (fp64 sums, fixed order).
+    {
+        double* s_p = reinterpret_cast<double*>(lds);          // one partial per wavefront (over s_L: the substitutions are done)
+        if (failed) {                                          // sigma still moves, on the W that stays: nothing was prefetched
+            const float* Wold = A.state + P.off[VJF_SLOT_W_MEAN];
+            const float* G = A.red + P.red_G;
+            const float* FDX = A.red + P.red_FDX;
+            for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
+                const int r = e >> 4, c = e & 15;
+                s_x[r * LX + c] = (r < n && c < dz) ? Wold[(size_t)r * dz + c] : 0.f;
+            }
+            const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int code = s_tab[32 + min(wave + 8 * q, ntri - 1)];
+                const int bi = code >> 8, bj = code & 255;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gi = min(bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n - 1), gj = min(bj * 32 + c, n - 1);
+                    gpre[q][r] = G[(size_t)gi * n + gj];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = tid + q * VJF_POST_THREADS, r = min(e >> 4, n - 1), cc = min(e & 15, dz - 1);
+                fpre[q] = FDX[r * dz + cc];
+            }
         }
         __syncthreads();
-    }
-    float* Wm = A.state + P.off[VJF_SLOT_W_MEAN];
-    for (int e = tid; e < n * dz; e += VJF_POST_THREADS) {
-        const int r = e / dz, c = e - r * dz;
-        Wm[e] = s_x[r * LX + c];
+        VJF_POST_STAMP(20);
+        double part = 0.0;
+        const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = wave + 8 * q;
+            if (t < ntri) {
+                const int code = s_tab[32 + t], bi = code >> 8, bj = code & 255;
+                vjf_f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                float wa[8], wb[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {                  // columns dz..15 and rows n.. of W are zero
+                    wa[k] = s_x[(bi * 32 + c) * LX + 2 * k + h];
+                    wb[k] = s_x[(bj * 32 + c) * LX + 2 * k + h];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (2 * k < dz) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[k], wb[k], acc, 0, 0, 0);   // (uniform branch)
+                double tp = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {                 // accumulator: row = (r&3) + 8*(r>>2) + 4*h, column = c
+                    const int gi = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, gj = bj * 32 + c;
+                    const float wgt = (gi >= n || gj > gi) ? 0.f : (gj == gi ? 1.f : 2.f);
+                    tp += (double)(wgt * gpre[q][r]) * (double)acc[r];
+                }
+                part += tp;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + q * VJF_POST_THREADS, r = e >> 4, cc = e & 15;
+            if (r < n && cc < dz) part -= 2.0 * (double)s_x[r * LX + cc] * (double)fpre[q];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (lane == 0) s_p[wave] = part;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < VJF_POST_THREADS / 64; ++w) t += s_p[w];
+            t += (double)pre_sdx2;
+            if (t < 0.0) t = 0.0;
+            float* St = A.state;
+            float* SC = St + P.off[VJF_SLOT_SCALARS];
+            const float mse = (float)(t * pre_scale);
+            St[P.off[VJF_SLOT_TR_LOGVAR]] = logf(pre_old + ((float)A.B_total / pre_tot) * mse);
+            SC[VJF_SC_N_TR] = pre_tot;
+            if (failed) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
+        }
+        VJF_POST_STAMP(21);
     }
 }
 
