@@ -42,7 +42,11 @@ __global__ __launch_bounds__(64) void k(const float* A, const float* Pn, float* 
         vjf_f32x16 acc;
         blk_load(acc, blk, lane);
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-        if (VAR == 0) {
+        if (VAR == 2) {
+            ok = potrf_inv_chain2(blk, inv, lane) && ok;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
+            t3 = t4 = t2;
+        } else if (VAR == 0) {
             ok = potrf_inv_chain(acc, blk, inv, lane) && ok;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
             t3 = t4 = t2;
@@ -88,6 +92,12 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         k<0><<<1, 64>>>(dA, dP, out, t); hipMemcpy(h, t, sizeof h, hipMemcpyDeviceToHost);
         printf("merged potrf+inverse : min %llu  (first %llu)\n", mn(0), h[0]);
+        k<2><<<1, 64>>>(dA, dP, out, t); hipMemcpy(h, t, sizeof h, hipMemcpyDeviceToHost); hipMemcpy(ho, out, sizeof ho, hipMemcpyDeviceToHost);
+        {
+            double eL = 0, eI = 0;
+            for (int r = 0; r < 32; ++r) for (int c = 0; c <= r; ++c) { eL = fmax(eL, fabs(ho[r * 32 + c] - L[r][c])); eI = fmax(eI, fabs(ho[1024 + r * 32 + c] - Li[r][c])); }
+            printf("rank-2 merged chain  : min %llu   max err L %.2e  Linv %.2e\n", mn(0), eL, eI);
+        }
         k<1><<<1, 64>>>(dA, dP, out, t); hipMemcpy(h, t, sizeof h, hipMemcpyDeviceToHost); hipMemcpy(ho, out, sizeof ho, hipMemcpyDeviceToHost);
         double eL = 0, eI = 0, eX = 0;
         for (int r = 0; r < 32; ++r) for (int c = 0; c < 32; ++c) {

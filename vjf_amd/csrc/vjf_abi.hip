@@ -98,7 +98,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t E, ACT, DEL, partial, slabs, red, red2, work, jobs, aux, post, total;
+    size_t E, ACT, DEL, partial, slabs, red, red2, work, jobs, aux, post, lscr, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -114,6 +114,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.red2 = take((size_t)P.red_len * 4);                  // odd steps' RLS statistics in the two-stream sequence
     c.work = take(vjf_serial_work_floats(P) * 4 + 256);   // + 32 u64 diagnostic stamps
     c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
+    c.lscr = take((size_t)P.n * P.n * 4);                  // L, column by column, from the Cholesky kernel to the post kernel
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
     c.total = o;
@@ -392,7 +393,7 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
     float* dinv = (float*)(c->ws + c->cv.post);
     double* rpart = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
     int* okflag = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
-    a.post = c->post_kernels ? 1 : 0; a.dinv_out = dinv; a.ok_out = okflag;
+    a.post = c->post_kernels ? 1 : 0; a.dinv_out = dinv; a.ok_out = okflag; a.lscr = (float*)(c->ws + c->cv.lscr);
     if (before_chol) VJF_HIP(hipStreamWaitEvent(st, before_chol, 0));
     switch (vjf_chol_dzp(P.dz)) {
         case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
@@ -408,7 +409,7 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
         if (rls) {
             // inverse column halves + the y / W workgroup, which also carries the state-noise update
             VjfPostArgs pa{};
-            pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.ok = okflag;
+            pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.ok = okflag; pa.lscr = a.lscr;
             pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
             VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st, stop, P, pa);
             VJF_HIP(hipGetLastError());

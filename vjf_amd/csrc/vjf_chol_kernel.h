@@ -233,6 +233,62 @@ __device__ __forceinline__ bool potrf_inv_chain(vjf_f32x16& acc, float* out, flo
     return (dmin > 0.f) && (slast == slast) && (fabsf(slast) < 3.0e38f);   // positive pivots, no NaN / inf came through
 }
 
+// Rank-2 form of the merged chain: two pivots per matrix-core round, so that BOTH k slots of v_mfma_f32_32x32x2 carry a
+// column (the rank-1 chain above zeroes one of them) -- 16 rounds of 2 MFMAs instead of 32 steps of 2.
+// The tile sits in the accumulator under a symmetric permutation: register r holds logical row 2r on lanes 0..31 and
+// logical row 2r + 1 on lanes 32..63 (physical row (r&3) + 8 (r>>2) + 4 half  <->  logical row 2r + half; same map for the
+// columns), so the two pivot rows of a round are the two halves of ONE register and land in the A / B operand layout
+// (k = lane >> 5) with no data movement; only column 2m scaled by its pivot has to cross to the other half once
+// (v_permlane32_swap) to update row 2m + 1 before its own pivot is taken.  A relabelling only: the factor is the lower
+// triangular L of the tile in the natural order.  Reads the tile from `dk`, writes L (lower) back and L^-1 (lower) to `inv`.
+__device__ __forceinline__ float vlo2both(float v) {            // lanes 0..31 of v on both halves
+    const unsigned u = __float_as_uint(v);
+    return __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[0]);
+}
+__device__ __forceinline__ bool potrf_inv_chain2(float* dk, float* inv, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+    const int lc = 2 * ((c & 3) + 4 * (c >> 3)) + ((c >> 2) & 1);   // logical column held by this lane
+    vjf_f32x16 acc, racc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lr = 2 * r + h;                                   // logical row of (register r, half h)
+        acc[r] = dk[vsw(lr, lc)];
+        racc[r] = (lr == lc) ? 1.f : 0.f;
+    }
+    float vcol[16], xcol[16];
+    float dmin = 3.0e38f, slast = 1.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int p1 = (m & 3) + 8 * (m >> 2), p2 = p1 + 4;         // physical columns of logical 2m and 2m + 1
+        const float d1 = vrl(acc[m], p1);                           // T[2m][2m]
+        const float q2 = vrl(acc[m], 32 + p2);                      // T[2m+1][2m+1], before column 2m is eliminated
+        const float s1 = __builtin_amdgcn_rsqf(d1);
+        const float l1 = acc[m] * s1;                               // lanes 0..31: L[.][2m]
+        const float e = vrl(l1, p2);                                // L[2m+1][2m]
+        const float t = fmaf(-e, vlo2both(l1), acc[m]);             // lanes 32..63: row 2m+1 with column 2m eliminated
+        const float d2 = fmaf(-e, e, q2);
+        const float s2 = __builtin_amdgcn_rsqf(d2);
+        const float v = h ? t * s2 : l1;                            // L[.][2m] | L[.][2m+1] by half = the k slot
+        const float x1 = racc[m] * s1;                              // lanes 0..31: Linv[2m][.]
+        const float x2 = fmaf(-e, vlo2both(x1), racc[m]) * s2;      // lanes 32..63: Linv[2m+1][.]
+        const float b = h ? x2 : x1;
+        const float nv = -v;
+        dmin = fminf(dmin, fminf(d1, d2));
+        slast = s2;
+        vcol[m] = v;
+        xcol[m] = b;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nv, v, acc, 0, 0, 0);
+        racc = __builtin_amdgcn_mfma_f32_32x32x2f32(nv, b, racc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int j = 2 * m + h;
+        if (lc >= j) dk[vsw(lc, j)] = vcol[m];
+        inv[vsw(j, lc)] = (lc <= j) ? xcol[m] : 0.f;
+    }
+    return (dmin > 0.f) && (slast == slast) && (fabsf(slast) < 3.0e38f);
+}
+
 // The same column chain split in three, so that each is a pure one-MFMA-per-step dependent chain (the merged chain
 // above pays the compiler's MFMA->VALU wait states twice per step: ~290 cycles/step against ~127 + ~94 + ~94 here)
 // and the inverse / the panel solves run on other wavefronts beside it.
@@ -332,6 +388,8 @@ struct VjfCholArgs {
     float* dinv_out;       // post mode: nbl blocks (32x32 row-major) of inverted diagonal blocks for vjf_rls_post_kernel
     int* ok_out;           // post mode: 1 = factor valid
     int post;              // 1: stop after L and the inverted diagonal blocks; the many-CU post kernels do the rest
+    float* lscr;           // post mode: (n, n) scratch that receives L column by column while the factorisation runs
+                           //            (vjf_rls_post_kernel copies it to w_pchol once the factor is known to be good)
 };
 
 #define VJF_STAMP(i)                                                                        \
@@ -407,46 +465,62 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
     __syncthreads();
 
     if (!warm) {
-        // ---- load the lower block triangle of P_new (vjf_prep_kernel already added Phi^T Phi / v): all loads
-        //      of a thread are issued before the first LDS store
-        {
-            float4 v[VJF_CHOL_Q];
+        // ---- load the lower block triangle of P_new (vjf_prep_kernel already added Phi^T Phi / v).  Wavefront 0 takes the
+        //      first diagonal block alone and starts its column chain; the other seven bring in the rest meanwhile.
+        //      All loads of a thread are issued before its first LDS store.
+        auto diag_chain = [&](int k) {                                  // L_kk and L_kk^-1 in one chain (one wavefront)
+            float* dk = s_blk + (size_t)vtri(k, k) * 1024;
+            if (!potrf_inv_chain2(dk, s_aux + (size_t)k * 1024, lane) && lane == 0) s_flag[0] = 0;
+        };
+        auto pad4 = [](int gi, int gj) {                                // identity padding outside the matrix
+            return make_float4(gi == gj ? 1.f : 0.f, gi == gj + 1 ? 1.f : 0.f, gi == gj + 2 ? 1.f : 0.f, gi == gj + 3 ? 1.f : 0.f);
+        };
+        if (wave == 0) {
+            float4 v[4];
 #pragma unroll
-            for (int q = 0; q < VJF_CHOL_Q; ++q) {
-                const int idx = tid + q * VJF_CHOL_THREADS;
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane + 64 * q, r = idx >> 3, c4 = (idx & 7) * 4;
+                v[q] = (r < n && c4 < n) ? *reinterpret_cast<const float4*>(Pm + (size_t)r * n + c4) : pad4(r, c4);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane + 64 * q, r = idx >> 3, c4 = (idx & 7) * 4;
+                s_blk[vsw(r, c4)] = v[q].x; s_blk[vsw(r, c4 + 1)] = v[q].y; s_blk[vsw(r, c4 + 2)] = v[q].z; s_blk[vsw(r, c4 + 3)] = v[q].w;
+            }
+            diag_chain(0);
+        } else {
+            constexpr int NT = VJF_CHOL_THREADS - 64, NQ = ((VJF_CHOL_MAXBLK * (VJF_CHOL_MAXBLK + 1) / 2 - 1) * 256 + NT - 1) / NT;
+            const int t2 = tid - 64;
+            float4 v[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int idx = 256 + t2 + q * NT;
                 v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (idx < ntri * 256) {
                     const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
                     const int gi = s_bi[b] * 32 + r, gj = s_bj[b] * 32 + c4;
-                    if (gi < n && gj < n) v[q] = *reinterpret_cast<const float4*>(Pm + (size_t)gi * n + gj);
-                    else { v[q].x = gi == gj ? 1.f : 0.f; v[q].y = gi == gj + 1 ? 1.f : 0.f; v[q].z = gi == gj + 2 ? 1.f : 0.f; v[q].w = gi == gj + 3 ? 1.f : 0.f; }
+                    v[q] = (gi < n && gj < n) ? *reinterpret_cast<const float4*>(Pm + (size_t)gi * n + gj) : pad4(gi, gj);
                 }
             }
 #pragma unroll
-            for (int q = 0; q < VJF_CHOL_Q; ++q) {
-                const int idx = tid + q * VJF_CHOL_THREADS;
+            for (int q = 0; q < NQ; ++q) {
+                const int idx = 256 + t2 + q * NT;
                 if (idx < ntri * 256) {
                     const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
                     float* blk = s_blk + (size_t)b * 1024;
                     blk[vsw(r, c4)] = v[q].x; blk[vsw(r, c4 + 1)] = v[q].y; blk[vsw(r, c4 + 2)] = v[q].z; blk[vsw(r, c4 + 3)] = v[q].w;
                 }
             }
-        }
-        for (int e = tid; e < npad * DZP; e += VJF_CHOL_THREADS) {
-            const int r = e / DZP, j = e - r * DZP;
-            s_g[e] = (r < n && j < dz) ? A.gbuf[(size_t)r * dz + j] : 0.f;
+            for (int e = t2; e < npad * DZP; e += NT) {
+                const int r = e / DZP, j = e - r * DZP;
+                s_g[e] = (r < n && j < dz) ? A.gbuf[(size_t)r * dz + j] : 0.f;
+            }
         }
         __syncthreads();
         VJF_STAMP(1);
 
         // ---- blocked right-looking Cholesky with look-ahead: while wavefronts 1..7 finish the trailing update of
         //      step k, wavefront 0 updates block (k+1,k+1) first and runs the next diagonal chain
-        auto diag_chain = [&](int k) {                                  // L_kk and L_kk^-1 in one chain (one wavefront)
-            float* dk = s_blk + (size_t)vtri(k, k) * 1024;
-            vjf_f32x16 acc;
-            blk_load(acc, dk, lane);
-            if (!potrf_inv_chain(acc, dk, s_aux + (size_t)k * 1024, lane) && lane == 0) s_flag[0] = 0;
-        };
         auto trail = [&](int k, int t) {                                // A_ij -= L_ik L_jk^T for the t-th lower block
             const int bi = k + 1 + s_bi[t], bj = k + 1 + s_bj[t];
             float* cb = s_blk + (size_t)vtri(bi, bj) * 1024;
@@ -455,8 +529,19 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
             blk_mma<true>(acc, s_blk + (size_t)vtri(bi, k) * 1024, s_blk + (size_t)vtri(bj, k) * 1024, -1.f, lane);
             blk_store(acc, cb, lane);
         };
-        if (wave == 0) diag_chain(0);
-        __syncthreads();
+        // post mode: one finished 32x32 block out to global memory (one wavefront, 4 float4 per lane)
+        auto put_block = [&](const float* blk, float* dst, int ld, int gi0, int gj0, bool lower_only) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane + 64 * q, r = idx >> 3, c4 = (idx & 7) * 4;
+                float4 o;
+                o.x = (!lower_only || c4 <= r) ? blk[vsw(r, c4)] : 0.f;
+                o.y = (!lower_only || c4 + 1 <= r) ? blk[vsw(r, c4 + 1)] : 0.f;
+                o.z = (!lower_only || c4 + 2 <= r) ? blk[vsw(r, c4 + 2)] : 0.f;
+                o.w = (!lower_only || c4 + 3 <= r) ? blk[vsw(r, c4 + 3)] : 0.f;
+                if (gi0 + r < ld && gj0 + c4 < ld) *reinterpret_cast<float4*>(dst + (size_t)(gi0 + r) * ld + gj0 + c4) = o;
+            }
+        };
         for (int k = 0; k < nbl; ++k) {
             if (!s_flag[0]) break;
             {                                                          // panel: L_ik = A_ik L_kk^-T, a plain block product
@@ -477,6 +562,14 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                     if (nt > 0) { trail(k, 0); diag_chain(k + 1); }    // block (k+1,k+1), then the next chain
                 } else {
                     for (int t = wave; t < nt; t += VJF_CHOL_THREADS / 64 - 1) trail(k, t);
+                    if (A.post) {
+                        // column k of L and Dinv_k are final: out they go, one block per wavefront, beside the next chain
+                        const int nitem = nbl - k + 1;
+                        for (int it = wave - 1; it < nitem; it += VJF_CHOL_THREADS / 64 - 1) {
+                            if (it < nbl - k) put_block(s_blk + (size_t)vtri(k + it, k) * 1024, A.lscr, n, (k + it) * 32, k * 32, it == 0);
+                            else put_block(s_aux + (size_t)k * 1024, A.dinv_out + (size_t)k * 1024, 32, 0, 0, false);
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -495,6 +588,20 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                 return;
             }
         } else {
+            if (A.post) {
+                // L and the inverted diagonal blocks already left column by column; one-time clearing of the zero halves; done
+                if (SC[VJF_SC_TRI_CLEAN] == 0.f) {
+                    for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) {
+                        const int i = e / n, j = e - i * n;
+                        if ((i >> 5) < (j >> 5)) Lm[e] = 0.f;
+                        if ((i >> 5) > (j >> 5)) Wc[e] = 0.f;
+                    }
+                    __syncthreads();
+                    if (tid == 0) SC[VJF_SC_TRI_CLEAN] = 1.f;
+                }
+                if (tid == 0) A.ok_out[0] = 1;
+                return;
+            }
             // ---- w_pchol = L (lower, module.py:99-100)
             {
                 float4 v[VJF_CHOL_Q];
@@ -522,24 +629,6 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                 }
             }
             VJF_STAMP(3);
-            if (A.post) {
-                // inverted diagonal blocks for the post kernels; one-time clearing of the zero halves; done
-                for (int e = tid; e < nbl * 1024; e += VJF_CHOL_THREADS) {
-                    const int b = e >> 10, r = (e >> 5) & 31, c = e & 31;
-                    A.dinv_out[e] = s_aux[(size_t)b * 1024 + vsw(r, c)];
-                }
-                if (SC[VJF_SC_TRI_CLEAN] == 0.f) {
-                    for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) {
-                        const int i = e / n, j = e - i * n;
-                        if ((i >> 5) < (j >> 5)) Lm[e] = 0.f;
-                        if ((i >> 5) > (j >> 5)) Wc[e] = 0.f;
-                    }
-                    __syncthreads();
-                    if (tid == 0) SC[VJF_SC_TRI_CLEAN] = 1.f;
-                }
-                if (tid == 0) A.ok_out[0] = 1;
-                return;
-            }
             VJF_STAMP(4);
             // ---- X = L^-1, block row by block row, in place over L:
             //      X_ij = -Dinv_i * sum_{k=j}^{i-1} L_ik X_kj   (X_jj = Dinv_j)

@@ -25,6 +25,7 @@
 struct VjfPostArgs {
     float* state;
     const float* dinv;      // nbl blocks (32x32 row-major) of inverted diagonal blocks, from vjf_chol_lds_kernel
+    const float* lscr;      // (n, n) L as vjf_chol_lds_kernel left it (block-lower part valid); copied to w_pchol here
     const float* gbuf;      // (n, dz) g
     const int* ok;          // device flag written by the Cholesky kernel: 1 = factor valid
     const float* red;       // reduce buffer (G, FDX, sum|dx|^2) of this step
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     float* s_y = s_x + (size_t)nbl * 32 * LX;                  // [32][17] the block just solved, for the eager updates
     int* s_tab = reinterpret_cast<int*>(s_y + 32 * LX);        // block -> (bi << 8) | bj: strictly lower, then diagonal
     const float* S = A.state;
-    const float* Lm = S + P.off[VJF_SLOT_W_PCHOL];
+    const float* Lm = A.lscr;
     const int j0 = solve ? 0 : (int)blockIdx.x >> 1;           // first block row of the substitution
     const int c0 = solve ? 0 : 16 * ((int)blockIdx.x & 1);
     auto tri = [](int bi, int bj) { return bi * (bi - 1) / 2 + bj; };       // strictly lower: bi > bj
@@ -207,6 +208,16 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         VJF_POST_STAMP(18);
 
         if (!solve) {
+            // ---- w_pchol = L (module.py:99-100): the factor is good, so the scratch copy goes to the state; 1/(2 nbl) each
+            {
+                float* Ls = A.state + P.off[VJF_SLOT_W_PCHOL];
+                const int nq = n * n / 4, per = (nq + 2 * nbl - 1) / (2 * nbl);
+                const int q0 = (int)blockIdx.x * per, q1 = min(nq, q0 + per);
+                for (int q = q0 + tid; q < q1; q += VJF_POST_THREADS) {
+                    const int e = 4 * q, i = e / n, j = e - i * n;
+                    if ((j >> 5) <= (i >> 5)) *reinterpret_cast<float4*>(Ls + e) = *reinterpret_cast<const float4*>(A.lscr + e);
+                }
+            }
             // ---- w_chol[(j0*32 + c0 + c)][i] = X[i][c]: rows of w_chol, contiguous over i  (module.py:102)
             float* Wc = A.state + P.off[VJF_SLOT_W_CHOL];
             const int first = j0 * 32;
