@@ -22,6 +22,7 @@ prev = T[1]
 for k in range(7):
     print(f'chol column {k}: {T[9 + k] - prev:7d}')
     prev = T[9 + k]
+print('column 0: wave0 panel product', T[8]-T[1], ' panel', T[3]-T[1], ' wave0 trail', T[4]-T[3], ' wave0 chain', T[5]-T[4], ' column end', T[9]-T[3])
 for i, nm in enumerate(["prefetch+stage", "forward", "backward", "W store", "sigma tail"]):
     print(f'post y/W workgroup {nm:16s} {T[17 + i] - T[16 + i]:7d}')
 names1 = ["stage0 inputs", "stage1 rbf", "stage2 var+mean", "stage3 recognition", "stage4 xt+decoder", "stage5 losses", "stage6 backward", "stage7 rows out"]

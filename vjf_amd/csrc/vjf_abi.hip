@@ -220,6 +220,10 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->fast_chol = fast_chol; c->lds_chol = vjf_chol_lds_bytes(P); c->stamps = false;
     c->lds_post = vjf_post_lds_bytes(P);
     c->post_kernels = fast_chol && P.dz <= 16 && c->lds_post <= kMaxLds - 1024;
+    // the single-workgroup chain kernels ask for the whole LDS of their compute unit: nothing else (every other kernel of
+    // a step uses some LDS) is then placed beside them to share their SIMDs' issue slots and matrix cores
+    if (fast_chol) c->lds_chol = kMaxLds;
+    if (c->post_kernels) c->lds_post = kMaxLds;
     c->lds_k1m = vjf_trial_mfma_lds_floats(P) * 4;
     c->mfma_trial = c->lds_k1m <= kMaxLds - 1024;
     c->n_ejobs = 0;

@@ -555,21 +555,22 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                     blk_store(acc, pb, lane);                           // same wavefront read all of pb before writing
                 }
             }
+            if (k == 0) VJF_STAMP(8);
             __syncthreads();
+            if (k == 0) VJF_STAMP(3);
             {
                 const int m = nbl - 1 - k, nt = m * (m + 1) / 2;
                 if (wave == 0) {
-                    if (nt > 0) { trail(k, 0); diag_chain(k + 1); }    // block (k+1,k+1), then the next chain
-                } else {
-                    for (int t = wave; t < nt; t += VJF_CHOL_THREADS / 64 - 1) trail(k, t);
+                    if (nt > 0) { trail(k, 0); if (k == 0) VJF_STAMP(4); diag_chain(k + 1); if (k == 0) VJF_STAMP(5); }    // block (k+1,k+1), then the next chain
+                } else if (wave == 4) {
+                    // (wavefront 4 shares wavefront 0's SIMD: it keeps off the matrix core while the chain runs there)
                     if (A.post) {
-                        // column k of L and Dinv_k are final: out they go, one block per wavefront, beside the next chain
-                        const int nitem = nbl - k + 1;
-                        for (int it = wave - 1; it < nitem; it += VJF_CHOL_THREADS / 64 - 1) {
-                            if (it < nbl - k) put_block(s_blk + (size_t)vtri(k + it, k) * 1024, A.lscr, n, (k + it) * 32, k * 32, it == 0);
-                            else put_block(s_aux + (size_t)k * 1024, A.dinv_out + (size_t)k * 1024, 32, 0, 0, false);
-                        }
+                        // column k of L and Dinv_k are final: out they go beside the next chain
+                        for (int it = 0; it < nbl - k; ++it) put_block(s_blk + (size_t)vtri(k + it, k) * 1024, A.lscr, n, (k + it) * 32, k * 32, it == 0);
+                        put_block(s_aux + (size_t)k * 1024, A.dinv_out + (size_t)k * 1024, 32, 0, 0, false);
                     }
+                } else {
+                    for (int t = 1 + (wave < 4 ? wave - 1 : wave - 2); t < nt; t += VJF_CHOL_THREADS / 64 - 2) trail(k, t);
                 }
             }
             __syncthreads();
