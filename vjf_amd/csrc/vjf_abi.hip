@@ -98,7 +98,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t E, ACT, DEL, partial, slabs, red, red2, work, jobs, aux, post, lscr, total;
+    size_t E, ACT, DEL, partial, slabs, red, red2, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -114,6 +114,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.red2 = take((size_t)P.red_len * 4);                  // odd steps' RLS statistics in the two-stream sequence
     c.work = take(vjf_serial_work_floats(P) * 4 + 256);   // + 32 u64 diagnostic stamps
     c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
+    c.flags = take(256);                                   // column flags of the Cholesky -> post hand-off (a block of their own)
     c.lscr = take((size_t)P.n * P.n * 4);                  // L, column by column, from the Cholesky kernel to the post kernel
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
@@ -151,8 +152,9 @@ struct vjf_ctx {
     size_t lds_chol;
     int n_ejobs;           // jobs [0, n_ejobs) are the E^T E tiles, the rest gradient tiles
     bool overlap;          // vjf_filter_seq: RLS chain on a second stream beside the trial / SGD chain
-    hipStream_t stream2;
-    hipEvent_t ev_e, ev_b, ev_s;
+    hipStream_t stream2, stream3;
+    hipEvent_t ev_e, ev_b, ev_s, ev_p, ev_c;
+    unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
 };
 
 extern "C" {
@@ -229,10 +231,12 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->n_ejobs = 0;
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
-    c->stream2 = nullptr; c->ev_e = c->ev_b = c->ev_s = nullptr;
+    c->stream2 = c->stream3 = nullptr; c->ev_e = c->ev_b = c->ev_s = c->ev_p = c->ev_c = nullptr;
+    c->epoch = 0;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red2, 0, (size_t)P.red_len * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.flags, 0, 256, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs` (host) must outlive the copy
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
     allow_lds(vjf_trial_kernel<16>, c->lds_k1); allow_lds(vjf_trial_kernel<8>, c->lds_k1); allow_lds(vjf_trial_kernel<4>, c->lds_k1);
@@ -248,9 +252,10 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
 
 int vjf_ctx_destroy(vjf_ctx* ctx) {
     if (ctx && ctx->stream2) {
-        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3);
         (void)hipEventDestroy(ctx->ev_e); (void)hipEventDestroy(ctx->ev_b); (void)hipEventDestroy(ctx->ev_s);
-        (void)hipStreamDestroy(ctx->stream2);
+        (void)hipEventDestroy(ctx->ev_p); (void)hipEventDestroy(ctx->ev_c);
+        (void)hipStreamDestroy(ctx->stream2); (void)hipStreamDestroy(ctx->stream3);
     }
     delete ctx;
     return 0;
@@ -370,7 +375,8 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
 }
 
 // which: 0 whole prep grid, 1 RLS operand rows only, 2 SGD + scalars only
-int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const float* red, int which, hipStream_t st) {
+int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const float* red, int which, hipStream_t st,
+                hipEvent_t stop = nullptr) {
     const VjfPlan& P = c->plan;
     VjfPrepArgs p{};
     p.state = c->state; p.red = red; p.gbuf = (float*)(c->ws + c->cv.work);
@@ -380,14 +386,17 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
     p.n_sgdblk = (P.train_len + 1023) / 1024;
     p.bid0 = which == 2 ? p.n_rowblk : 0;
     const int grid = which == 0 ? p.n_rowblk + p.n_sgdblk + 1 : which == 1 ? p.n_rowblk : p.n_sgdblk + 1;
-    hipLaunchKernelGGL(vjf_prep_kernel, dim3(grid), dim3(256), 0, st, P, p);
+    VJF_LAUNCH(vjf_prep_kernel, dim3(grid), dim3(256), 0, st, stop, P, p);
     VJF_HIP(hipGetLastError());
     return 0;
 }
 
 // Cholesky + RLS tail + state-noise update.  `before_chol` / `before_post`: events the stream waits for first (or null).
 int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, hipEvent_t before_chol,
-               hipEvent_t before_post, hipEvent_t stop = nullptr) {
+               hipStream_t st_post, hipEvent_t before_post0, hipEvent_t before_post1, hipEvent_t stop = nullptr) {
+    // `st_post` may differ from `st`: the post kernel's workgroups then start beside the Cholesky kernel and take each
+    // column of L as the flag for it appears (the Cholesky kernel is always enqueued first, so even on one hardware queue
+    // nothing waits for a kernel behind it).
     const VjfPlan& P = c->plan;
     if (!(flags & VJF_FLAG_UPDATE)) return 0;
     VjfCholArgs a{};
@@ -397,7 +406,9 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
     float* dinv = (float*)(c->ws + c->cv.post);
     double* rpart = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
     int* okflag = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
+    unsigned* colflags = (unsigned*)(c->ws + c->cv.flags);
     a.post = c->post_kernels ? 1 : 0; a.dinv_out = dinv; a.ok_out = okflag; a.lscr = (float*)(c->ws + c->cv.lscr);
+    a.flags_out = colflags; a.epoch = ++c->epoch;
     if (before_chol) VJF_HIP(hipStreamWaitEvent(st, before_chol, 0));
     switch (vjf_chol_dzp(P.dz)) {
         case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
@@ -407,21 +418,23 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
         default: hipLaunchKernelGGL(vjf_chol_lds_kernel<32>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
     }
     VJF_HIP(hipGetLastError());
-    if (before_post) VJF_HIP(hipStreamWaitEvent(st, before_post, 0));
+    if (before_post0) VJF_HIP(hipStreamWaitEvent(st_post, before_post0, 0));
+    if (before_post1) VJF_HIP(hipStreamWaitEvent(st_post, before_post1, 0));
     if (c->post_kernels) {
         const bool rls = !(flags & VJF_FLAG_WARM_UP);
         if (rls) {
             // inverse column halves + the y / W workgroup, which also carries the state-noise update
             VjfPostArgs pa{};
-            pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.ok = okflag; pa.lscr = a.lscr;
+            pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.lscr = a.lscr;
+            pa.flags = colflags; pa.epoch = a.epoch; pa.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
             pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
-            VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st, stop, P, pa);
+            VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st_post, stop, P, pa);
             VJF_HIP(hipGetLastError());
         } else {
             VjfResidArgs ra{};
             ra.state = c->state; ra.red = red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
-            hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra);
-            VJF_LAUNCH(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, stop, P, ra, (const int*)nullptr);
+            hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st_post, P, ra);
+            VJF_LAUNCH(vjf_sigma_kernel, dim3(1), dim3(64), 0, st_post, stop, P, ra, (const int*)nullptr);
             VJF_HIP(hipGetLastError());
         }
     }
@@ -442,6 +455,9 @@ int launch_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const fl
 int ensure_stream2(vjf_ctx* c) {
     if (c->stream2) return 0;
     VJF_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    VJF_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    VJF_HIP(hipEventCreate(&c->ev_p));
+    VJF_HIP(hipEventCreate(&c->ev_c));
     VJF_HIP(hipEventCreate(&c->ev_e));          // (default flags: the events are attached to kernel launches)
     VJF_HIP(hipEventCreate(&c->ev_b));
     VJF_HIP(hipEventCreate(&c->ev_s));
@@ -461,7 +477,7 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     if (rc) return rc;
     const VjfPlan& P = c->plan;
     const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
-    hipStream_t sa = c->stream, sb = c->stream2;
+    hipStream_t sa = c->stream, sb = c->stream2, sc = c->stream3;
     float* red[2] = {(float*)(c->ws + c->cv.red), (float*)(c->ws + c->cv.red2)};
     auto args = [&](int t) {
         return trial_args(c, B, y + t * sy, u ? u + t * su : nullptr, t ? mu + (t - 1) * sz : mu0, t ? lv + (t - 1) * sz : lv0,
@@ -477,11 +493,16 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     if ((rc = launch_gram(c, B, 0, ne, kScRls, red[0], sa, c->ev_e))) return rc;
     for (int t = 0; t < T; ++t) {
         VJF_HIP(hipStreamWaitEvent(sb, c->ev_e, 0));                       // chain B(t) <- E^T E(t)
-        if (t > 0) VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));            // backward half(t) <- W, w_chol, sigma of t-1
+        if (t > 0) {
+            VJF_HIP(hipStreamWaitEvent(sb, c->ev_s, 0));                   // ... and W, sigma of t-1 (the post kernel is on sc)
+            VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                   // backward half(t) <- W, w_chol, sigma of t-1
+        }
         if ((rc = launch_trial(c, args(t), 2, sa, c->ev_b))) return rc;
-        if ((rc = launch_prep(c, B, nullptr, flags, red[t & 1], 1, sb))) return rc;
-        // the first Cholesky of a blob clears w_chol's zero half in place (VJF_SC_TRI_CLEAN): keep it behind the reader
-        if ((rc = launch_rls(c, B, flags, red[t & 1], sb, t == 0 ? c->ev_b : nullptr, c->ev_b, c->ev_s))) return rc;
+        if ((rc = launch_prep(c, B, nullptr, flags, red[t & 1], 1, sb, c->ev_p))) return rc;
+        // Cholesky on sb; the post kernel on sc beside it, behind g (prep) and behind the reader of W, w_chol, sigma (backward
+        // half).  The first Cholesky of a blob clears w_chol's zero half in place (VJF_SC_TRI_CLEAN): that one waits for the
+        // reader too.
+        if ((rc = launch_rls(c, B, flags, red[t & 1], sb, t == 0 ? c->ev_b : nullptr, sc, c->ev_p, c->ev_b, c->ev_s))) return rc;
         if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, red[0], sa))) return rc;
         if ((rc = launch_prep(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags, red[0], 2, sa))) return rc;
         if (t + 1 < T) {
@@ -489,7 +510,9 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             if ((rc = launch_gram(c, B, 0, ne, kScRls, red[(t + 1) & 1], sa, c->ev_e))) return rc;
         }
     }
+    VJF_HIP(hipEventRecord(c->ev_c, sb));
     VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                           // join: the caller's stream sees the final state
+    VJF_HIP(hipStreamWaitEvent(sa, c->ev_c, 0));
     return 0;
 }
 }  // namespace
@@ -507,7 +530,7 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
         const float* red = (const float*)(c->ws + c->cv.red);
         int rc = launch_prep(c, B_total, loss4, flags, red, 0, c->stream);
         if (rc) return rc;
-        return launch_rls(c, B_total, flags, red, c->stream, nullptr, nullptr);
+        return launch_rls(c, B_total, flags, red, c->stream, nullptr, c->stream, nullptr, nullptr);
     }
     VjfSerialArgs s{};
     s.state = c->state; s.red = (const float*)(c->ws + c->cv.red); s.work = (float*)(c->ws + c->cv.work);

@@ -389,6 +389,8 @@ struct VjfCholArgs {
     int* ok_out;           // post mode: 1 = factor valid
     int post;              // 1: stop after L and the inverted diagonal blocks; the many-CU post kernels do the rest
     float* lscr;           // post mode: (n, n) scratch that receives L column by column while the factorisation runs
+    unsigned* flags_out;   // post mode: flags_out[k] = (epoch << 1) | failed once column k of L and Dinv_k are in global memory:
+    unsigned epoch;        //   vjf_rls_post_kernel, launched beside this kernel, consumes the columns as they appear
                            //            (vjf_rls_post_kernel copies it to w_pchol once the factor is known to be good)
 };
 
@@ -530,18 +532,29 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
             blk_store(acc, cb, lane);
         };
         // post mode: one finished 32x32 block out to global memory (one wavefront, 4 float4 per lane)
+        // Write-through (sc1) 16-byte stores: the bytes are in memory, visible to every XCD, once the storing wavefront's vmcnt
+        // has drained -- no release fence (cdna guide, Guideline 16 R1).  The asm store is not counted by the compiler: the
+        // publishing code below drains it by hand.
         auto put_block = [&](const float* blk, float* dst, int ld, int gi0, int gj0, bool lower_only) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int idx = lane + 64 * q, r = idx >> 3, c4 = (idx & 7) * 4;
-                float4 o;
-                o.x = (!lower_only || c4 <= r) ? blk[vsw(r, c4)] : 0.f;
-                o.y = (!lower_only || c4 + 1 <= r) ? blk[vsw(r, c4 + 1)] : 0.f;
-                o.z = (!lower_only || c4 + 2 <= r) ? blk[vsw(r, c4 + 2)] : 0.f;
-                o.w = (!lower_only || c4 + 3 <= r) ? blk[vsw(r, c4 + 3)] : 0.f;
-                if (gi0 + r < ld && gj0 + c4 < ld) *reinterpret_cast<float4*>(dst + (size_t)(gi0 + r) * ld + gj0 + c4) = o;
+                vjf_f32x4 o;
+                o[0] = (!lower_only || c4 <= r) ? blk[vsw(r, c4)] : 0.f;
+                o[1] = (!lower_only || c4 + 1 <= r) ? blk[vsw(r, c4 + 1)] : 0.f;
+                o[2] = (!lower_only || c4 + 2 <= r) ? blk[vsw(r, c4 + 2)] : 0.f;
+                o[3] = (!lower_only || c4 + 3 <= r) ? blk[vsw(r, c4 + 3)] : 0.f;
+                if (gi0 + r < ld && gj0 + c4 < ld) {
+                    float* p = dst + (size_t)(gi0 + r) * ld + gj0 + c4;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(o) : "memory");
+                }
             }
         };
+        auto publish = [&](int k0, int k1, unsigned fail) {             // one wavefront: its stores drained, then the flags
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane >= k0 && lane < k1) __hip_atomic_store(A.flags_out + lane, (A.epoch << 1) | fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        int kdone = 0;                                                  // iterations completed = columns published
         for (int k = 0; k < nbl; ++k) {
             if (!s_flag[0]) break;
             {                                                          // panel: L_ik = A_ik L_kk^-T, a plain block product
@@ -568,12 +581,14 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                         // column k of L and Dinv_k are final: out they go beside the next chain
                         for (int it = 0; it < nbl - k; ++it) put_block(s_blk + (size_t)vtri(k + it, k) * 1024, A.lscr, n, (k + it) * 32, k * 32, it == 0);
                         put_block(s_aux + (size_t)k * 1024, A.dinv_out + (size_t)k * 1024, 32, 0, 0, false);
+                        publish(k, k + 1, 0u);
                     }
                 } else {
                     for (int t = 1 + (wave < 4 ? wave - 1 : wave - 2); t < nt; t += VJF_CHOL_THREADS / 64 - 2) trail(k, t);
                 }
             }
             __syncthreads();
+            kdone = k + 1;
             if (k < 7) VJF_STAMP(9 + k);
         }
         const bool ok = s_flag[0] != 0;
@@ -585,6 +600,8 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
             const float inv_v = expf(-sig);
             for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) Pm[e] = Pm[e] - G[e] * inv_v;
             if (A.post) {
+                // columns published so far are those of iterations that completed; every other flag says "failed"
+                if (wave == 4) publish(kdone, VJF_CHOL_MAXBLK + 1, 1u);
                 if (tid == 0) { A.ok_out[0] = 0; vjf_status_or(SC + VJF_SC_STATUS, st); }
                 return;
             }
@@ -601,6 +618,7 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                     if (tid == 0) SC[VJF_SC_TRI_CLEAN] = 1.f;
                 }
                 if (tid == 0) A.ok_out[0] = 1;
+                if (wave == 4) publish(VJF_CHOL_MAXBLK, VJF_CHOL_MAXBLK + 1, 0u);   // the factor as a whole is good
                 return;
             }
             // ---- w_pchol = L (lower, module.py:99-100)

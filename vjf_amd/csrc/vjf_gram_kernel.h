@@ -13,6 +13,7 @@
 #include "vjf_plan.h"
 
 typedef float vjf_f32x16 __attribute__((ext_vector_type(16)));
+typedef float vjf_f32x4 __attribute__((ext_vector_type(4)));
 
 struct VjfGramArgs {
     const VjfJob* jobs;

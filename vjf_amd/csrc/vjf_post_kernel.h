@@ -27,7 +27,10 @@ struct VjfPostArgs {
     const float* dinv;      // nbl blocks (32x32 row-major) of inverted diagonal blocks, from vjf_chol_lds_kernel
     const float* lscr;      // (n, n) L as vjf_chol_lds_kernel left it (block-lower part valid); copied to w_pchol here
     const float* gbuf;      // (n, dz) g
-    const int* ok;          // device flag written by the Cholesky kernel: 1 = factor valid
+    const unsigned* flags;  // flags[k] = (epoch << 1) | failed: column k of L (in lscr) and Dinv_k are in memory;
+    unsigned epoch;         //   flags[VJF_CHOL_MAXBLK]: the factor as a whole is good.  Written by vjf_chol_lds_kernel, which may
+                            //   still be running: the workgroups here consume the columns as they appear
+    float* status;          // the status scalar of the state blob (time-out of the wait below)
     const float* red;       // reduce buffer (G, FDX, sum|dx|^2) of this step
     int B_total;
     int fold_sigma;         // 1: the y / W workgroup goes on to the state-noise update (no vjf_resid / vjf_sigma launch)
@@ -46,7 +49,7 @@ struct VjfPostArgs {
 static inline size_t vjf_post_lds_bytes(const VjfPlan& P) {
     const int nbl = (P.n + 31) / 32;
     // L blocks + Dinv blocks | solution | block just solved | block table
-    return ((size_t)(nbl * (nbl - 1) / 2 + nbl) * 32 * VJF_POST_LDB + (size_t)nbl * 32 * VJF_POST_LDX + 32 * VJF_POST_LDX + 64 + 16) * 4;
+    return ((size_t)(nbl * (nbl - 1) / 2 + nbl) * 32 * VJF_POST_LDB + (size_t)nbl * 32 * VJF_POST_LDX + 32 * VJF_POST_LDX + 64 + 16 + 16) * 4;
 }
 
 // acc(row = 4*(lane>>4)+r of the 16-row tile, col = lane&15) += sum_m A(tile row, m) * B[m][col], m < 32
@@ -66,19 +69,39 @@ __device__ __forceinline__ void post_mma32(vjf_f32x4& acc, const float* Bs, int 
     acc += acc1;
 }
 
+// Wait (one lane polls, relaxed, bounded) until the Cholesky kernel has published flag word `k` for this epoch, then make
+// its bytes visible to the whole workgroup: one agent-scope acquire, its vmcnt drained, the workgroup barrier, and only then
+// the plain loads (cdna guide, Guideline 16).  Returns 0 = there, 1 = the factorisation failed, 2 = timed out.
+__device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned epoch, int k, int* s_ctl, int tid) {
+    if (tid == 0) {
+        int st = 2;
+        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+            const unsigned v = __hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 1) == epoch) { st = (int)(v & 1u); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ctl[0] = st;
+    }
+    __syncthreads();
+    const int st = s_ctl[0];
+    __syncthreads();                                           // (s_ctl is reused by the next wait)
+    return st;
+}
+
 __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan P, VjfPostArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = P.n, dz = P.dz, nbl = (n + 31) / 32, ntri = nbl * (nbl + 1) / 2, nlow = ntri - nbl;
     const bool solve = (int)blockIdx.x == 2 * nbl;             // the y / W workgroup
-    const bool failed = A.ok[0] == 0;                          // factorisation failed: RLS state stays as it was
-    if (failed && !(solve && A.fold_sigma)) return;
     constexpr int LB = VJF_POST_LDB, LX = VJF_POST_LDX;
     float* s_L = lds;                                          // strictly-lower blocks [32][33] of L (bi > bj)
     float* s_D = s_L + (size_t)nlow * 32 * LB;                 // nbl blocks [32][33]: inverted diagonal blocks
     float* s_x = s_D + (size_t)nbl * 32 * LB;                  // [npad][17] right-hand sides -> solution
     float* s_y = s_x + (size_t)nbl * 32 * LX;                  // [32][17] the block just solved, for the eager updates
-    int* s_tab = reinterpret_cast<int*>(s_y + 32 * LX);        // block -> (bi << 8) | bj: strictly lower, then diagonal
+    int* s_tab = reinterpret_cast<int*>(s_y + 32 * LX);        // [32..64): lower tiles incl. diagonal -> (bi << 8) | bj
+    int* s_ctl = s_tab + 64;
     const float* S = A.state;
     const float* Lm = A.lscr;
     const int j0 = solve ? 0 : (int)blockIdx.x >> 1;           // first block row of the substitution
@@ -98,115 +121,109 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         pre_scale = 1.0 / ((double)Bf * (double)P.dz);
     }
     VJF_POST_STAMP(16);
-    if (tid < nlow) {
-        int bi = 1;
-        while ((bi + 1) * bi / 2 <= tid) ++bi;                 // tri(bi, 0) <= tid < tri(bi + 1, 0)
-        s_tab[tid] = (bi << 8) | (tid - bi * (bi - 1) / 2);
-    } else if (tid < ntri) s_tab[tid] = ((tid - nlow) << 8) | (tid - nlow);
-    if (tid >= 64 && tid < 64 + ntri) {                        // lower tiles, diagonal included: t = bi (bi + 1) / 2 + bj
-        const int t = tid - 64;
+    if (tid < ntri) {                                          // lower tiles, diagonal included: t = bi (bi + 1) / 2 + bj
         int bi = 0;
-        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-        s_tab[32 + t] = (bi << 8) | (t - bi * (bi + 1) / 2);
+        while ((bi + 1) * (bi + 2) / 2 <= tid) ++bi;
+        s_tab[32 + tid] = (bi << 8) | (tid - bi * (bi + 1) / 2);
+    }
+    // right-hand side: 16 columns of the identity (inverse) or g padded to 16 columns (solve)
+    for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
+        const int r = e >> 4, c = e & 15;
+        float v0;
+        if (solve) v0 = (r < n && c < dz) ? A.gbuf[(size_t)r * dz + c] : 0.f;
+        else v0 = (r == j0 * 32 + c0 + c) ? 1.f : 0.f;
+        s_x[r * LX + c] = v0;
     }
     __syncthreads();
 
-    // ---- stage L (blocks with row > col >= j0) and the inverted diagonal blocks: straight-line code, every load of a
-    //      thread (<= 14 float4: 28 blocks x 256 chunks / 512 threads) in flight before the first LDS store
+    // the y / W workgroup prefetches what its tail needs: wavefront w the lower 32x32 tiles w, w + 8, .. of G in the
+    // matrix-core accumulator layout, and FDX (plain loads from clamped addresses: the tail masks what lies outside)
     float gpre[4][16], fpre[8];
-    if (!failed) {
-        constexpr int NQ = (VJF_CHOL_MAXBLK * (VJF_CHOL_MAXBLK + 1) / 2 * 256 + VJF_POST_THREADS - 1) / VJF_POST_THREADS;
-        // chunk e = tid + 512 q of block b = 2 q + (tid >> 8): row and column of the chunk inside its block do not depend on q
-        const int bh = tid >> 8, r = (tid >> 3) & 31, c4 = (tid & 7) * 4;
-        float4 v[NQ];
-        unsigned need = 0, put = 0;
+    if (solve && A.fold_sigma) {
+        const float* G = A.red + P.red_G;
+        const float* FDX = A.red + P.red_FDX;
+        const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int b = 2 * q + bh;
-            const int code = s_tab[min(b, ntri - 1)], bi = code >> 8, bj = code & 255;
-            const int gi = bi * 32 + r, gj = bj * 32 + c4;
-            const bool isl = b < nlow;
-            const bool wanted = b < ntri && bj >= j0;                          // this workgroup's substitution reads it
-            const bool real = wanted && (!isl || (gi < n && gj < n));          // (padding rows / columns of L are zero)
-            const float* src = isl ? Lm + (size_t)gi * n + gj : A.dinv + (size_t)bj * 1024 + r * 32 + c4;
-            v[q] = *reinterpret_cast<const float4*>(real ? src : A.dinv);
-            need |= (real ? 1u : 0u) << q;
-            put |= (wanted ? 1u : 0u) << q;
+        for (int q = 0; q < 4; ++q) {
+            const int code = s_tab[32 + min(wave + 8 * q, ntri - 1)];
+            const int bi = code >> 8, bj = code & 255;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gi = min(bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n - 1), gj = min(bj * 32 + c, n - 1);
+                gpre[q][r] = G[(size_t)gi * n + gj];
+            }
         }
-        // the y / W workgroup prefetches what its tail needs (behind the staging loads: vmcnt retires in order):
-        // wavefront w the lower 32x32 tiles w, w + 8, .. of G in the matrix-core accumulator layout, and FDX
-        if (solve && A.fold_sigma) {
-            const float* G = A.red + P.red_G;
-            const float* FDX = A.red + P.red_FDX;
-            const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                                      // plain loads from clamped addresses: the
-                const int code = s_tab[32 + min(wave + 8 * q, ntri - 1)];      // tail masks what lies outside the matrix
-                const int bi = code >> 8, bj = code & 255;
+        for (int q = 0; q < 8; ++q) {                                          // W's [row][16] grid: 224 * 16 <= 8 * 512
+            const int e = tid + q * VJF_POST_THREADS, r = min(e >> 4, n - 1), cc = min(e & 15, dz - 1);
+            fpre[q] = FDX[r * dz + cc];
+        }
+    }
+
+    // Both substitutions run eagerly: as soon as block k of the solution exists (two wavefronts, one 16-row tile each),
+    // every wavefront subtracts its contribution from the 16-row tiles of the later blocks it owns, in place in s_x.
+    const int tile = wave & 1, grp = wave >> 1;                // owner of tile `tile` of blocks first + grp, first + grp + 4, ..
+    const int xr = 4 * (lane >> 4), xc = lane & 15;            // accumulator element (row xr + r, column xc) of a 16x16 tile
+    int bad = 0;
+    // ---- forward  Y_k = Dinv_k R_k ;  R_i -= L_ik Y_k  (i > k),   k = j0 .. nbl-1, column k of L staged when it appears
+    for (int k = j0; k < nbl; ++k) {
+        bad = post_wait_column(A.flags, A.epoch, k, s_ctl, tid);
+        if (bad) break;
+        {   // stage column k: blocks (i, k), i > k, and Dinv_k; (nbl - k) x 256 float4 chunks, all of a thread's in flight
+            const int nb = nbl - k;
+            float4 v[4];                                                       // nb * 256 <= 7 * 256 <= 4 * 512
+            const int r = (tid >> 3) & 31, c4 = (tid & 7) * 4, bh = tid >> 8;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gi = min(bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n - 1), gj = min(bj * 32 + c, n - 1);
-                    gpre[q][r] = G[(size_t)gi * n + gj];
+            for (int q = 0; q < 4; ++q) {
+                const int it = 2 * q + bh;                                     // 0: Dinv_k; i = k + it: L block (i, k)
+                const int gi = (k + it) * 32 + r, gj = k * 32 + c4;
+                const bool real = it < nb && (it == 0 || (gi < n && gj < n));  // (padding rows / columns of L are zero)
+                const float* src = it == 0 ? A.dinv + (size_t)k * 1024 + r * 32 + c4 : Lm + (size_t)gi * n + gj;
+                v[q] = *reinterpret_cast<const float4*>(real ? src : A.dinv);
+                if (!real) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int it = 2 * q + bh;
+                if (it < nb) {
+                    float* dst = (it == 0 ? s_D + ((size_t)k * 32 + r) * LB : s_L + ((size_t)tri(k + it, k) * 32 + r) * LB) + c4;
+                    dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {                                      // W's [row][16] grid: 224 * 16 <= 8 * 512
-                const int e = tid + q * VJF_POST_THREADS, r = min(e >> 4, n - 1), cc = min(e & 15, dz - 1);
-                fpre[q] = FDX[r * dz + cc];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (!((put >> q) & 1u)) continue;
-            const int b = 2 * q + bh;
-            float* dst = (b < nlow ? s_L + ((size_t)b * 32 + r) * LB : s_D + ((size_t)(b - nlow) * 32 + r) * LB) + c4;
-            const bool real = (need >> q) & 1u;
-            dst[0] = real ? v[q].x : 0.f; dst[1] = real ? v[q].y : 0.f; dst[2] = real ? v[q].z : 0.f; dst[3] = real ? v[q].w : 0.f;
-        }
-        // right-hand side: 16 columns of the identity (inverse) or g padded to 16 columns (solve)
-        for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
-            const int r = e >> 4, c = e & 15;
-            float v0;
-            if (solve) v0 = (r < n && c < dz) ? A.gbuf[(size_t)r * dz + c] : 0.f;
-            else v0 = (r == j0 * 32 + c0 + c) ? 1.f : 0.f;
-            s_x[r * LX + c] = v0;
         }
         __syncthreads();
-        VJF_POST_STAMP(17);
-
-        // Both substitutions run eagerly: as soon as block k of the solution exists (two wavefronts, one 16-row tile each),
-        // every wavefront subtracts its contribution from the 16-row tiles of the later blocks it owns, in place in s_x.
-        // Two barriers and two dependent block products per block row.
-        const int tile = wave & 1, grp = wave >> 1;            // owner of tile `tile` of blocks first + grp, first + grp + 4, ..
-        const int xr = 4 * (lane >> 4), xc = lane & 15;        // accumulator element (row xr + r, column xc) of a 16x16 tile
-        // ---- forward  Y_k = Dinv_k R_k ;  R_i -= L_ik Y_k  (i > k),   k = j0 .. nbl-1
-        for (int k = j0; k < nbl; ++k) {
-            vjf_f32x4 y = {0.f, 0.f, 0.f, 0.f};
-            if (wave < 2) {
-                const float* Db = s_D + (size_t)k * 32 * LB;
-                post_mma32(y, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Db[(16 * wave + i) * LB + m]; });
+        if (k == j0) VJF_POST_STAMP(17);
+        vjf_f32x4 y = {0.f, 0.f, 0.f, 0.f};
+        if (wave < 2) {
+            const float* Db = s_D + (size_t)k * 32 * LB;
+            post_mma32(y, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Db[(16 * wave + i) * LB + m]; });
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s_y[(16 * wave + xr + r) * LX + xc] = y[r];
-            }
-            __syncthreads();
-            if (wave < 2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s_x[(k * 32 + 16 * wave + xr + r) * LX + xc] = y[r];
-            }
-            for (int i = k + 1 + grp; i < nbl; i += VJF_POST_THREADS / 128) {
-                const float* Lb = s_L + (size_t)tri(i, k) * 32 * LB;
-                float* xt = s_x + ((size_t)i * 32 + 16 * tile + xr) * LX + xc;
-                vjf_f32x4 acc;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = xt[r * LX];
-                post_mma32(acc, s_y, lane, [&](int ii, int m) { return -Lb[(16 * tile + ii) * LB + m]; });
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xt[r * LX] = acc[r];
-            }
-            __syncthreads();
+            for (int r = 0; r < 4; ++r) s_y[(16 * wave + xr + r) * LX + xc] = y[r];
         }
-        VJF_POST_STAMP(18);
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_x[(k * 32 + 16 * wave + xr + r) * LX + xc] = y[r];
+        }
+        for (int i = k + 1 + grp; i < nbl; i += VJF_POST_THREADS / 128) {
+            const float* Lb = s_L + (size_t)tri(i, k) * 32 * LB;
+            float* xt = s_x + ((size_t)i * 32 + 16 * tile + xr) * LX + xc;
+            vjf_f32x4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = xt[r * LX];
+            post_mma32(acc, s_y, lane, [&](int ii, int m) { return -Lb[(16 * tile + ii) * LB + m]; });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xt[r * LX] = acc[r];
+        }
+        __syncthreads();
+    }
+    if (!bad) bad = post_wait_column(A.flags, A.epoch, VJF_CHOL_MAXBLK, s_ctl, tid);   // the factor as a whole
+    VJF_POST_STAMP(18);
+    if (bad == 2 && tid == 0) vjf_status_or(A.status, VJF_STATUS_RLS_FAILED);
+    const bool failed = bad != 0;                              // factorisation failed: RLS state stays as it was
+    if (failed && !(solve && A.fold_sigma)) return;
 
+    if (!failed) {
         if (!solve) {
             // ---- w_pchol = L (module.py:99-100): the factor is good, so the scratch copy goes to the state; 1/(2 nbl) each
             {
@@ -267,29 +284,11 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     //      f32 matrix cores and contracts them with the tiles of G it prefetched at kernel start (fp64 sums, fixed order).
     {
         double* s_p = reinterpret_cast<double*>(lds);          // one partial per wavefront (over s_L: the substitutions are done)
-        if (failed) {                                          // sigma still moves, on the W that stays: nothing was prefetched
+        if (failed) {                                          // sigma still moves, on the W that stays
             const float* Wold = A.state + P.off[VJF_SLOT_W_MEAN];
-            const float* G = A.red + P.red_G;
-            const float* FDX = A.red + P.red_FDX;
             for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
                 const int r = e >> 4, c = e & 15;
                 s_x[r * LX + c] = (r < n && c < dz) ? Wold[(size_t)r * dz + c] : 0.f;
-            }
-            const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int code = s_tab[32 + min(wave + 8 * q, ntri - 1)];
-                const int bi = code >> 8, bj = code & 255;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gi = min(bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n - 1), gj = min(bj * 32 + c, n - 1);
-                    gpre[q][r] = G[(size_t)gi * n + gj];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = tid + q * VJF_POST_THREADS, r = min(e >> 4, n - 1), cc = min(e & 15, dz - 1);
-                fpre[q] = FDX[r * dz + cc];
             }
         }
         __syncthreads();
