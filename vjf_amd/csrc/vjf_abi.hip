@@ -98,7 +98,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t E, ACT, DEL, partial, slabs, red, red2, work, jobs, aux, post, lscr, flags, total;
+    size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -106,9 +106,11 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = (o + bytes + 255) / 256 * 256; return at; };
     c.E = take((size_t)max_batch * P.ldE * 4);
+    c.E2 = take((size_t)max_batch * P.ldE * 4);            // odd steps' E rows in the multi-stream sequence
     c.ACT = take((size_t)max_batch * P.ldA * 4);
     c.DEL = take((size_t)max_batch * P.ldD * 4);
     c.partial = take(((size_t)max_batch / 4 + 2) * RS_N * 4);
+    c.partial2 = take(((size_t)max_batch / 4 + 2) * RS_N * 4);
     c.slabs = take((size_t)njobs * split_for(max_batch) * 1024 * 4);
     c.red = take((size_t)P.red_len * 4);
     c.red2 = take((size_t)P.red_len * 4);                  // odd steps' RLS statistics in the two-stream sequence
@@ -153,7 +155,7 @@ struct vjf_ctx {
     int n_ejobs;           // jobs [0, n_ejobs) are the E^T E tiles, the rest gradient tiles
     bool overlap;          // vjf_filter_seq: RLS chain on a second stream beside the trial / SGD chain
     hipStream_t stream2, stream3;
-    hipEvent_t ev_e, ev_b, ev_s, ev_p, ev_c;
+    hipEvent_t ev_a, ev_b, ev_s, ev_p, ev_c;
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
 };
 
@@ -231,7 +233,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->n_ejobs = 0;
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
-    c->stream2 = c->stream3 = nullptr; c->ev_e = c->ev_b = c->ev_s = c->ev_p = c->ev_c = nullptr;
+    c->stream2 = c->stream3 = nullptr; c->ev_a = c->ev_b = c->ev_s = c->ev_p = c->ev_c = nullptr;
     c->epoch = 0;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
@@ -253,7 +255,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
 int vjf_ctx_destroy(vjf_ctx* ctx) {
     if (ctx && ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3);
-        (void)hipEventDestroy(ctx->ev_e); (void)hipEventDestroy(ctx->ev_b); (void)hipEventDestroy(ctx->ev_s);
+        (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_b); (void)hipEventDestroy(ctx->ev_s);
         (void)hipEventDestroy(ctx->ev_p); (void)hipEventDestroy(ctx->ev_c);
         (void)hipStreamDestroy(ctx->stream2); (void)hipStreamDestroy(ctx->stream3);
     }
@@ -322,12 +324,12 @@ int check_step_args(vjf_ctx* c, int32_t B, const float* y, const float* u, const
 }
 
 VjfTrialArgs trial_args(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
-                        const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags) {
+                        const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags, int gen = 0) {
     VjfTrialArgs a{};
     a.y = y; a.u = u; a.mu_s = mu_s; a.lv_s = lv_s; a.eps_s = eps_s; a.eps_t = eps_t; a.mu_t = mu_t; a.lv_t = lv_t;
     a.state = c->state;
-    a.E = (float*)(c->ws + c->cv.E); a.ACT = (float*)(c->ws + c->cv.ACT); a.DEL = (float*)(c->ws + c->cv.DEL);
-    a.partial = (float*)(c->ws + c->cv.partial);
+    a.E = (float*)(c->ws + (gen ? c->cv.E2 : c->cv.E)); a.ACT = (float*)(c->ws + c->cv.ACT); a.DEL = (float*)(c->ws + c->cv.DEL);
+    a.partial = (float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial));
     a.B = B; a.flags = flags;
     return a;
 }
@@ -355,19 +357,20 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
 }
 
 // Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
-int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, hipEvent_t stop = nullptr) {
+int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, hipEvent_t stop = nullptr,
+                int gen = 0) {
     const VjfPlan& P = c->plan;
     const int nsplit = split_for(B);
     VjfGramArgs g{};
     g.jobs = (const VjfJob*)(c->ws + c->cv.jobs);
-    g.E = (const float*)(c->ws + c->cv.E); g.ACT = (const float*)(c->ws + c->cv.ACT); g.DEL = (const float*)(c->ws + c->cv.DEL);
+    g.E = (const float*)(c->ws + (gen ? c->cv.E2 : c->cv.E)); g.ACT = (const float*)(c->ws + c->cv.ACT); g.DEL = (const float*)(c->ws + c->cv.DEL);
     g.slabs = (float*)(c->ws + c->cv.slabs);
     g.B = B; g.nsplit = nsplit; g.job0 = job0;
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
     hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(256), 0, st, P, g);
     VJF_HIP(hipGetLastError());
     VjfReduceArgs r{};
-    r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + c->cv.partial); r.red = red;
+    r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial)); r.red = red;
     r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask;
     VJF_LAUNCH(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(256), 0, st, stop, P, r);
     VJF_HIP(hipGetLastError());
@@ -458,7 +461,7 @@ int ensure_stream2(vjf_ctx* c) {
     VJF_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     VJF_HIP(hipEventCreate(&c->ev_p));
     VJF_HIP(hipEventCreate(&c->ev_c));
-    VJF_HIP(hipEventCreate(&c->ev_e));          // (default flags: the events are attached to kernel launches)
+    VJF_HIP(hipEventCreate(&c->ev_a));          // (default flags: the events are attached to kernel launches)
     VJF_HIP(hipEventCreate(&c->ev_b));
     VJF_HIP(hipEventCreate(&c->ev_s));
     return 0;
@@ -481,20 +484,20 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     float* red[2] = {(float*)(c->ws + c->cv.red), (float*)(c->ws + c->cv.red2)};
     auto args = [&](int t) {
         return trial_args(c, B, y + t * sy, u ? u + t * su : nullptr, t ? mu + (t - 1) * sz : mu0, t ? lv + (t - 1) * sz : lv0,
-                          eps + (size_t)t * 2 * sz, eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags);
+                          eps + (size_t)t * 2 * sz, eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags, t & 1);
     };
     rc = check_step_args(c, B, y, u, mu0, lv0, eps, eps + sz, mu, lv);
     if (rc) return rc;
     rc = refresh_aux(c);
     if (rc) return rc;
     const int ne = c->n_ejobs, ng = c->njobs - ne;
-    // prologue: forward half and RLS statistics of step 0
-    if ((rc = launch_trial(c, args(0), 1, sa))) return rc;
-    if ((rc = launch_gram(c, B, 0, ne, kScRls, red[0], sa, c->ev_e))) return rc;
+    if ((rc = launch_trial(c, args(0), 1, sa, c->ev_a))) return rc;        // prologue: forward half of step 0
     for (int t = 0; t < T; ++t) {
-        VJF_HIP(hipStreamWaitEvent(sb, c->ev_e, 0));                       // chain B(t) <- E^T E(t)
+        // sb: RLS statistics of step t as soon as its forward half is done, then (behind W, sigma of t-1) P += G/v, g, Cholesky
+        VJF_HIP(hipStreamWaitEvent(sb, c->ev_a, 0));
+        if ((rc = launch_gram(c, B, 0, ne, kScRls, red[t & 1], sb, nullptr, t & 1))) return rc;
         if (t > 0) {
-            VJF_HIP(hipStreamWaitEvent(sb, c->ev_s, 0));                   // ... and W, sigma of t-1 (the post kernel is on sc)
+            VJF_HIP(hipStreamWaitEvent(sb, c->ev_s, 0));
             VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                   // backward half(t) <- W, w_chol, sigma of t-1
         }
         if ((rc = launch_trial(c, args(t), 2, sa, c->ev_b))) return rc;
@@ -503,12 +506,9 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         // half).  The first Cholesky of a blob clears w_chol's zero half in place (VJF_SC_TRI_CLEAN): that one waits for the
         // reader too.
         if ((rc = launch_rls(c, B, flags, red[t & 1], sb, t == 0 ? c->ev_b : nullptr, sc, c->ev_p, c->ev_b, c->ev_s))) return rc;
-        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, red[0], sa))) return rc;
+        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, red[0], sa, nullptr, t & 1))) return rc;
         if ((rc = launch_prep(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags, red[0], 2, sa))) return rc;
-        if (t + 1 < T) {
-            if ((rc = launch_trial(c, args(t + 1), 1, sa))) return rc;
-            if ((rc = launch_gram(c, B, 0, ne, kScRls, red[(t + 1) & 1], sa, c->ev_e))) return rc;
-        }
+        if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, c->ev_a))) return rc;
     }
     VJF_HIP(hipEventRecord(c->ev_c, sb));
     VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                           // join: the caller's stream sees the final state
