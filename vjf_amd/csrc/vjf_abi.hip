@@ -155,8 +155,9 @@ struct vjf_ctx {
     int n_ejobs;           // jobs [0, n_ejobs) are the E^T E tiles, the rest gradient tiles
     bool overlap;          // vjf_filter_seq: RLS chain on a second stream beside the trial / SGD chain
     hipStream_t stream2, stream3;
-    hipEvent_t ev_a, ev_b, ev_s, ev_p, ev_c;
+    hipEvent_t ev_a, ev_s, ev_c;
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
+    unsigned k1_count;     // workgroups of the matrix-core trial kernel (whole step or backward half) launched so far
 };
 
 extern "C" {
@@ -233,8 +234,8 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->n_ejobs = 0;
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
-    c->stream2 = c->stream3 = nullptr; c->ev_a = c->ev_b = c->ev_s = c->ev_p = c->ev_c = nullptr;
-    c->epoch = 0;
+    c->stream2 = c->stream3 = nullptr; c->ev_a = c->ev_s = c->ev_c = nullptr;
+    c->epoch = 0; c->k1_count = 0;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red2, 0, (size_t)P.red_len * 4, c->stream);
@@ -255,8 +256,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
 int vjf_ctx_destroy(vjf_ctx* ctx) {
     if (ctx && ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3);
-        (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_b); (void)hipEventDestroy(ctx->ev_s);
-        (void)hipEventDestroy(ctx->ev_p); (void)hipEventDestroy(ctx->ev_c);
+        (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_s); (void)hipEventDestroy(ctx->ev_c);
         (void)hipStreamDestroy(ctx->stream2); (void)hipStreamDestroy(ctx->stream3);
     }
     delete ctx;
@@ -343,6 +343,8 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
     if (c->mfma_trial) {
         VjfTrialMfmaArgs m{};
         m.t = a; m.aux = (const float*)(c->ws + c->cv.aux); m.part = part;
+        m.done = (unsigned*)(c->ws + c->cv.flags) + 16;
+        if (part != 1) c->k1_count += (unsigned)nblk;
         m.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
         VJF_LAUNCH(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, stop, P, m);
     } else {
@@ -395,11 +397,13 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
 }
 
 // Cholesky + RLS tail + state-noise update.  `before_chol` / `before_post`: events the stream waits for first (or null).
-int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, hipEvent_t before_chol,
-               hipStream_t st_post, hipEvent_t before_post0, hipEvent_t before_post1, hipEvent_t stop = nullptr) {
+int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, hipStream_t st_post,
+               hipEvent_t stop = nullptr, bool no_triclean = false) {
     // `st_post` may differ from `st`: the post kernel's workgroups then start beside the Cholesky kernel and take each
     // column of L as the flag for it appears (the Cholesky kernel is always enqueued first, so even on one hardware queue
-    // nothing waits for a kernel behind it).
+    // nothing waits for a kernel behind it).  What the post kernel needs from elsewhere it waits for itself: g through the
+    // column flags (the prep kernel precedes the Cholesky kernel in `st`), the readers of W, w_chol, sigma through the trial
+    // kernel's workgroup count.
     const VjfPlan& P = c->plan;
     if (!(flags & VJF_FLAG_UPDATE)) return 0;
     VjfCholArgs a{};
@@ -411,8 +415,7 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
     int* okflag = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
     unsigned* colflags = (unsigned*)(c->ws + c->cv.flags);
     a.post = c->post_kernels ? 1 : 0; a.dinv_out = dinv; a.ok_out = okflag; a.lscr = (float*)(c->ws + c->cv.lscr);
-    a.flags_out = colflags; a.epoch = ++c->epoch;
-    if (before_chol) VJF_HIP(hipStreamWaitEvent(st, before_chol, 0));
+    a.flags_out = colflags; a.epoch = ++c->epoch; a.no_triclean = no_triclean ? 1 : 0;
     switch (vjf_chol_dzp(P.dz)) {
         case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
         case 8: hipLaunchKernelGGL(vjf_chol_lds_kernel<8>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
@@ -421,8 +424,6 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
         default: hipLaunchKernelGGL(vjf_chol_lds_kernel<32>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
     }
     VJF_HIP(hipGetLastError());
-    if (before_post0) VJF_HIP(hipStreamWaitEvent(st_post, before_post0, 0));
-    if (before_post1) VJF_HIP(hipStreamWaitEvent(st_post, before_post1, 0));
     if (c->post_kernels) {
         const bool rls = !(flags & VJF_FLAG_WARM_UP);
         if (rls) {
@@ -430,6 +431,7 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
             VjfPostArgs pa{};
             pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.lscr = a.lscr;
             pa.flags = colflags; pa.epoch = a.epoch; pa.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
+            pa.k1_done = c->mfma_trial ? colflags + 16 : nullptr; pa.k1_target = c->k1_count;
             pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
             VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st_post, stop, P, pa);
             VJF_HIP(hipGetLastError());
@@ -459,10 +461,8 @@ int ensure_stream2(vjf_ctx* c) {
     if (c->stream2) return 0;
     VJF_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     VJF_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
-    VJF_HIP(hipEventCreate(&c->ev_p));
     VJF_HIP(hipEventCreate(&c->ev_c));
     VJF_HIP(hipEventCreate(&c->ev_a));          // (default flags: the events are attached to kernel launches)
-    VJF_HIP(hipEventCreate(&c->ev_b));
     VJF_HIP(hipEventCreate(&c->ev_s));
     return 0;
 }
@@ -500,12 +500,17 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             VJF_HIP(hipStreamWaitEvent(sb, c->ev_s, 0));
             VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                   // backward half(t) <- W, w_chol, sigma of t-1
         }
-        if ((rc = launch_trial(c, args(t), 2, sa, c->ev_b))) return rc;
-        if ((rc = launch_prep(c, B, nullptr, flags, red[t & 1], 1, sb, c->ev_p))) return rc;
-        // Cholesky on sb; the post kernel on sc beside it, behind g (prep) and behind the reader of W, w_chol, sigma (backward
-        // half).  The first Cholesky of a blob clears w_chol's zero half in place (VJF_SC_TRI_CLEAN): that one waits for the
-        // reader too.
-        if ((rc = launch_rls(c, B, flags, red[t & 1], sb, t == 0 ? c->ev_b : nullptr, sc, c->ev_p, c->ev_b, c->ev_s))) return rc;
+        if ((rc = launch_trial(c, args(t), 2, sa))) return rc;
+        if (t == 0) {
+            // the post kernel writes only the block-upper half of w_chol (block-lower of w_pchol): the other halves are cleared
+            // once per blob (VJF_SC_TRI_CLEAN), here behind the backward half that may still read a full w_chol
+            hipLaunchKernelGGL(vjf_triclean_kernel, dim3(64), dim3(256), 0, sa, P, c->state);
+            hipLaunchKernelGGL(vjf_triclean_done_kernel, dim3(1), dim3(1), 0, sa, P, c->state);
+            VJF_HIP(hipGetLastError());
+        }
+        if ((rc = launch_prep(c, B, nullptr, flags, red[t & 1], 1, sb))) return rc;
+        // Cholesky on sb; the post kernel on sc beside it (it takes the columns of L as they appear)
+        if ((rc = launch_rls(c, B, flags, red[t & 1], sb, sc, c->ev_s, true))) return rc;
         if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, red[0], sa, nullptr, t & 1))) return rc;
         if ((rc = launch_prep(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags, red[0], 2, sa))) return rc;
         if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, c->ev_a))) return rc;
@@ -530,7 +535,7 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
         const float* red = (const float*)(c->ws + c->cv.red);
         int rc = launch_prep(c, B_total, loss4, flags, red, 0, c->stream);
         if (rc) return rc;
-        return launch_rls(c, B_total, flags, red, c->stream, nullptr, c->stream, nullptr, nullptr);
+        return launch_rls(c, B_total, flags, red, c->stream, c->stream);
     }
     VjfSerialArgs s{};
     s.state = c->state; s.red = (const float*)(c->ws + c->cv.red); s.work = (float*)(c->ws + c->cv.work);

@@ -391,6 +391,7 @@ struct VjfCholArgs {
     float* lscr;           // post mode: (n, n) scratch that receives L column by column while the factorisation runs
     unsigned* flags_out;   // post mode: flags_out[k] = (epoch << 1) | failed once column k of L and Dinv_k are in global memory:
     unsigned epoch;        //   vjf_rls_post_kernel, launched beside this kernel, consumes the columns as they appear
+    int no_triclean;       // post mode: the caller clears the zero halves of w_chol / w_pchol itself (vjf_triclean_kernel)
                            //            (vjf_rls_post_kernel copies it to w_pchol once the factor is known to be good)
 };
 
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
         } else {
             if (A.post) {
                 // L and the inverted diagonal blocks already left column by column; one-time clearing of the zero halves; done
-                if (SC[VJF_SC_TRI_CLEAN] == 0.f) {
+                if (!A.no_triclean && SC[VJF_SC_TRI_CLEAN] == 0.f) {
                     for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) {
                         const int i = e / n, j = e - i * n;
                         if ((i >> 5) < (j >> 5)) Lm[e] = 0.f;
@@ -837,3 +838,20 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
     }
     VJF_STAMP(8);
 }
+
+// One-time clearing of the halves that the post kernel never writes (block-lower part of w_chol, block-upper part of
+// w_pchol), for callers that run the Cholesky kernel beside a reader of w_chol (vjf_filter_seq).  grid-stride.
+__global__ void vjf_triclean_kernel(VjfPlan P, float* state) {
+    float* SC = state + P.off[VJF_SLOT_SCALARS];
+    if (SC[VJF_SC_TRI_CLEAN] != 0.f) return;
+    float* Wc = state + P.off[VJF_SLOT_W_CHOL];
+    float* Lm = state + P.off[VJF_SLOT_W_PCHOL];
+    const int n = P.n;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x) {
+        const int i = e / n, j = e - i * n;
+        if ((i >> 5) < (j >> 5)) Lm[e] = 0.f;
+        if ((i >> 5) > (j >> 5)) Wc[e] = 0.f;
+    }
+}
+// (the flag is set by a second, one-thread launch behind it: every workgroup above must have seen it clear)
+__global__ void vjf_triclean_done_kernel(VjfPlan P, float* state) { state[P.off[VJF_SLOT_SCALARS] + VJF_SC_TRI_CLEAN] = 1.f; }

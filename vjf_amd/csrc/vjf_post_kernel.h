@@ -31,6 +31,8 @@ struct VjfPostArgs {
     unsigned epoch;         //   flags[VJF_CHOL_MAXBLK]: the factor as a whole is good.  Written by vjf_chol_lds_kernel, which may
                             //   still be running: the workgroups here consume the columns as they appear
     float* status;          // the status scalar of the state blob (time-out of the wait below)
+    const unsigned* k1_done;  // workgroups of the trial kernel that have finished reading W, w_chol, sigma (null: not needed);
+    unsigned k1_target;       //   nothing of those is written before the count reaches k1_target
     const float* red;       // reduce buffer (G, FDX, sum|dx|^2) of this step
     int B_total;
     int fold_sigma;         // 1: the y / W workgroup goes on to the state-noise update (no vjf_resid / vjf_sigma launch)
@@ -108,10 +110,26 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     const int c0 = solve ? 0 : 16 * ((int)blockIdx.x & 1);
     auto tri = [](int bi, int bj) { return bi * (bi - 1) / 2 + bj; };       // strictly lower: bi > bj
 
-    // scalars of the state-noise update, fetched now so that the tail does not wait for them
     float pre_sdx2 = 0.f, pre_old = 0.f, pre_tot = 1.f;         // sum|dx|^2, old share of the running variance, new count
     double pre_scale = 0.0;                                     // mse -> new share of the running variance
-    if (solve && A.fold_sigma) {
+    VJF_POST_STAMP(16);
+    if (tid < ntri) {                                          // lower tiles, diagonal included: t = bi (bi + 1) / 2 + bj
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= tid) ++bi;
+        s_tab[32 + tid] = (bi << 8) | (tid - bi * (bi + 1) / 2);
+    }
+    // right-hand side: 16 columns of the identity (inverse); the y / W workgroup takes g after its first wait below (g comes
+    // from the prep kernel, which the Cholesky kernel follows in its stream: a column flag of this epoch says it is there)
+    if (!solve)
+        for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
+            const int r = e >> 4, c = e & 15;
+            s_x[r * LX + c] = (r == j0 * 32 + c0 + c) ? 1.f : 0.f;
+        }
+    __syncthreads();
+
+    float gpre[4][16], fpre[8];
+    auto prefetch_tail = [&]() {
+        // scalars of the state-noise update, fetched now so that the tail does not wait for them
         pre_sdx2 = A.red[P.red_SC + RS_SDX2];
         const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
         const float Bf = (float)A.B_total;
@@ -119,27 +137,8 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         pre_tot = acc + Bf;
         pre_old = (acc / pre_tot) * expf(sig);
         pre_scale = 1.0 / ((double)Bf * (double)P.dz);
-    }
-    VJF_POST_STAMP(16);
-    if (tid < ntri) {                                          // lower tiles, diagonal included: t = bi (bi + 1) / 2 + bj
-        int bi = 0;
-        while ((bi + 1) * (bi + 2) / 2 <= tid) ++bi;
-        s_tab[32 + tid] = (bi << 8) | (tid - bi * (bi + 1) / 2);
-    }
-    // right-hand side: 16 columns of the identity (inverse) or g padded to 16 columns (solve)
-    for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
-        const int r = e >> 4, c = e & 15;
-        float v0;
-        if (solve) v0 = (r < n && c < dz) ? A.gbuf[(size_t)r * dz + c] : 0.f;
-        else v0 = (r == j0 * 32 + c0 + c) ? 1.f : 0.f;
-        s_x[r * LX + c] = v0;
-    }
-    __syncthreads();
-
-    // the y / W workgroup prefetches what its tail needs: wavefront w the lower 32x32 tiles w, w + 8, .. of G in the
-    // matrix-core accumulator layout, and FDX (plain loads from clamped addresses: the tail masks what lies outside)
-    float gpre[4][16], fpre[8];
-    if (solve && A.fold_sigma) {
+        // wavefront w: the lower 32x32 tiles w, w + 8, .. of G in the matrix-core accumulator layout, and FDX
+        // (plain loads from clamped addresses: the tail masks what lies outside the matrix)
         const float* G = A.red + P.red_G;
         const float* FDX = A.red + P.red_FDX;
         const int c = lane & 31, h = lane >> 5;
@@ -154,11 +153,11 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
             }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {                                          // W's [row][16] grid: 224 * 16 <= 8 * 512
+        for (int q = 0; q < 8; ++q) {                                  // W's [row][16] grid: 224 * 16 <= 8 * 512
             const int e = tid + q * VJF_POST_THREADS, r = min(e >> 4, n - 1), cc = min(e & 15, dz - 1);
             fpre[q] = FDX[r * dz + cc];
         }
-    }
+    };
 
     // Both substitutions run eagerly: as soon as block k of the solution exists (two wavefronts, one 16-row tile each),
     // every wavefront subtracts its contribution from the 16-row tiles of the later blocks it owns, in place in s_x.
@@ -169,6 +168,15 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     for (int k = j0; k < nbl; ++k) {
         bad = post_wait_column(A.flags, A.epoch, k, s_ctl, tid);
         if (bad) break;
+        if (solve && k == 0) {
+            // Everything this workgroup takes from the kernels that precede the Cholesky kernel in its stream (g, the RLS
+            // statistics) is read behind the first column flag of this epoch: the flag says those kernels are complete.
+            for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
+                const int r = e >> 4, c = e & 15;
+                s_x[r * LX + c] = (r < n && c < dz) ? A.gbuf[(size_t)r * dz + c] : 0.f;
+            }
+            if (A.fold_sigma) prefetch_tail();
+        }
         {   // stage column k: blocks (i, k), i > k, and Dinv_k; (nbl - k) x 256 float4 chunks, all of a thread's in flight
             const int nb = nbl - k;
             float4 v[4];                                                       // nb * 256 <= 7 * 256 <= 4 * 512
@@ -218,6 +226,20 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         __syncthreads();
     }
     if (!bad) bad = post_wait_column(A.flags, A.epoch, VJF_CHOL_MAXBLK, s_ctl, tid);   // the factor as a whole
+    if (A.k1_done) {                                           // readers of W, w_chol, sigma on another stream: all done?
+        if (tid == 0) {
+            int st = 2;
+            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                const unsigned v = __hip_atomic_load(A.k1_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(v - A.k1_target) >= 0) { st = 0; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            s_ctl[0] = st;
+        }
+        __syncthreads();
+        if (s_ctl[0] && !bad) bad = 2;
+        __syncthreads();
+    }
     VJF_POST_STAMP(18);
     if (bad == 2 && tid == 0) vjf_status_or(A.status, VJF_STATUS_RLS_FAILED);
     const bool failed = bad != 0;                              // factorisation failed: RLS state stays as it was
@@ -290,6 +312,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
                 const int r = e >> 4, c = e & 15;
                 s_x[r * LX + c] = (r < n && c < dz) ? Wold[(size_t)r * dz + c] : 0.f;
             }
+            prefetch_tail();                                   // (the failure may have come before the first column)
         }
         __syncthreads();
         VJF_POST_STAMP(20);

@@ -71,6 +71,8 @@ struct VjfTrialMfmaArgs {
     VjfTrialArgs t;
     const float* aux;      // transposed weights (VjfPlan::aux_*)
     unsigned long long* stamps;   // diagnostic only (null in normal runs)
+    unsigned* done;        // += 1 per workgroup once it has read W, w_chol, sigma for the last time (null: not counted):
+                           //   the post kernel, on another stream, waits for the count before it overwrites them
     int part;              // 0: whole step; 1: forward half (features, recognition, E / ACT rows, posterior);
                            // 2: backward half (predictive mean / variance, losses, backward, DEL rows) -- reloads the
                            //    forward half's rows, so that it can run after the RLS update of the previous step while
@@ -91,7 +93,7 @@ static inline size_t vjf_trial_mfma_lds_floats(const VjfPlan& P) {
     return feat * VJF_LDT + 16 * RS_N + VJF_K1M_WAVES * 16 + 16 + 64;
 }
 
-__global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrialMfmaArgs AA) {
+__global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrialMfmaArgs AA) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const VjfTrialArgs& A = AA.t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) void vjf_trial_mfma_kernel(VjfPlan
         for (int c = lane; c < 2 * dz + dy; c += 64) drow[c] = c < 2 * dz ? s_dmu[c * LD + b] : s_dpy[(c - 2 * dz) * LD + b];   // s_dlv follows s_dmu
     }
     VJF_K1_STAMP(30);
+    if (AA.done && bwd && tid == 0) __hip_atomic_fetch_add(AA.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Refresh the transposed weight copies from the canonical tensors (run at the start of an API call:
