@@ -214,8 +214,9 @@ def main():
                          "traffic_note": "HBM bytes per step: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, "
                                          "summed over the kernels of a step (profiles/pmc_traffic_current.json); algorithmic bytes "
                                          "per step = bytes_per_trial_step x trials",
-                         "kernel": "one filter step = vjf_trial_kernel + vjf_gram_kernel + vjf_gram_reduce_kernel + "
-                                   "vjf_serial_kernel (HIP events around the timed region / steps)",
+                         "kernel": "one filter step = vjf_trial_mfma_kernel (forward + backward half), vjf_gram_kernel x2, "
+                                   "vjf_gram_reduce_kernel x2, vjf_prep_kernel x2, vjf_chol_lds_kernel, vjf_rls_post_kernel on three "
+                                   "streams (HIP events around the timed region / steps)",
                          "flops_per_trial_step": flops, "serial_flops_per_step": serial_flops,
                          "step_us": step_s * 1e6, "host_enqueue_us_per_step": enq / K * 1e6, "trial_half_us": loc, "serial_half_us": glob,
                          "hbm_achieved_GBs": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS,

@@ -12,6 +12,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python - <<'PY'
 import csv, glob, json, collections
+NSTEP = 35                               # --steps 30 --warmup 5: every vjf_ kernel of the run belongs to one of them
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True)
@@ -21,17 +22,19 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f[0])):
         if r.get("Counter_Name") == c and "vjf_" in r["Kernel_Name"]:
             per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    out[c] = {k: {"dispatches": len(v), "avg_KB": sum(v) / len(v)} for k, v in per.items()}
+    out[c] = {k: {"dispatches": len(v), "avg_KB": sum(v) / len(v), "KB_per_step": sum(v) / NSTEP} for k, v in per.items()}
 names = sorted(set(out.get("FETCH_SIZE", {})) | set(out.get("WRITE_SIZE", {})))
 tot = 0.0
 for k in names:
-    if "vjf_aux_kernel" in k:
-        continue                      # runs once per API call, not per step
-    fe = out.get("FETCH_SIZE", {}).get(k, {}).get("avg_KB", 0.0) * 2.0     # gfx950 correction
-    wr = out.get("WRITE_SIZE", {}).get(k, {}).get("avg_KB", 0.0)
-    print(f"{k:36s} fetch(corrected) {fe:10.1f} KB  write {wr:10.1f} KB")
+    if "vjf_aux_kernel" in k or "triclean" in k:
+        continue                      # run once per API call, not per step
+    fe = out.get("FETCH_SIZE", {}).get(k, {}).get("KB_per_step", 0.0) * 2.0     # gfx950 correction
+    wr = out.get("WRITE_SIZE", {}).get(k, {}).get("KB_per_step", 0.0)
+    nd = out.get("FETCH_SIZE", {}).get(k, {}).get("dispatches", 0)
+    print(f"{k:36s} {nd / NSTEP:4.1f} launches/step  fetch(corrected) {fe:10.1f} KB/step  write {wr:10.1f} KB/step")
     tot += fe + wr
 out["bytes_per_step_corrected"] = tot * 1024
+out["note"] = "sum over all dispatches of the run / 35 steps; FETCH_SIZE x2 (gfx950), WRITE_SIZE as is; KB = 1024 B"
 print("HBM bytes per step (corrected):", tot * 1024)
 json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 PY
