@@ -252,6 +252,39 @@ def test_nonfinite_loss_is_flagged(vjf):
     assert np.isfinite(float(loss))
 
 
+def test_rls_failure_is_flagged_and_leaves_rls_state(vjf):
+    """A precision matrix that is not positive definite: the reference's fallback raises (module.py:104-112); here the RLS
+    tensors stay as they were, the status bit is raised and nothing hangs -- through the single-step path and through the
+    sequence path, where the post kernel waits on the Cholesky kernel's column flags."""
+    for n_rbf, bad_from in ((16, 0), (72, 0), (72, 40)):          # 1 block; 3 blocks failing in the first / second column
+        torch.manual_seed(4)
+        model = vjf.VJF.make_model(10, 3, 0, n_rbf, [8], likelihood="gaussian")
+        g = torch.Generator().manual_seed(5)
+        T, B = 3, 64
+        y, eps = torch.randn(T, B, 10, generator=g), torch.randn(T, 2, B, 3, generator=g)
+        lr = model.transition.velocity
+        with torch.no_grad():
+            P = lr.w_precision.clone()
+            P[bad_from:, bad_from:] -= 1e6 * torch.eye(n_rbf - bad_from, device=P.device)
+            lr.w_precision.copy_(P)
+        keep = {k: getattr(lr, k).clone() for k in ("w_mean", "w_chol", "w_pchol", "w_precision")}
+        sig0 = model.transition.logvar.clone()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model.filter(y[0], eps=(eps[0, 0], eps[0, 1]))
+            assert model.status() & 8                                # VJF_STATUS_RLS_FAILED
+            for k in ("w_mean", "w_chol", "w_pchol"):
+                assert torch.equal(getattr(lr, k), keep[k]), k
+            close(lr.w_precision, keep["w_precision"], rtol=1e-5, atol=1e-2)
+            assert not torch.equal(model.transition.logvar, sig0)    # the state-noise estimate still moves (model.py:373-377)
+            model.filter_sequence(y, eps=eps)
+            assert model.status() & 8
+            for k in ("w_mean", "w_chol", "w_pchol"):
+                assert torch.equal(getattr(lr, k), keep[k]), k
+            assert torch.isfinite(model.transition.logvar).all()
+
+
 def test_bad_arguments(vjf):
     model = vjf.VJF.make_model(10, 3, 2, 16, [8], likelihood="gaussian")
     with pytest.raises(TypeError):
