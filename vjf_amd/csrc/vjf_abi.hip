@@ -49,7 +49,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr size_t kMaxLds = 160 * 1024;
 
 int split_for(int B) {
-    int s = B / 512;
+    int s = B / 256;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
     return s;
