@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown-steps", type=int, default=20)
     ap.add_argument("--no-overlap", action="store_true", help="one-stream order inside filter_sequence (A/B of the schedule)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 only: run the sharded path (local half, RCCL all-reduce, global half) with a one-rank group")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,6 +127,11 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+    elif a.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["VJF_FORCE_DIST"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     import vjf_amd
     from vjf_amd import _native as N

@@ -119,6 +119,15 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status);
  * one-stream order.  Returns the resulting setting (1 / 0), or a negative error code. */
 int vjf_set_overlap(vjf_ctx* ctx, int enable);
 
+/* Trials sharded over ranks, one process per GPU: with communicators attached, vjf_filter_seq sums the RLS statistics and
+ * the gradients over ranks itself (two RCCL all-reduces per step, one on each chain of its schedule) and B in its
+ * arguments is the LOCAL batch.  RCCL is resolved at run time from the process (torch's copy) or librccl.so.
+ * vjf_comm_unique_id: rank 0 fills 256 bytes (two ncclUniqueId) that the caller broadcasts to every rank;
+ * vjf_comm_init: every rank, collectively.  Replaces the caller-side all-reduce between vjf_filter_local and
+ * vjf_filter_global (vjf/model.py has no multi-GPU path: SURVEY 8e). */
+int vjf_comm_unique_id(void* ids256);
+int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world);
+
 /* Diagnostic: enable/disable s_memtime phase stamps in the serial kernel and (out32 != NULL) copy the
  * 32 stamp words of the last step to the host.  Not part of the reference surface. */
 int vjf_debug_stamps(vjf_ctx* ctx, int enable, uint64_t* out32);

@@ -67,6 +67,8 @@ class FakeLib:
 
     def vjf_set_stream(self, ctx, stream): return 0
     def vjf_set_overlap(self, ctx, enable): return 0
+    def vjf_comm_unique_id(self, ids): return -111
+    def vjf_comm_init(self, ctx, ids, rank, world): return -111
 
     def vjf_get_status(self, ctx, out):
         c = self.ctxs[ctx.value]

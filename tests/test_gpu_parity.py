@@ -285,6 +285,37 @@ def test_rls_failure_is_flagged_and_leaves_rls_state(vjf):
             assert torch.isfinite(model.transition.logvar).all()
 
 
+def test_sharded_path_one_rank_nccl(vjf):
+    """The multi-GPU protocol (local half -> all-reduce of the reduce buffer over RCCL -> global half) with ONE rank on
+    this GPU: a one-rank sum is the identity, so the trajectory must match the plain path (same kernels: bitwise)."""
+    import os
+    import torch.distributed as dist
+    z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
+    m1, m2 = _model_for(vjf, info), _model_for(vjf, info)
+    load_fixture_state(m1, z, "s0")
+    load_fixture_state(m2, z, "s0")
+    y, eps = torch.tensor(z["y"][:4]), torch.tensor(z["eps"][:4])
+    m1.set_overlap(False)
+    o1 = m1.filter_sequence(y, None, None, eps=eps)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    os.environ["VJF_FORCE_DIST"] = "1"
+    try:
+        o2 = m2.filter_sequence(y, None, None, eps=eps)
+        q, loss = m2.filter(torch.tensor(z["y"][4]), eps=(torch.tensor(z["eps"][4, 0]), torch.tensor(z["eps"][4, 1])))
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("VJF_FORCE_DIST", None)
+        dist.destroy_process_group()
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    q1, loss1 = m1.filter(torch.tensor(z["y"][4]), eps=(torch.tensor(z["eps"][4, 0]), torch.tensor(z["eps"][4, 1])))
+    assert torch.equal(q.mean, q1.mean) and torch.equal(loss, loss1)
+    assert torch.equal(m1._blob, m2._blob)
+
+
 def test_bad_arguments(vjf):
     model = vjf.VJF.make_model(10, 3, 2, 16, [8], likelihood="gaussian")
     with pytest.raises(TypeError):

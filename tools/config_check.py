@@ -18,7 +18,7 @@ if c["dz"] >= 32:
     m.transition.velocity.feature.centroid.uniform_(-r, r)
     m.transition.velocity.feature.logwidth.fill_(float(np.log(r)))
 g = torch.Generator().manual_seed(1)
-T = 12
+T = 12 if c['n'] > 224 else 62
 if c["lik"] == "poisson":
     y = torch.poisson(torch.exp(0.5 * torch.randn(T, c["B"], c["dy"], generator=g) - 0.5), generator=g)
 else:
@@ -34,7 +34,10 @@ for t in range(2):
     print(f"step {t}: max|d mu| {err:.2e}  loss {float(loss):.6f} vs oracle {o.loss:.6f}  rel {abs(float(loss)-o.loss)/abs(o.loss):.1e}")
     assert err < 1e-4 and abs(float(loss) - o.loss) / abs(o.loss) < 1e-4
 yd, ed = y.cuda(), eps.cuda()
+W = 2 + (T - 2) // 6                                  # untimed: the first sequence call also creates the side streams
+mu_w, lv_w, _ = m.filter_sequence(yd[2:W], qs=q, eps=ed[2:W])
+q = vjf_amd.Gaussian(mu_w[-1], lv_w[-1])
 torch.cuda.synchronize(); t0 = time.perf_counter()
-m.filter_sequence(yd[2:], qs=q, eps=ed[2:])
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (T - 2)
+m.filter_sequence(yd[W:], qs=q, eps=ed[W:])
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (T - W)
 print(f"config {sys.argv[1]}: {dt*1e6:.0f} us/step, {c['B']/dt/1e6:.2f} M trial-timesteps/s, status {m.status()}")

@@ -51,6 +51,8 @@ SIGNATURES = {
     "vjf_set_stream": [_P, _P],
     "vjf_get_status": [_P, C.POINTER(_U)],
     "vjf_set_overlap": [_P, _I],
+    "vjf_comm_unique_id": [_P],
+    "vjf_comm_init": [_P, _P, _I, _I],
     "vjf_debug_stamps": [_P, _I, C.POINTER(C.c_uint64)],
     "vjf_filter_step": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U],
     "vjf_filter_local": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _U],

@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -44,6 +46,46 @@ int fail(int code, const char* fmt, ...) {
     do {                                                                                               \
         if (stop) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)(lds), st, nullptr, stop, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                            \
+    } while (0)
+
+// ---- RCCL, resolved at run time from the copy already in the process (torch's) or librccl.so: the library has no link-time
+//      dependency on it, and a single-GPU user never touches it
+struct VjfNcclId { char internal[128]; };
+typedef int (*nccl_get_unique_id_t)(VjfNcclId*);
+typedef int (*nccl_comm_init_rank_t)(void**, int, VjfNcclId, int);
+typedef int (*nccl_comm_destroy_t)(void*);
+typedef int (*nccl_all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_group_t)();
+typedef const char* (*nccl_err_t)(int);
+struct VjfNccl {
+    nccl_get_unique_id_t get_unique_id; nccl_comm_init_rank_t comm_init_rank; nccl_comm_destroy_t comm_destroy;
+    nccl_all_reduce_t all_reduce; nccl_group_t group_start, group_end; nccl_err_t err;
+    bool ok;
+};
+constexpr int kNcclFloat = 7, kNcclSum = 0;        // ncclFloat32, ncclSum (rccl.h)
+const VjfNccl& nccl() {
+    static VjfNccl n = [] {
+        VjfNccl v{};
+        void* h = RTLD_DEFAULT;
+        if (!dlsym(h, "ncclAllReduce")) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return v;
+        v.get_unique_id = (nccl_get_unique_id_t)dlsym(h, "ncclGetUniqueId");
+        v.comm_init_rank = (nccl_comm_init_rank_t)dlsym(h, "ncclCommInitRank");
+        v.comm_destroy = (nccl_comm_destroy_t)dlsym(h, "ncclCommDestroy");
+        v.all_reduce = (nccl_all_reduce_t)dlsym(h, "ncclAllReduce");
+        v.group_start = (nccl_group_t)dlsym(h, "ncclGroupStart");
+        v.group_end = (nccl_group_t)dlsym(h, "ncclGroupEnd");
+        v.err = (nccl_err_t)dlsym(h, "ncclGetErrorString");
+        v.ok = v.get_unique_id && v.comm_init_rank && v.comm_destroy && v.all_reduce && v.group_start && v.group_end;
+        return v;
+    }();
+    return n;
+}
+#define VJF_NCCL(call)                                                                           \
+    do {                                                                                         \
+        int e_ = (call);                                                                         \
+        if (e_ != 0) return fail(-110, "%s failed: %s", #call, nccl().err ? nccl().err(e_) : "rccl error"); \
     } while (0)
 
 constexpr size_t kMaxLds = 160 * 1024;
@@ -98,7 +140,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, work, jobs, aux, post, lscr, flags, total;
+    size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -113,7 +155,8 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.partial2 = take(((size_t)max_batch / 4 + 2) * RS_N * 4);
     c.slabs = take((size_t)njobs * split_for(max_batch) * 1024 * 4);
     c.red = take((size_t)P.red_len * 4);
-    c.red2 = take((size_t)P.red_len * 4);                  // odd steps' RLS statistics in the two-stream sequence
+    c.red2 = take((size_t)P.red_len * 4);                  // RLS statistics of even / odd steps in the multi-stream sequence
+    c.red3 = take((size_t)P.red_len * 4);
     c.work = take(vjf_serial_work_floats(P) * 4 + 256);   // + 32 u64 diagnostic stamps
     c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
     c.flags = take(256);                                   // column flags of the Cholesky -> post hand-off (a block of their own)
@@ -158,6 +201,8 @@ struct vjf_ctx {
     hipEvent_t ev_a, ev_s, ev_c;
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
     unsigned k1_count;     // workgroups of the matrix-core trial kernel (whole step or backward half) launched so far
+    void* comm_a; void* comm_b;   // RCCL communicators of the two chains of vjf_filter_seq (null: single rank)
+    int world;
 };
 
 extern "C" {
@@ -236,9 +281,11 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
     c->stream2 = c->stream3 = nullptr; c->ev_a = c->ev_s = c->ev_c = nullptr;
     c->epoch = 0; c->k1_count = 0;
+    c->comm_a = c->comm_b = nullptr; c->world = 1;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red2, 0, (size_t)P.red_len * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red3, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.flags, 0, 256, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs` (host) must outlive the copy
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
@@ -254,6 +301,12 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
 }
 
 int vjf_ctx_destroy(vjf_ctx* ctx) {
+    if (ctx && ctx->comm_a) {
+        if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3); }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)nccl().comm_destroy(ctx->comm_a); (void)nccl().comm_destroy(ctx->comm_b);
+        ctx->comm_a = ctx->comm_b = nullptr;
+    }
     if (ctx && ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3);
         (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_s); (void)hipEventDestroy(ctx->ev_c);
@@ -267,6 +320,30 @@ int vjf_set_overlap(vjf_ctx* ctx, int enable) {
     if (!ctx) return fail(-1, "vjf_set_overlap: null context");
     ctx->overlap = enable != 0 && ctx->fast_chol && ctx->post_kernels && ctx->mfma_trial;
     return ctx->overlap ? 1 : 0;
+}
+
+int vjf_comm_unique_id(void* ids256) {
+    if (!ids256) return fail(-1, "vjf_comm_unique_id: null output");
+    if (!nccl().ok) return fail(-111, "vjf_comm_unique_id: RCCL is not available in this process");
+    VJF_NCCL(nccl().get_unique_id((VjfNcclId*)ids256));
+    VJF_NCCL(nccl().get_unique_id((VjfNcclId*)ids256 + 1));
+    return 0;
+}
+
+int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world) {
+    if (!ctx || !ids256) return fail(-1, "vjf_comm_init: null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(-20, "vjf_comm_init: rank %d of %d", rank, world);
+    if (!nccl().ok) return fail(-111, "vjf_comm_init: RCCL is not available in this process");
+    if (ctx->comm_a) return fail(-112, "vjf_comm_init: the context already has communicators");
+    VJF_HIP(hipSetDevice(ctx->cfg.device));
+    VjfNcclId ids[2];
+    memcpy(ids, ids256, sizeof ids);
+    void* ca = nullptr; void* cb = nullptr;
+    VJF_NCCL(nccl().comm_init_rank(&ca, world, ids[0], rank));
+    int e = nccl().comm_init_rank(&cb, world, ids[1], rank);
+    if (e != 0) { (void)nccl().comm_destroy(ca); return fail(-110, "ncclCommInitRank failed: %s", nccl().err ? nccl().err(e) : "rccl error"); }
+    ctx->comm_a = ca; ctx->comm_b = cb; ctx->world = world;
+    return 0;
 }
 
 int vjf_set_stream(vjf_ctx* ctx, void* stream) {
@@ -481,7 +558,9 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     const VjfPlan& P = c->plan;
     const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
     hipStream_t sa = c->stream, sb = c->stream2, sc = c->stream3;
-    float* red[2] = {(float*)(c->ws + c->cv.red), (float*)(c->ws + c->cv.red2)};
+    float* redg = (float*)(c->ws + c->cv.red);                             // gradients + loss sums (chain A)
+    float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};   // RLS statistics of even / odd steps (chain B)
+    const int Bt = B * c->world;                                           // trials of all ranks
     auto args = [&](int t) {
         return trial_args(c, B, y + t * sy, u ? u + t * su : nullptr, t ? mu + (t - 1) * sz : mu0, t ? lv + (t - 1) * sz : lv0,
                           eps + (size_t)t * 2 * sz, eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags, t & 1);
@@ -495,7 +574,10 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     for (int t = 0; t < T; ++t) {
         // sb: RLS statistics of step t as soon as its forward half is done, then (behind W, sigma of t-1) P += G/v, g, Cholesky
         VJF_HIP(hipStreamWaitEvent(sb, c->ev_a, 0));
-        if ((rc = launch_gram(c, B, 0, ne, kScRls, red[t & 1], sb, nullptr, t & 1))) return rc;
+        if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, nullptr, t & 1))) return rc;
+        if (c->comm_b)                                                     // trials are sharded over ranks: sum [G | FDX | sums]
+            VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum,
+                                       c->comm_b, sb));
         if (t > 0) {
             VJF_HIP(hipStreamWaitEvent(sb, c->ev_s, 0));
             VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                   // backward half(t) <- W, w_chol, sigma of t-1
@@ -508,11 +590,19 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             hipLaunchKernelGGL(vjf_triclean_done_kernel, dim3(1), dim3(1), 0, sa, P, c->state);
             VJF_HIP(hipGetLastError());
         }
-        if ((rc = launch_prep(c, B, nullptr, flags, red[t & 1], 1, sb))) return rc;
+        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb))) return rc;
         // Cholesky on sb; the post kernel on sc beside it (it takes the columns of L as they appear)
-        if ((rc = launch_rls(c, B, flags, red[t & 1], sb, sc, c->ev_s, true))) return rc;
-        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, red[0], sa, nullptr, t & 1))) return rc;
-        if ((rc = launch_prep(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags, red[0], 2, sa))) return rc;
+        if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, c->ev_s, true))) return rc;
+        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1))) return rc;
+        if (c->comm_a) {                                                   // sum the gradients and the loss sums over ranks
+            VJF_NCCL(nccl().group_start());
+            int e1 = nccl().all_reduce(redg, redg, (size_t)P.train_len, kNcclFloat, kNcclSum, c->comm_a, sa);
+            int e2 = nccl().all_reduce(redg + P.red_SC, redg + P.red_SC, (size_t)RS_N, kNcclFloat, kNcclSum, c->comm_a, sa);
+            VJF_NCCL(nccl().group_end());
+            VJF_NCCL(e1);
+            VJF_NCCL(e2);
+        }
+        if ((rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa))) return rc;
         if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, c->ev_a))) return rc;
     }
     VJF_HIP(hipEventRecord(c->ev_c, sb));
@@ -559,6 +649,9 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
     if (!y || !eps || !mu || !lv) return fail(-1, "vjf_filter_seq: null tensor");
     if (c->overlap && !c->stamps && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP))
         return filter_seq_overlap(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
+    if (c->world > 1)
+        return fail(-24, "vjf_filter_seq: with communicators only the multi-stream schedule exists (update, no warm-up, T > 1, "
+                         "fast kernels); use vjf_filter_local / vjf_filter_global around your own all-reduce otherwise");
     const VjfPlan& P = c->plan;
     const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
     const float* ms = mu0; const float* ls = lv0;

@@ -337,10 +337,40 @@ class VJF(Module):
 
     @staticmethod
     def _world():
+        import os
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
-            return dist.get_world_size()
-        return 1
+            w = dist.get_world_size()
+            # VJF_FORCE_DIST=1: take the sharded path (local half -> all-reduce -> global half) even with one rank, so that it
+            # can be exercised on a single GPU
+            return (w, True) if (w > 1 or os.environ.get("VJF_FORCE_DIST") == "1") else (1, False)
+        return 1, False
+
+    def _native_comm(self, world) -> bool:
+        """RCCL communicators inside the context (collective over the ranks; once per context).  False -> the caller keeps
+        the all-reduce on its side (vjf_filter_local / torch.distributed.all_reduce / vjf_filter_global)."""
+        import os
+        import torch.distributed as dist
+        if getattr(self, "_comm_ctx", None) is self._ctx:
+            return self._comm_ok
+        self._comm_ctx, self._comm_ok = self._ctx, False
+        L = self._backend()
+        ids = (ctypes.c_char * 256)()
+        ok = (os.environ.get("VJF_NATIVE_RCCL", "1") != "0" and self._overlap_flag() and L.vjf_set_overlap(self._ctx, 1) == 1
+              and L.vjf_comm_unique_id(ids) == 0)
+        flag = torch.tensor([1 if ok else 0], device=self._blob.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # every rank takes the same route
+        if int(flag.item()) == 0:
+            return False
+        t = torch.frombuffer(bytearray(bytes(ids)), dtype=torch.uint8).to(self._blob.device)
+        dist.broadcast(t, src=0)
+        buf = (ctypes.c_char * 256).from_buffer_copy(t.cpu().numpy().tobytes())
+        N.check(L.vjf_comm_init(self._ctx, buf, dist.get_rank(), world), "vjf_comm_init")
+        self._comm_ok = True
+        return True
+
+    def _overlap_flag(self) -> bool:
+        return getattr(self, "_overlap", True)
 
     @staticmethod
     def _flags(sgd, update, warm_up):
@@ -444,8 +474,8 @@ class VJF(Module):
         loss4 = torch.empty(4, device=dev, dtype=torch.float32)
         flags = self._flags(sgd, update, warm_up)
         L.vjf_set_stream(self._ctx, stream_ptr())
-        world = self._world()
-        if world == 1:
+        world, sharded = self._world()
+        if not sharded:
             N.check(L.vjf_filter_step(self._ctx, B, N.ptr(y), N.ptr(u), N.ptr(mu_s), N.ptr(lv_s), N.ptr(eps_s), N.ptr(eps_t),
                                       N.ptr(mu_t), N.ptr(lv_t), N.ptr(loss4), flags), "vjf_filter_step")
         else:
@@ -494,8 +524,9 @@ class VJF(Module):
         loss = torch.empty(T, 4, device=dev, dtype=torch.float32)
         flags = self._flags(sgd, update, warm_up)
         L.vjf_set_stream(self._ctx, stream_ptr())
-        world = self._world()
-        if world == 1:
+        world, sharded = self._world()
+        if not sharded or (update and not warm_up and T > 1 and self._native_comm(world)):
+            # one C-ABI call for the whole sequence; with ranks, the library sums statistics and gradients over them itself
             N.check(L.vjf_filter_seq(self._ctx, T, B, N.ptr(y), N.ptr(u), N.ptr(eps), N.ptr(mu0), N.ptr(lv0), N.ptr(mu), N.ptr(lv),
                                      N.ptr(loss), flags), "vjf_filter_seq")
         else:
