@@ -201,6 +201,8 @@ struct vjf_ctx {
     hipEvent_t ev_a, ev_s, ev_c;
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
     unsigned k1_count;     // workgroups of the matrix-core trial kernel (whole step or backward half) launched so far
+    unsigned post_count;   // workgroups of the post kernel launched so far
+    unsigned fwd_count;    // workgroups of forward halves launched with a completion count
     void* comm_a; void* comm_b;   // RCCL communicators of the two chains of vjf_filter_seq (null: single rank)
     int world;
 };
@@ -280,7 +282,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
     c->stream2 = c->stream3 = nullptr; c->ev_a = c->ev_s = c->ev_c = nullptr;
-    c->epoch = 0; c->k1_count = 0;
+    c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
@@ -414,7 +416,7 @@ VjfTrialArgs trial_args(vjf_ctx* c, int32_t B, const float* y, const float* u, c
 int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16 : (B + c->TB - 1) / c->TB; }
 
 // K1.  part: 0 whole step, 1 forward half, 2 backward half (matrix-core kernel only)
-int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hipEvent_t stop = nullptr) {
+int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hipEvent_t stop = nullptr, bool count_fwd = false) {
     const VjfPlan& P = c->plan;
     const int nblk = trial_blocks(c, a.B);
     if (c->mfma_trial) {
@@ -422,6 +424,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
         m.t = a; m.aux = (const float*)(c->ws + c->cv.aux); m.part = part;
         m.done = (unsigned*)(c->ws + c->cv.flags) + 16;
         if (part != 1) c->k1_count += (unsigned)nblk;
+        if (part == 1 && count_fwd) { m.fwd_done = (unsigned*)(c->ws + c->cv.flags) + 48; c->fwd_count += (unsigned)nblk; }
         m.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
         VJF_LAUNCH(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, stop, P, m);
     } else {
@@ -509,6 +512,7 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
             pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.lscr = a.lscr;
             pa.flags = colflags; pa.epoch = a.epoch; pa.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
             pa.k1_done = c->mfma_trial ? colflags + 16 : nullptr; pa.k1_target = c->k1_count;
+            pa.done = colflags + 32; c->post_count += (unsigned)(2 * nbl + 1);
             pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
             VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st_post, stop, P, pa);
             VJF_HIP(hipGetLastError());
@@ -570,17 +574,25 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     rc = refresh_aux(c);
     if (rc) return rc;
     const int ne = c->n_ejobs, ng = c->njobs - ne;
-    if ((rc = launch_trial(c, args(0), 1, sa, c->ev_a))) return rc;        // prologue: forward half of step 0
+    unsigned* fdone = (unsigned*)(c->ws + c->cv.flags) + 48;
+    float* stw = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
+    if ((rc = launch_trial(c, args(0), 1, sa, nullptr, true))) return rc;   // prologue: forward half of step 0
     for (int t = 0; t < T; ++t) {
         // sb: RLS statistics of step t as soon as its forward half is done, then (behind W, sigma of t-1) P += G/v, g, Cholesky
-        VJF_HIP(hipStreamWaitEvent(sb, c->ev_a, 0));
+        //     (no cross-stream events inside the loop: a kernel carrying a completion signal holds up the next one of its own
+        //     stream by ~10 us on this stack; one-wavefront gate kernels wait on workgroup counters instead)
+        hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
         if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, nullptr, t & 1))) return rc;
         if (c->comm_b)                                                     // trials are sharded over ranks: sum [G | FDX | sums]
             VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum,
                                        c->comm_b, sb));
         if (t > 0) {
-            VJF_HIP(hipStreamWaitEvent(sb, c->ev_s, 0));
-            VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                   // backward half(t) <- W, w_chol, sigma of t-1
+            // backward half(t) and P += G/v, g (t) read W, w_chol, sigma of step t-1: a gate kernel on each stream ends when
+            // every workgroup of post(t-1) has its outputs in memory
+            unsigned* pdone = (unsigned*)(c->ws + c->cv.flags) + 32;
+            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)pdone, c->post_count, stw);
+            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sa, (const unsigned*)pdone, c->post_count, stw);
+            VJF_HIP(hipGetLastError());
         }
         if ((rc = launch_trial(c, args(t), 2, sa))) return rc;
         if (t == 0) {
@@ -592,7 +604,7 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         }
         if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb))) return rc;
         // Cholesky on sb; the post kernel on sc beside it (it takes the columns of L as they appear)
-        if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, c->ev_s, true))) return rc;
+        if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, t == T - 1 ? c->ev_s : nullptr, true))) return rc;
         if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1))) return rc;
         if (c->comm_a) {                                                   // sum the gradients and the loss sums over ranks
             VJF_NCCL(nccl().group_start());
@@ -603,7 +615,7 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             VJF_NCCL(e2);
         }
         if ((rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa))) return rc;
-        if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, c->ev_a))) return rc;
+        if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
     }
     VJF_HIP(hipEventRecord(c->ev_c, sb));
     VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                           // join: the caller's stream sees the final state

@@ -33,6 +33,8 @@ struct VjfPostArgs {
     float* status;          // the status scalar of the state blob (time-out of the wait below)
     const unsigned* k1_done;  // workgroups of the trial kernel that have finished reading W, w_chol, sigma (null: not needed);
     unsigned k1_target;       //   nothing of those is written before the count reaches k1_target
+    unsigned* done;           // += 1 per workgroup when its outputs (W, w_chol, sigma: write-through stores) are in memory:
+                              //   vjf_gate_kernel on another stream lets the readers of the next step start on it
     const float* red;       // reduce buffer (G, FDX, sum|dx|^2) of this step
     int B_total;
     int fold_sigma;         // 1: the y / W workgroup goes on to the state-noise update (no vjf_resid / vjf_sigma launch)
@@ -104,6 +106,11 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     float* s_y = s_x + (size_t)nbl * 32 * LX;                  // [32][17] the block just solved, for the eager updates
     int* s_tab = reinterpret_cast<int*>(s_y + 32 * LX);        // [32..64): lower tiles incl. diagonal -> (bi << 8) | bj
     int* s_ctl = s_tab + 64;
+    auto leave = [&]() {                                       // every workgroup, on every path, exactly once
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && A.done) __hip_atomic_fetch_add(A.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     const float* S = A.state;
     const float* Lm = A.lscr;
     const int j0 = solve ? 0 : (int)blockIdx.x >> 1;           // first block row of the substitution
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     VJF_POST_STAMP(18);
     if (bad == 2 && tid == 0) vjf_status_or(A.status, VJF_STATUS_RLS_FAILED);
     const bool failed = bad != 0;                              // factorisation failed: RLS state stays as it was
-    if (failed && !(solve && A.fold_sigma)) return;
+    if (failed && !(solve && A.fold_sigma)) { leave(); return; }
 
     if (!failed) {
         if (!solve) {
@@ -263,8 +270,10 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
             for (int c = wave; c < 16; c += VJF_POST_THREADS / 64) {
                 const int gc = j0 * 32 + c0 + c;
                 if (gc >= n) continue;
-                for (int i = first + lane; i < n; i += 64) Wc[(size_t)gc * n + i] = s_x[i * LX + c];
+                for (int i = first + lane; i < n; i += 64)
+                    __hip_atomic_store(Wc + (size_t)gc * n + i, s_x[i * LX + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1
             }
+            leave();
             return;
         }
         // ---- backward  W_k = Dinv_k^T R_k ;  R_i -= L_ki^T W_k  (i < k),   k = nbl-1 .. 0   (module.py:101)
@@ -297,10 +306,10 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         float* Wm = A.state + P.off[VJF_SLOT_W_MEAN];
         for (int e = tid; e < n * 16; e += VJF_POST_THREADS) {
             const int r = e >> 4, c = e & 15;
-            if (c < dz) Wm[r * dz + c] = s_x[r * LX + c];
+            if (c < dz) __hip_atomic_store(Wm + r * dz + c, s_x[r * LX + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1
         }
     }   // !failed
-    if (!A.fold_sigma) return;
+    if (!A.fold_sigma) { leave(); return; }
     // ---- state-noise update on the new W (model.py:373-377):  q = sum|dx|^2 - 2 tr(W^T FDX) + tr(W^T G W)  over the batch.
     //      tr(W^T G W) = sum_ij G_ij (W W^T)_ij: wavefront w forms the lower 32x32 tiles t = w, w + 8, .. of W W^T on the
     //      f32 matrix cores and contracts them with the tiles of G it prefetched at kernel start (fp64 sums, fixed order).
@@ -363,12 +372,27 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
             float* St = A.state;
             float* SC = St + P.off[VJF_SLOT_SCALARS];
             const float mse = (float)(t * pre_scale);
-            St[P.off[VJF_SLOT_TR_LOGVAR]] = logf(pre_old + ((float)A.B_total / pre_tot) * mse);
-            SC[VJF_SC_N_TR] = pre_tot;
+            __hip_atomic_store(St + P.off[VJF_SLOT_TR_LOGVAR], logf(pre_old + ((float)A.B_total / pre_tot) * mse), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(SC + VJF_SC_N_TR, pre_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (failed) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
         }
         VJF_POST_STAMP(21);
     }
+    leave();
+}
+
+// One wavefront that ends when `*count` has reached `target` (bounded): the next kernel of its stream then starts behind the
+// producers on another stream without a cross-stream event (6-13 us on this stack).  It holds no LDS and one wave slot, so
+// it cannot keep the single-workgroup chain kernels (which need a whole CU's LDS) from being placed.
+__global__ __launch_bounds__(64) void vjf_gate_kernel(const unsigned* count, unsigned target, float* status) {
+    if (threadIdx.x != 0) return;
+    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+        const unsigned v = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - target) >= 0) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    vjf_status_or(status, VJF_STATUS_RLS_FAILED);
 }
 
 struct VjfResidArgs {

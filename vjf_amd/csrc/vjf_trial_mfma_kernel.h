@@ -73,6 +73,8 @@ struct VjfTrialMfmaArgs {
     unsigned long long* stamps;   // diagnostic only (null in normal runs)
     unsigned* done;        // += 1 per workgroup once it has read W, w_chol, sigma for the last time (null: not counted):
                            //   the post kernel, on another stream, waits for the count before it overwrites them
+    unsigned* fwd_done;    // forward half: += 1 per workgroup once its E / ACT rows and posterior are written back to memory
+                           //   (release at agent scope): the statistics Gram on another stream starts behind vjf_gate_kernel on it
     int part;              // 0: whole step; 1: forward half (features, recognition, E / ACT rows, posterior);
                            // 2: backward half (predictive mean / variance, losses, backward, DEL rows) -- reloads the
                            //    forward half's rows, so that it can run after the RLS update of the previous step while
@@ -486,6 +488,18 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     VJF_K1_STAMP(30);
     if (AA.done && bwd && tid == 0) __hip_atomic_fetch_add(AA.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (AA.fwd_done && !bwd) {
+        // producer side of a hand-off between launches on different streams (MI355X guide, visibility, valid forms): every
+        // storing wavefront drains its stores, the workgroup barrier, one lane releases at agent scope (L2 write-back),
+        // drains again, then the relaxed agent-scope signal
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(AA.fwd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Refresh the transposed weight copies from the canonical tensors (run at the start of an API call:
