@@ -208,6 +208,18 @@ def main():
             traffic = float(json.load(open(TRAFFIC_FILE))["bytes_per_step_corrected"])
         except Exception:
             pass
+        kstats = None
+        try:                                                    # per-kernel averages of the committed rocprofv3 --stats run of this build
+            import csv
+            ks = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_kernel_stats.csv")))
+            rows = list(csv.DictReader(open(ks[-1])))
+            steps_in_profile = max(int(r["Calls"]) for r in rows if "chol" in r["Name"] or "serial" in r["Name"])
+            kstats = {"file": "profiles/" + os.path.basename(ks[-1]),
+                      "kernels": [{"name": r["Name"].split("(")[0].replace("void ", ""), "avg_us": float(r["AverageNs"]) / 1e3,
+                                   "launches_per_step": round(int(r["Calls"]) / steps_in_profile, 2)}
+                                  for r in rows if int(r["Calls"]) >= steps_in_profile]}
+        except Exception:
+            pass
         out = {
             "metric": "trial-timesteps/sec", "value": value, "unit": "trial-timesteps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": wall_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -225,6 +237,7 @@ def main():
                                    "vjf_gram_reduce_kernel x2, vjf_prep_kernel x2, vjf_chol_lds_kernel, vjf_rls_post_kernel on three "
                                    "streams (HIP events around the timed region / steps)",
                          "flops_per_trial_step": flops, "serial_flops_per_step": serial_flops,
+                         "rocprof_kernel_averages": kstats,
                          "step_us": step_s * 1e6, "host_enqueue_us_per_step": enq / K * 1e6, "trial_half_us": loc, "serial_half_us": glob,
                          "hbm_achieved_GBs": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
                          "bytes_per_trial_step": b_trial + b_shared / c["B"]},

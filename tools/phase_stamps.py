@@ -6,10 +6,11 @@ from vjf_amd import _native as N
 torch.manual_seed(0)
 B, dz, dy, n = 4096, 10, 50, 200
 m = vjf_amd.VJF.make_model(dy, dz, 0, n, [128], likelihood="gaussian", noise="device")
-y = torch.randn(8, B, dy, device="cuda"); 
-m.filter_sequence(y[:4])
-N.check(m._backend().vjf_debug_stamps(m._ctx, 1, None))
-m.filter_sequence(y[4:])
+y = torch.randn(16, B, dy, device="cuda"); 
+m.filter_sequence(y[:8])
+MODE = 2 if len(sys.argv) > 1 and sys.argv[1] == 'overlap' else 1
+N.check(m._backend().vjf_debug_stamps(m._ctx, MODE, None))
+m.filter_sequence(y[8:])
 out = (ctypes.c_uint64 * 32)()
 N.check(m._backend().vjf_debug_stamps(m._ctx, 0, out))
 t = list(out)[:9]

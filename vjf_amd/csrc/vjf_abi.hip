@@ -193,6 +193,7 @@ struct vjf_ctx {
     bool mfma_trial;       // 16 trials' working set fits LDS: matrix-core trial kernel
     size_t lds_k1m;
     bool stamps;           // diagnostic: record s_memtime phase stamps in the serial kernel
+    bool stamps_keep_overlap;   // ... without forcing vjf_filter_seq into the one-stream order (enable = 2)
     bool fast_chol;        // n_rbf <= 224: prep kernel + LDS-resident MFMA Cholesky; else the generic serial kernel
     size_t lds_chol;
     int n_ejobs;           // jobs [0, n_ejobs) are the E^T E tiles, the rest gradient tiles
@@ -269,7 +270,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->cfg = *cfg; c->plan = P; c->state = state; c->ws = (char*)workspace; c->ws_bytes = workspace_bytes;
     c->stream = (hipStream_t)stream; c->cv = cv; c->njobs = (int)jobs.size(); c->TB = TB;
     c->lds_k1 = vjf_trial_lds_floats(P, TB) * 4; c->lds_k2 = lds_k2;
-    c->fast_chol = fast_chol; c->lds_chol = vjf_chol_lds_bytes(P); c->stamps = false;
+    c->fast_chol = fast_chol; c->lds_chol = vjf_chol_lds_bytes(P); c->stamps = false; c->stamps_keep_overlap = false;
     c->lds_post = vjf_post_lds_bytes(P);
     c->post_kernels = fast_chol && P.dz <= 16 && c->lds_post <= kMaxLds - 1024;
     // the single-workgroup chain kernels ask for the whole LDS of their compute unit: nothing else (every other kernel of
@@ -368,6 +369,7 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status) {
 int vjf_debug_stamps(vjf_ctx* ctx, int enable, uint64_t* out32) {
     if (!ctx) return fail(-1, "vjf_debug_stamps: null context");
     ctx->stamps = enable != 0;
+    ctx->stamps_keep_overlap = enable == 2;
     if (out32) {
         VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.work + vjf_serial_work_floats(ctx->plan) * 4, 256, hipMemcpyDeviceToHost, ctx->stream));
         VJF_HIP(hipStreamSynchronize(ctx->stream));
@@ -659,7 +661,7 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
     if (!c) return fail(-1, "vjf_filter_seq: null context");
     if (T < 1) return fail(-23, "vjf_filter_seq: T=%d", T);
     if (!y || !eps || !mu || !lv) return fail(-1, "vjf_filter_seq: null tensor");
-    if (c->overlap && !c->stamps && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP))
+    if (c->overlap && (!c->stamps || c->stamps_keep_overlap) && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP))
         return filter_seq_overlap(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
     if (c->world > 1)
         return fail(-24, "vjf_filter_seq: with communicators only the multi-stream schedule exists (update, no warm-up, T > 1, "

@@ -579,10 +579,12 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                 } else if (wave == 4) {
                     // (wavefront 4 shares wavefront 0's SIMD: it keeps off the matrix core while the chain runs there)
                     if (A.post) {
-                        // column k of L and Dinv_k are final: out they go beside the next chain
+                        // column k of L and Dinv_k are final: out they go beside the next chain.  Their flag follows one phase
+                        // later, when the write-through stores have long drained: this wavefront never holds up the phase barrier
+                        if (k > 0) publish(k - 1, k, 0u);
                         for (int it = 0; it < nbl - k; ++it) put_block(s_blk + (size_t)vtri(k + it, k) * 1024, A.lscr, n, (k + it) * 32, k * 32, it == 0);
                         put_block(s_aux + (size_t)k * 1024, A.dinv_out + (size_t)k * 1024, 32, 0, 0, false);
-                        publish(k, k + 1, 0u);
+                        if (k == nbl - 1) publish(k, k + 1, 0u);
                     }
                 } else {
                     for (int t = 1 + (wave < 4 ? wave - 1 : wave - 2); t < nt; t += VJF_CHOL_THREADS / 64 - 2) trail(k, t);
@@ -602,7 +604,10 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
             for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) Pm[e] = Pm[e] - G[e] * inv_v;
             if (A.post) {
                 // columns published so far are those of iterations that completed; every other flag says "failed"
-                if (wave == 4) publish(kdone, VJF_CHOL_MAXBLK + 1, 1u);
+                if (wave == 4) {
+                    if (kdone > 0) publish(kdone - 1, kdone, 0u);      // (stored in the last completed phase, flag still due)
+                    publish(kdone, VJF_CHOL_MAXBLK + 1, 1u);
+                }
                 if (tid == 0) { A.ok_out[0] = 0; vjf_status_or(SC + VJF_SC_STATUS, st); }
                 return;
             }
