@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown-steps", type=int, default=20)
     ap.add_argument("--no-overlap", action="store_true", help="one-stream order inside filter_sequence (A/B of the schedule)")
+    ap.add_argument("--serial-schedule", action="store_true",
+                    help="the multi-stream schedule's kernels on ONE stream: use under rocprofv3 --pmc, which serialises kernels")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1 only: run the sharded path (local half, RCCL all-reduce, global half) with a one-rank group")
     a = ap.parse_args()
@@ -142,6 +144,8 @@ def main():
     model = vjf_amd.VJF.make_model(c["dy"], c["dz"], c["du"], c["n"], c["hidden"], likelihood=c["lik"], noise="device")
     if a.no_overlap:
         model.set_overlap(False)
+    if a.serial_schedule:
+        model.set_overlap(2)
     y = synth_data(c, T, 1234 + rank, dev)                      # each rank filters its own trials
     eps = torch.randn(T, 2, c["B"], c["dz"], device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + rank))
 

@@ -116,7 +116,9 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status);
 
 /* vjf_filter_seq runs the RLS chain of a step on a second (internal, non-blocking) stream beside the trial / SGD
  * chain when the fast kernels apply (default on; results are bit-identical either way).  enable = 0 forces the
- * one-stream order.  Returns the resulting setting (1 / 0), or a negative error code. */
+ * one-stream order; enable = 2 keeps the multi-stream schedule's kernels and hand-offs but enqueues them on the caller's
+ * stream alone -- for tools that serialise kernels (rocprofv3 --pmc): a kernel that waits in-kernel for one that the tool has
+ * not let run yet would only time out.  Returns the resulting setting (2 / 1 / 0), or a negative error code. */
 int vjf_set_overlap(vjf_ctx* ctx, int enable);
 
 /* Trials sharded over ranks, one process per GPU: with communicators attached, vjf_filter_seq sums the RLS statistics and

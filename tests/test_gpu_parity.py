@@ -146,17 +146,21 @@ def test_filter_sequence_two_stream_equals_one_stream(vjf):
     load_fixture_state(m1, z, "s0")
     load_fixture_state(m2, z, "s0")
     m2.set_overlap(False)
+    m3 = _model_for(vjf, info)                 # the multi-stream schedule's kernels on one stream (profiler mode)
+    load_fixture_state(m3, z, "s0")
+    m3.set_overlap(2)
     u = torch.tensor(z["u"]) if info["du"] else None
     for rep in range(2):                       # second call: starts from a posterior, TRI_CLEAN already set
-        q1 = q2 = None
+        q1 = q2 = q3 = None
         if rep:
-            q1, q2 = vjf.Gaussian(o1[0][-1], o1[1][-1]), vjf.Gaussian(o2[0][-1], o2[1][-1])
+            q1, q2, q3 = (vjf.Gaussian(o[0][-1], o[1][-1]) for o in (o1, o2, o3))
         o1 = m1.filter_sequence(torch.tensor(z["y"]), u, q1, eps=torch.tensor(z["eps"]))
         o2 = m2.filter_sequence(torch.tensor(z["y"]), u, q2, eps=torch.tensor(z["eps"]))
-        for a, b in zip(o1, o2):
-            assert torch.equal(a, b)
-        assert torch.equal(m1._blob, m2._blob)
-    assert m1.status() == 0 and m2.status() == 0
+        o3 = m3.filter_sequence(torch.tensor(z["y"]), u, q3, eps=torch.tensor(z["eps"]))
+        for a, b, c in zip(o1, o2, o3):
+            assert torch.equal(a, b) and torch.equal(a, c)
+        assert torch.equal(m1._blob, m2._blob) and torch.equal(m1._blob, m3._blob)
+    assert m1.status() == 0 and m2.status() == 0 and m3.status() == 0
 
 
 def test_seeded_drop_in(vjf):

@@ -2,12 +2,13 @@
 # HBM traffic per filter step from the L2 fabric counters (MI355X_MICROARCH.md §HBM):
 # two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only; FETCH_SIZE is doubled
 # (gfx950 reports half the bytes of wide coalesced reads), WRITE_SIZE is taken as is.  Units: KB.
+# --pmc serialises kernels: the run uses --serial-schedule (the pipelined schedule's kernels, one stream).
 set -o pipefail
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --breakdown-steps 0 > gpurun_out/pmc_$c.json 2> gpurun_out/pmc_$c.err
+  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --breakdown-steps 0 --serial-schedule > gpurun_out/pmc_$c.json 2> gpurun_out/pmc_$c.err
   echo "pmc $c exit $?"
 done
 python - <<'PY'

@@ -198,6 +198,7 @@ struct vjf_ctx {
     size_t lds_chol;
     int n_ejobs;           // jobs [0, n_ejobs) are the E^T E tiles, the rest gradient tiles
     bool overlap;          // vjf_filter_seq: RLS chain on a second stream beside the trial / SGD chain
+    bool overlap_serial;   // ... same kernels and hand-offs, but enqueued on ONE stream (profilers that serialise kernels)
     hipStream_t stream2, stream3;
     hipEvent_t ev_a, ev_s, ev_c;
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
@@ -282,6 +283,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->n_ejobs = 0;
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
+    c->overlap_serial = false;
     c->stream2 = c->stream3 = nullptr; c->ev_a = c->ev_s = c->ev_c = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1;
@@ -295,6 +297,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     allow_lds(vjf_trial_kernel<16>, c->lds_k1); allow_lds(vjf_trial_kernel<8>, c->lds_k1); allow_lds(vjf_trial_kernel<4>, c->lds_k1);
     allow_lds(vjf_serial_kernel, c->lds_k2);
     allow_lds(vjf_rls_post_kernel, c->lds_post);
+    allow_lds(vjf_prepg_kernel, vjf_prepg_lds_bytes(P));
     if (c->mfma_trial) allow_lds(vjf_trial_mfma_kernel, c->lds_k1m);
     allow_lds(vjf_chol_lds_kernel<4>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<8>, c->lds_chol);
     allow_lds(vjf_chol_lds_kernel<12>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<16>, c->lds_chol);
@@ -322,7 +325,8 @@ int vjf_ctx_destroy(vjf_ctx* ctx) {
 int vjf_set_overlap(vjf_ctx* ctx, int enable) {
     if (!ctx) return fail(-1, "vjf_set_overlap: null context");
     ctx->overlap = enable != 0 && ctx->fast_chol && ctx->post_kernels && ctx->mfma_trial;
-    return ctx->overlap ? 1 : 0;
+    ctx->overlap_serial = ctx->overlap && enable == 2;
+    return ctx->overlap ? (ctx->overlap_serial ? 2 : 1) : 0;
 }
 
 int vjf_comm_unique_id(void* ids256) {
@@ -471,9 +475,14 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
     p.loss4 = loss4; p.B_total = B_total; p.flags = flags;
     p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
     p.n_sgdblk = (P.train_len + 1023) / 1024;
-    p.bid0 = which == 2 ? p.n_rowblk : 0;
-    const int grid = which == 0 ? p.n_rowblk + p.n_sgdblk + 1 : which == 1 ? p.n_rowblk : p.n_sgdblk + 1;
-    VJF_LAUNCH(vjf_prep_kernel, dim3(grid), dim3(256), 0, st, stop, P, p);
+    if (which != 2) {                                          // RLS operands: g and P += G/v, 16 rows per workgroup
+        const size_t lds = vjf_prepg_lds_bytes(P);
+        VJF_LAUNCH(vjf_prepg_kernel, dim3((P.n + 15) / 16), dim3(256), lds, st, which == 1 ? stop : (hipEvent_t) nullptr, P, p);
+        VJF_HIP(hipGetLastError());
+        if (which == 1) return 0;
+    }
+    p.bid0 = p.n_rowblk;                                       // clip + SGD and the scalars
+    VJF_LAUNCH(vjf_prep_kernel, dim3(p.n_sgdblk + 1), dim3(256), 0, st, stop, P, p);
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -563,7 +572,8 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     if (rc) return rc;
     const VjfPlan& P = c->plan;
     const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
-    hipStream_t sa = c->stream, sb = c->stream2, sc = c->stream3;
+    // (overlap_serial: the three chains share the caller's stream; every wait below is then satisfied when it is reached)
+    hipStream_t sa = c->stream, sb = c->overlap_serial ? sa : c->stream2, sc = c->overlap_serial ? sa : c->stream3;
     float* redg = (float*)(c->ws + c->cv.red);                             // gradients + loss sums (chain A)
     float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};   // RLS statistics of even / odd steps (chain B)
     const int Bt = B * c->world;                                           // trials of all ranks

@@ -128,6 +128,80 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
+// RLS operands, 16 rows of P per workgroup (replaces the row part of vjf_prep_kernel on the fast path):
+//   g[i][:] = sum_k P[i][k] W[k][:] + (Phi^T dx)[i][:] / v     (module.py:94)   on v_mfma_f32_16x16x4_f32, K split over 4 wavefronts
+//   P[i][:] += (Phi^T Phi)[i][:] / v                            (module.py:96)   on the rows just read
+// grid = ceil(n / 16) workgroups of 256 threads; n % 4 == 0.
+#define VJF_PREPG_LDP(n) ((n) + 4)
+static inline size_t vjf_prepg_lds_bytes(const VjfPlan& P) { return ((size_t)16 * VJF_PREPG_LDP(P.n) + (size_t)P.n * 17 + 4 * 16 * 17) * 4; }
+
+__global__ __launch_bounds__(256) void vjf_prepg_kernel(VjfPlan P, VjfPrepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned do_upd = A.flags & VJF_FLAG_UPDATE, warm = A.flags & VJF_FLAG_WARM_UP;
+    if (!do_upd || warm) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = P.n, dz = P.dz, i0 = blockIdx.x * 16, ldp = VJF_PREPG_LDP(n);
+    float* s_p = lds;                                  // [16][n + 4]  rows of P before the update
+    float* s_w = s_p + 16 * ldp;                       // [n][17]      W, columns dz..15 zero
+    float* s_r = s_w + (size_t)n * 17;                 // [4][16][17]  per-wavefront partial products
+    float* S = A.state;
+    const float inv_v = expf(-S[P.off[VJF_SLOT_TR_LOGVAR]]);
+    float* Pm = S + P.off[VJF_SLOT_W_PREC];
+    const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
+    const float* G = A.red + P.red_G;
+    const float* FDX = A.red + P.red_FDX;
+    const int n4 = n >> 2;
+    for (int e0 = tid; e0 < 16 * n4; e0 += 4 * 256) {  // 4 float4 of P and of G in flight per thread
+        float4 p[4], g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * 256, row = e / n4, c4 = (e - row * n4) * 4;
+            const bool in = e < 16 * n4 && i0 + row < n;
+            const size_t off = in ? (size_t)(i0 + row) * n + c4 : 0;
+            p[q] = *reinterpret_cast<const float4*>(Pm + off);
+            g[q] = *reinterpret_cast<const float4*>(G + off);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * 256, row = e / n4, c4 = (e - row * n4) * 4;
+            if (e >= 16 * n4) continue;
+            const bool in = i0 + row < n;
+            float* d = s_p + row * ldp + c4;
+            d[0] = in ? p[q].x : 0.f; d[1] = in ? p[q].y : 0.f; d[2] = in ? p[q].z : 0.f; d[3] = in ? p[q].w : 0.f;
+            if (in) {
+                float4 o;
+                o.x = p[q].x + g[q].x * inv_v; o.y = p[q].y + g[q].y * inv_v; o.z = p[q].z + g[q].z * inv_v; o.w = p[q].w + g[q].w * inv_v;
+                *reinterpret_cast<float4*>(Pm + (size_t)(i0 + row) * n + c4) = o;
+            }
+        }
+    }
+    for (int e = tid; e < n * 16; e += 256) {
+        const int k = e >> 4, c = e & 15;
+        s_w[k * 17 + c] = c < dz ? Wm[(size_t)k * dz + c] : 0.f;
+    }
+    __syncthreads();
+    {
+        const int i = lane & 15, kk = lane >> 4;
+        vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s4 = wave; s4 < n4; s4 += 4) {        // k-step s4 covers k = 4 s4 .. 4 s4 + 3
+            const float a = s_p[i * ldp + 4 * s4 + kk];
+            const float b = s_w[(4 * s4 + kk) * 17 + i];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_r[(wave * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] = acc[r];   // row 4(lane>>4)+r, column lane&15
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * 16; e += 256) {
+        const int r = e >> 4, c = e & 15;
+        if (c < dz && i0 + r < n) {
+            const float v = ((s_r[r * 17 + c] + s_r[(16 + r) * 17 + c]) + s_r[(32 + r) * 17 + c]) + s_r[(48 + r) * 17 + c];
+            A.gbuf[(size_t)(i0 + r) * dz + c] = v + FDX[(size_t)(i0 + r) * dz + c] * inv_v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS block helpers.  A 32x32 block is 1024 floats; element (r,c) sits at r*32 + (c ^ r), which
 // makes row reads, column reads and the MFMA operand reads bank-conflict free.
 __device__ __forceinline__ int vsw(int r, int c) { return r * 32 + (c ^ r); }

@@ -118,7 +118,7 @@ static inline int vjf_make_plan(const vjf_config* c, VjfPlan* p) {
     p->colD_dlv = col; col += p->dz;
     p->colD_dpy = col; col += p->dy;
     p->ldD = (int)vjf_align(col, 4);
-    int64_t r = p->train_len;
+    int64_t r = vjf_align(p->train_len, 4);            // (G is read as float4)
     p->red_G = (int)r; r += (int64_t)p->n * p->n;
     p->red_FDX = (int)r; r = vjf_align(r + (int64_t)p->n * p->dz, 4);
     p->red_SC = (int)r; r += RS_N;

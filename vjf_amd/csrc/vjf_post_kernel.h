@@ -16,6 +16,8 @@
 #include "vjf_chol_kernel.h"         // VJF_CHOL_MAXBLK, vjf_f32x16
 #include "vjf_trial_mfma_kernel.h"   // vjf_f32x4
 
+// bound of every in-kernel wait (each poll is an L2 round trip + s_sleep: ~0.5 s in all); time-out -> status bit, never a hang
+#define VJF_SPIN_LIMIT (1u << 19)
 #define VJF_POST_THREADS 512
 #define VJF_POST_KPAR 4                // wavefronts = 2 row tiles x 4 interleaved block sums
 #define VJF_POST_LDB 33               // padded leading dimension of a 32x32 block in LDS
@@ -79,7 +81,7 @@ __device__ __forceinline__ void post_mma32(vjf_f32x4& acc, const float* Bs, int 
 __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned epoch, int k, int* s_ctl, int tid) {
     if (tid == 0) {
         int st = 2;
-        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+        for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
             const unsigned v = __hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((v >> 1) == epoch) { st = (int)(v & 1u); break; }
             __builtin_amdgcn_s_sleep(4);
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     if (A.k1_done) {                                           // readers of W, w_chol, sigma on another stream: all done?
         if (tid == 0) {
             int st = 2;
-            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+            for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
                 const unsigned v = __hip_atomic_load(A.k1_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int)(v - A.k1_target) >= 0) { st = 0; break; }
                 __builtin_amdgcn_s_sleep(4);
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
 // it cannot keep the single-workgroup chain kernels (which need a whole CU's LDS) from being placed.
 __global__ __launch_bounds__(64) void vjf_gate_kernel(const unsigned* count, unsigned target, float* status) {
     if (threadIdx.x != 0) return;
-    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+    for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
         const unsigned v = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(v - target) >= 0) return;
         __builtin_amdgcn_s_sleep(2);

@@ -285,9 +285,11 @@ class VJF(Module):
     def set_overlap(self, enable: bool = True):
         """filter_sequence runs a step's RLS chain on a second stream beside the trial / SGD chain (default);
         False forces the one-stream order.  Results are bit-identical either way."""
-        self._overlap = bool(enable)
+        self._overlap = int(enable) if enable in (0, 1, 2, True, False) else 1     # 2: same schedule on one stream (profilers)
         if self._ctx is not None:
-            N.check(self._backend().vjf_set_overlap(self._ctx, int(self._overlap)), "vjf_set_overlap")
+            rc = self._backend().vjf_set_overlap(self._ctx, int(self._overlap))       # returns the resulting setting
+            if rc < 0:
+                N.check(rc, "vjf_set_overlap")
 
     def status(self) -> int:
         """Sticky VJF_STATUS_* bits raised by the device since the last call (clears them)."""
@@ -313,8 +315,10 @@ class VJF(Module):
         N.check(L.vjf_ctx_create(ctypes.byref(cfg), N.ptr(self._blob), N.ptr(self._workspace), nbytes.value, stream_ptr(),
                                  ctypes.byref(ctx)), "vjf_ctx_create")
         self._ctx, self._ctx_batch = ctx, B
-        if not getattr(self, "_overlap", True):
-            N.check(L.vjf_set_overlap(ctx, 0), "vjf_set_overlap")
+        if getattr(self, "_overlap", 1) != 1:
+            rc = L.vjf_set_overlap(ctx, int(self._overlap))
+            if rc < 0:
+                N.check(rc, "vjf_set_overlap")
         p, n = ctypes.c_void_p(), ctypes.c_int64()
         N.check(L.vjf_reduce_buffer(ctx, ctypes.byref(p), ctypes.byref(n)), "vjf_reduce_buffer")
         o = p.value - self._workspace.data_ptr()
@@ -356,7 +360,7 @@ class VJF(Module):
         self._comm_ctx, self._comm_ok = self._ctx, False
         L = self._backend()
         ids = (ctypes.c_char * 256)()
-        ok = (os.environ.get("VJF_NATIVE_RCCL", "1") != "0" and self._overlap_flag() and L.vjf_set_overlap(self._ctx, 1) == 1
+        ok = (os.environ.get("VJF_NATIVE_RCCL", "1") != "0" and self._overlap_flag() and L.vjf_set_overlap(self._ctx, int(getattr(self, "_overlap", 1))) >= 1
               and L.vjf_comm_unique_id(ids) == 0)
         flag = torch.tensor([1 if ok else 0], device=self._blob.device, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # every rank takes the same route
@@ -370,7 +374,7 @@ class VJF(Module):
         return True
 
     def _overlap_flag(self) -> bool:
-        return getattr(self, "_overlap", True)
+        return bool(getattr(self, "_overlap", 1))
 
     @staticmethod
     def _flags(sgd, update, warm_up):
