@@ -588,10 +588,11 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
                     blk[vsw(r, c4)] = v[q].x; blk[vsw(r, c4 + 1)] = v[q].y; blk[vsw(r, c4 + 2)] = v[q].z; blk[vsw(r, c4 + 3)] = v[q].w;
                 }
             }
-            for (int e = t2; e < npad * DZP; e += NT) {
-                const int r = e / DZP, j = e - r * DZP;
-                s_g[e] = (r < n && j < dz) ? A.gbuf[(size_t)r * dz + j] : 0.f;
-            }
+            if (!A.post)                                                // (post mode: g goes to vjf_rls_post_kernel, not here)
+                for (int e = t2; e < npad * DZP; e += NT) {
+                    const int r = e / DZP, j = e - r * DZP;
+                    s_g[e] = (r < n && j < dz) ? A.gbuf[(size_t)r * dz + j] : 0.f;
+                }
         }
         __syncthreads();
         VJF_STAMP(1);
