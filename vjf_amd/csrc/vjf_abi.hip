@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -198,6 +199,10 @@ struct vjf_ctx {
     size_t lds_chol;
     int n_ejobs;           // jobs [0, n_ejobs) are the E^T E tiles, the rest gradient tiles
     bool overlap;          // vjf_filter_seq: RLS chain on a second stream beside the trial / SGD chain
+    bool gate_post;        // experiment: hold the post kernel back until the Cholesky kernel runs (frees 15 CUs for the trial kernel,
+                           // but then the post kernel cannot be placed before the trial kernel has drained: measured slower)
+    bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
+                           // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
     bool overlap_serial;   // ... same kernels and hand-offs, but enqueued on ONE stream (profilers that serialise kernels)
     hipStream_t stream2, stream3;
     hipEvent_t ev_a, ev_s, ev_c;
@@ -283,7 +288,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->n_ejobs = 0;
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
-    c->overlap_serial = false;
+    c->overlap_serial = false; c->gate_post = getenv("VJF_GATE_POST") != nullptr; c->sb_gates = getenv("VJF_SB_INKERNEL_WAIT") == nullptr;
     c->stream2 = c->stream3 = nullptr; c->ev_a = c->ev_s = c->ev_c = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1;
@@ -446,7 +451,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
 
 // Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
 int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, hipEvent_t stop = nullptr,
-                int gen = 0) {
+                int gen = 0, const unsigned* wait_count = nullptr, unsigned wait_target = 0) {
     const VjfPlan& P = c->plan;
     const int nsplit = split_for(B);
     VjfGramArgs g{};
@@ -454,6 +459,7 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     g.E = (const float*)(c->ws + (gen ? c->cv.E2 : c->cv.E)); g.ACT = (const float*)(c->ws + c->cv.ACT); g.DEL = (const float*)(c->ws + c->cv.DEL);
     g.slabs = (float*)(c->ws + c->cv.slabs);
     g.B = B; g.nsplit = nsplit; g.job0 = job0;
+    g.wait_count = wait_count; g.wait_target = wait_target; g.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
     hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(256), 0, st, P, g);
     VJF_HIP(hipGetLastError());
@@ -467,7 +473,7 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
 
 // which: 0 whole prep grid, 1 RLS operand rows only, 2 SGD + scalars only
 int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const float* red, int which, hipStream_t st,
-                hipEvent_t stop = nullptr) {
+                hipEvent_t stop = nullptr, const unsigned* wait_count = nullptr, unsigned wait_target = 0) {
     const VjfPlan& P = c->plan;
     VjfPrepArgs p{};
     p.state = c->state; p.red = red; p.gbuf = (float*)(c->ws + c->cv.work);
@@ -475,6 +481,7 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
     p.loss4 = loss4; p.B_total = B_total; p.flags = flags;
     p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
     p.n_sgdblk = (P.train_len + 1023) / 1024;
+    p.wait_count = wait_count; p.wait_target = wait_target;
     if (which != 2) {                                          // RLS operands: g and P += G/v, 16 rows per workgroup
         const size_t lds = vjf_prepg_lds_bytes(P);
         VJF_LAUNCH(vjf_prepg_kernel, dim3((P.n + 15) / 16), dim3(256), lds, st, which == 1 ? stop : (hipEvent_t) nullptr, P, p);
@@ -517,6 +524,11 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
     VJF_HIP(hipGetLastError());
     if (c->post_kernels) {
         const bool rls = !(flags & VJF_FLAG_WARM_UP);
+        if (rls && st_post != st && c->gate_post) {            // (see the Cholesky kernel's "running" word)
+            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, st_post, (const unsigned*)(colflags + VJF_CHOL_MAXBLK + 2), a.epoch,
+                               c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS);
+            VJF_HIP(hipGetLastError());
+        }
         if (rls) {
             // inverse column halves + the y / W workgroup, which also carries the state-noise update
             VjfPostArgs pa{};
@@ -590,11 +602,12 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     float* stw = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     if ((rc = launch_trial(c, args(0), 1, sa, nullptr, true))) return rc;   // prologue: forward half of step 0
     for (int t = 0; t < T; ++t) {
+        const unsigned post_before = c->post_count;                      // workgroups of post(0 .. t-1)
         // sb: RLS statistics of step t as soon as its forward half is done, then (behind W, sigma of t-1) P += G/v, g, Cholesky
         //     (no cross-stream events inside the loop: a kernel carrying a completion signal holds up the next one of its own
         //     stream by ~10 us on this stack; one-wavefront gate kernels wait on workgroup counters instead)
-        hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
-        if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, nullptr, t & 1))) return rc;
+        if (c->sb_gates) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
+        if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, nullptr, t & 1, c->sb_gates ? nullptr : fdone, c->fwd_count))) return rc;
         if (c->comm_b)                                                     // trials are sharded over ranks: sum [G | FDX | sums]
             VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum,
                                        c->comm_b, sb));
@@ -602,7 +615,6 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             // backward half(t) and P += G/v, g (t) read W, w_chol, sigma of step t-1: a gate kernel on each stream ends when
             // every workgroup of post(t-1) has its outputs in memory
             unsigned* pdone = (unsigned*)(c->ws + c->cv.flags) + 32;
-            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)pdone, c->post_count, stw);
             hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sa, (const unsigned*)pdone, c->post_count, stw);
             VJF_HIP(hipGetLastError());
         }
@@ -614,7 +626,9 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             hipLaunchKernelGGL(vjf_triclean_done_kernel, dim3(1), dim3(1), 0, sa, P, c->state);
             VJF_HIP(hipGetLastError());
         }
-        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb))) return rc;
+        const unsigned* pd = (const unsigned*)((unsigned*)(c->ws + c->cv.flags) + 32);
+        if (c->sb_gates && t > 0) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, pd, post_before, stw);
+        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, (t > 0 && !c->sb_gates) ? pd : nullptr, post_before))) return rc;
         // Cholesky on sb; the post kernel on sc beside it (it takes the columns of L as they appear)
         if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, t == T - 1 ? c->ev_s : nullptr, true))) return rc;
         if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1))) return rc;

@@ -33,6 +33,8 @@ struct VjfPrepArgs {
     int B_total;
     unsigned flags;
     int n_rowblk, n_sgdblk;
+    const unsigned* wait_count;   // vjf_prepg_kernel: non-null -> W, sigma come from a kernel on another stream: wait (bounded)
+    unsigned wait_target;         //   until *wait_count has reached wait_target, then acquire at agent scope
     int bid0;             // first logical workgroup of this launch: 0 (whole grid, or the RLS-operand rows only)
                           // or n_rowblk (SGD + scalars only) -- the two halves run on different streams in vjf_filter_seq
 };
@@ -145,7 +147,21 @@ __global__ __launch_bounds__(256) void vjf_prepg_kernel(VjfPlan P, VjfPrepArgs A
     float* s_w = s_p + 16 * ldp;                       // [n][17]      W, columns dz..15 zero
     float* s_r = s_w + (size_t)n * 17;                 // [4][16][17]  per-wavefront partial products
     float* S = A.state;
-    const float inv_v = expf(-S[P.off[VJF_SLOT_TR_LOGVAR]]);
+    if (A.wait_count) {
+        if (tid == 0) {
+            bool there = false;
+            for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+                if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.wait_target) >= 0) { there = true; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!there) vjf_status_or(S + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+    // (a vector load that bypasses L1 / the scalar cache: sigma may have been written while this kernel was already waiting)
+    const float inv_v = expf(-__hip_atomic_load(S + P.off[VJF_SLOT_TR_LOGVAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     float* Pm = S + P.off[VJF_SLOT_W_PREC];
     const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
     const float* G = A.red + P.red_G;
@@ -512,6 +528,9 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
     const bool do_upd = A.flags & VJF_FLAG_UPDATE, warm = A.flags & VJF_FLAG_WARM_UP;
     if (!do_upd) return;
     if (A.post && warm) return;                      // no RLS in warm-up; the residual / sigma kernels run on their own
+    // "running": the caller keeps the post kernel (2 nbl + 1 workgroups that each take a whole CU's LDS) behind a one-wavefront
+    // gate on this word, so that they do not sit on 15 CUs before there is anything for them to do
+    if (A.post && tid == 0) __hip_atomic_store(A.flags_out + VJF_CHOL_MAXBLK + 2, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float* s_blk = lds;                               // ntri blocks: lower block triangle of P -> L -> L^-1
     float* s_aux = s_blk + (size_t)ntri * 1024;       // nbl blocks: inverted diagonal blocks of L; later scratch
     float* s_g = s_aux + (size_t)nbl * 1024;          // npad x DZP  g, later W

@@ -21,12 +21,28 @@ struct VjfGramArgs {
     float* slabs;            // (njobs, nsplit, 1024)
     int B, nsplit, rows_per_split;
     int job0;                // first job of this launch (the grid covers a contiguous job range)
+    const unsigned* wait_count;   // non-null: the rows come from a kernel on another stream; every workgroup first waits
+    unsigned wait_target;         //   (bounded) until *wait_count has reached wait_target, then acquires at agent scope
+    float* status;
 };
 
 __global__ __launch_bounds__(256) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A) {
     __shared__ float s_acc[3 * 1024];
     // linear id = job * nsplit + split: workgroups are dealt round-robin over the 8 XCDs, so with nsplit a
     // multiple of 8 every job of one trial range lands on the same XCD and re-reads its rows from that L2
+    if (A.wait_count) {
+        if (threadIdx.x == 0) {
+            bool there = false;
+            for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+                if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.wait_target) >= 0) { there = true; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!there) vjf_status_or(A.status, VJF_STATUS_RLS_FAILED);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
     const int split = blockIdx.x % A.nsplit, jobid = A.job0 + blockIdx.x / A.nsplit;
     const VjfJob job = A.jobs[jobid];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
