@@ -204,8 +204,8 @@ struct vjf_ctx {
     bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
                            // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
     bool overlap_serial;   // ... same kernels and hand-offs, but enqueued on ONE stream (profilers that serialise kernels)
-    hipStream_t stream2, stream3;
-    hipEvent_t ev_a, ev_s, ev_c;
+    hipStream_t stream2, stream3, stream4;
+    hipEvent_t ev_a, ev_s, ev_c, ev_d;
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
     unsigned k1_count;     // workgroups of the matrix-core trial kernel (whole step or backward half) launched so far
     unsigned post_count;   // workgroups of the post kernel launched so far
@@ -289,7 +289,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
     c->overlap_serial = false; c->gate_post = getenv("VJF_GATE_POST") != nullptr; c->sb_gates = getenv("VJF_SB_INKERNEL_WAIT") == nullptr;
-    c->stream2 = c->stream3 = nullptr; c->ev_a = c->ev_s = c->ev_c = nullptr;
+    c->stream2 = c->stream3 = c->stream4 = nullptr; c->ev_a = c->ev_s = c->ev_c = c->ev_d = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
@@ -313,15 +313,15 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
 
 int vjf_ctx_destroy(vjf_ctx* ctx) {
     if (ctx && ctx->comm_a) {
-        if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3); }
+        if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamSynchronize(ctx->stream4); }
         (void)hipStreamSynchronize(ctx->stream);
         (void)nccl().comm_destroy(ctx->comm_a); (void)nccl().comm_destroy(ctx->comm_b);
         ctx->comm_a = ctx->comm_b = nullptr;
     }
     if (ctx && ctx->stream2) {
-        (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3);
-        (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_s); (void)hipEventDestroy(ctx->ev_c);
-        (void)hipStreamDestroy(ctx->stream2); (void)hipStreamDestroy(ctx->stream3);
+        (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamSynchronize(ctx->stream4);
+        (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_s); (void)hipEventDestroy(ctx->ev_c); (void)hipEventDestroy(ctx->ev_d);
+        (void)hipStreamDestroy(ctx->stream2); (void)hipStreamDestroy(ctx->stream3); (void)hipStreamDestroy(ctx->stream4);
     }
     delete ctx;
     return 0;
@@ -496,7 +496,7 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
 
 // Cholesky + RLS tail + state-noise update.  `before_chol` / `before_post`: events the stream waits for first (or null).
 int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, hipStream_t st_post,
-               hipEvent_t stop = nullptr, bool no_triclean = false) {
+               hipEvent_t stop = nullptr, bool no_triclean = false, hipStream_t st_inv = nullptr) {
     // `st_post` may differ from `st`: the post kernel's workgroups then start beside the Cholesky kernel and take each
     // column of L as the flag for it appears (the Cholesky kernel is always enqueued first, so even on one hardware queue
     // nothing waits for a kernel behind it).  What the post kernel needs from elsewhere it waits for itself: g through the
@@ -537,7 +537,16 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
             pa.k1_done = c->mfma_trial ? colflags + 16 : nullptr; pa.k1_target = c->k1_count;
             pa.done = colflags + 32; c->post_count += (unsigned)(2 * nbl + 1);
             pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
-            VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st_post, stop, P, pa);
+            if (st_inv && st_inv != st_post) {
+                // two launches: the inverse workgroups keep one column of L in LDS and share their CUs with the trial kernel;
+                // the y / W workgroup (all of L in LDS) runs beside them on its own stream
+                pa.role = 1;
+                hipLaunchKernelGGL(vjf_rls_post_kernel, dim3(2 * nbl), dim3(VJF_POST_THREADS), vjf_post_inv_lds_bytes(P), st_inv, P, pa);
+                pa.role = 2;
+                VJF_LAUNCH(vjf_rls_post_kernel, dim3(1), dim3(VJF_POST_THREADS), c->lds_post, st_post, stop, P, pa);
+            } else {
+                VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st_post, stop, P, pa);
+            }
             VJF_HIP(hipGetLastError());
         } else {
             VjfResidArgs ra{};
@@ -565,6 +574,8 @@ int ensure_stream2(vjf_ctx* c) {
     if (c->stream2) return 0;
     VJF_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     VJF_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    VJF_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
+    VJF_HIP(hipEventCreate(&c->ev_d));
     VJF_HIP(hipEventCreate(&c->ev_c));
     VJF_HIP(hipEventCreate(&c->ev_a));          // (default flags: the events are attached to kernel launches)
     VJF_HIP(hipEventCreate(&c->ev_s));
@@ -586,6 +597,7 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
     // (overlap_serial: the three chains share the caller's stream; every wait below is then satisfied when it is reached)
     hipStream_t sa = c->stream, sb = c->overlap_serial ? sa : c->stream2, sc = c->overlap_serial ? sa : c->stream3;
+    hipStream_t sd = (c->overlap_serial || getenv("VJF_POST_ONE_LAUNCH")) ? sc : c->stream4;   // the post kernel's inverse workgroups
     float* redg = (float*)(c->ws + c->cv.red);                             // gradients + loss sums (chain A)
     float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};   // RLS statistics of even / odd steps (chain B)
     const int Bt = B * c->world;                                           // trials of all ranks
@@ -630,7 +642,7 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         if (c->sb_gates && t > 0) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, pd, post_before, stw);
         if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, (t > 0 && !c->sb_gates) ? pd : nullptr, post_before))) return rc;
         // Cholesky on sb; the post kernel on sc beside it (it takes the columns of L as they appear)
-        if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, t == T - 1 ? c->ev_s : nullptr, true))) return rc;
+        if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, t == T - 1 ? c->ev_s : nullptr, true, sd))) return rc;
         if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1))) return rc;
         if (c->comm_a) {                                                   // sum the gradients and the loss sums over ranks
             VJF_NCCL(nccl().group_start());
@@ -646,6 +658,10 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     VJF_HIP(hipEventRecord(c->ev_c, sb));
     VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                           // join: the caller's stream sees the final state
     VJF_HIP(hipStreamWaitEvent(sa, c->ev_c, 0));
+    if (sd != sc) {
+        VJF_HIP(hipEventRecord(c->ev_d, sd));
+        VJF_HIP(hipStreamWaitEvent(sa, c->ev_d, 0));
+    }
     return 0;
 }
 }  // namespace

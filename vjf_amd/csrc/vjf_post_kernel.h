@@ -39,6 +39,9 @@ struct VjfPostArgs {
                               //   vjf_gate_kernel on another stream lets the readers of the next step start on it
     const float* red;       // reduce buffer (G, FDX, sum|dx|^2) of this step
     int B_total;
+    int role;               // 0: one launch, 2 nbl + 1 workgroups; 1: the 2 nbl inverse workgroups alone -- they keep only the
+                            //    current column of L in LDS (48 KB: they fit beside a trial-kernel workgroup on its CU);
+                            //    2: the y / W workgroup alone (it needs all of L for the backward substitution)
     int fold_sigma;         // 1: the y / W workgroup goes on to the state-noise update (no vjf_resid / vjf_sigma launch)
     unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memtime of the y / W workgroup, slots 16..21
 };
@@ -52,6 +55,10 @@ struct VjfPostArgs {
         }                                                                                   \
     } while (0)
 
+static inline size_t vjf_post_inv_lds_bytes(const VjfPlan& P) {      // role 1: (nbl - 1) blocks of one column + Dinv_k | solution | ...
+    const int nbl = (P.n + 31) / 32;
+    return ((size_t)nbl * 32 * VJF_POST_LDB + (size_t)nbl * 32 * VJF_POST_LDX + 32 * VJF_POST_LDX + 64 + 16 + 16) * 4;
+}
 static inline size_t vjf_post_lds_bytes(const VjfPlan& P) {
     const int nbl = (P.n + 31) / 32;
     // L blocks + Dinv blocks | solution | block just solved | block table
@@ -100,11 +107,12 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = P.n, dz = P.dz, nbl = (n + 31) / 32, ntri = nbl * (nbl + 1) / 2, nlow = ntri - nbl;
-    const bool solve = (int)blockIdx.x == 2 * nbl;             // the y / W workgroup
+    const bool solve = A.role == 2 || (int)blockIdx.x == 2 * nbl;   // the y / W workgroup
+    const bool col_only = A.role == 1;                         // LDS holds the current column of L only
     constexpr int LB = VJF_POST_LDB, LX = VJF_POST_LDX;
-    float* s_L = lds;                                          // strictly-lower blocks [32][33] of L (bi > bj)
-    float* s_D = s_L + (size_t)nlow * 32 * LB;                 // nbl blocks [32][33]: inverted diagonal blocks
-    float* s_x = s_D + (size_t)nbl * 32 * LB;                  // [npad][17] right-hand sides -> solution
+    float* s_L = lds;                                          // strictly-lower blocks [32][33] of L (bi > bj); col_only: (i - k - 1)
+    float* s_D = s_L + (size_t)(col_only ? nbl - 1 : nlow) * 32 * LB;   // nbl blocks [32][33]: inverted diagonal blocks; col_only: one
+    float* s_x = s_D + (size_t)(col_only ? 1 : nbl) * 32 * LB; // [npad][17] right-hand sides -> solution
     float* s_y = s_x + (size_t)nbl * 32 * LX;                  // [32][17] the block just solved, for the eager updates
     int* s_tab = reinterpret_cast<int*>(s_y + 32 * LX);        // [32..64): lower tiles incl. diagonal -> (bi << 8) | bj
     int* s_ctl = s_tab + 64;
@@ -118,6 +126,8 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     const int j0 = solve ? 0 : (int)blockIdx.x >> 1;           // first block row of the substitution
     const int c0 = solve ? 0 : 16 * ((int)blockIdx.x & 1);
     auto tri = [](int bi, int bj) { return bi * (bi - 1) / 2 + bj; };       // strictly lower: bi > bj
+    auto lblk = [&](int bi, int bj) { return s_L + (size_t)(col_only ? bi - bj - 1 : tri(bi, bj)) * 32 * LB; };   // block (bi, bj), bi > bj
+    auto dblk = [&](int k) { return s_D + (size_t)(col_only ? 0 : k) * 32 * LB; };
 
     float pre_sdx2 = 0.f, pre_old = 0.f, pre_tot = 1.f;         // sum|dx|^2, old share of the running variance, new count
     double pre_scale = 0.0;                                     // mse -> new share of the running variance
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
             for (int q = 0; q < 4; ++q) {
                 const int it = 2 * q + bh;
                 if (it < nb) {
-                    float* dst = (it == 0 ? s_D + ((size_t)k * 32 + r) * LB : s_L + ((size_t)tri(k + it, k) * 32 + r) * LB) + c4;
+                    float* dst = (it == 0 ? dblk(k) : lblk(k + it, k)) + (size_t)r * LB + c4;
                     dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
                 }
             }
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         if (k == j0) VJF_POST_STAMP(17);
         vjf_f32x4 y = {0.f, 0.f, 0.f, 0.f};
         if (wave < 2) {
-            const float* Db = s_D + (size_t)k * 32 * LB;
+            const float* Db = dblk(k);
             post_mma32(y, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Db[(16 * wave + i) * LB + m]; });
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_y[(16 * wave + xr + r) * LX + xc] = y[r];
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
             for (int r = 0; r < 4; ++r) s_x[(k * 32 + 16 * wave + xr + r) * LX + xc] = y[r];
         }
         for (int i = k + 1 + grp; i < nbl; i += VJF_POST_THREADS / 128) {
-            const float* Lb = s_L + (size_t)tri(i, k) * 32 * LB;
+            const float* Lb = lblk(i, k);
             float* xt = s_x + ((size_t)i * 32 + 16 * tile + xr) * LX + xc;
             vjf_f32x4 acc;
 #pragma unroll
