@@ -320,6 +320,26 @@ def test_sharded_path_one_rank_nccl(vjf):
     assert torch.equal(m1._blob, m2._blob)
 
 
+def test_state_io_resume_is_bit_exact(vjf, tmp_path):
+    """save_state after some steps, load into a fresh model, continue: identical to the uninterrupted run."""
+    z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
+    m1, m2 = _model_for(vjf, info), _model_for(vjf, info)
+    load_fixture_state(m1, z, "s0")
+    y, eps = torch.tensor(z["y"]), torch.tensor(z["eps"])
+    k = y.shape[0] // 2
+    mu, lv, _ = m1.filter_sequence(y[:k], eps=eps[:k])
+    m1.save_state(tmp_path / "s.npz")
+    m2.load_state(tmp_path / "s.npz")
+    q = vjf.Gaussian(mu[-1], lv[-1])
+    o1 = m1.filter_sequence(y[k:], qs=q, eps=eps[k:])
+    o2 = m2.filter_sequence(y[k:], qs=vjf.Gaussian(mu[-1].clone(), lv[-1].clone()), eps=eps[k:])
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    st1, st2 = m1.get_state(), m2.get_state()
+    for kk in st1:
+        assert np.array_equal(st1[kk], st2[kk]), kk
+
+
 def test_bad_arguments(vjf):
     model = vjf.VJF.make_model(10, 3, 2, 16, [8], likelihood="gaussian")
     with pytest.raises(TypeError):

@@ -153,3 +153,35 @@ def test_host_sequence_and_reference_noise_order(fake):
         close(q.mean, mu[t], rtol=1e-6, atol=1e-7)
         close(l, loss[t, 0], rtol=1e-6)
     close(m1._blob, m2._blob, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the stand-in backend works on CPU tensors")
+def test_state_io_roundtrip_cpu(fake, tmp_path):
+    """get_state / set_state / save_state / load_state on the host side (oracle-backed stand-in library)."""
+    import vjf_amd as vjf
+    torch.manual_seed(3)
+    m1 = vjf.VJF.make_model(6, 2, 1, 8, [5], likelihood="gaussian")
+    g = torch.Generator().manual_seed(1)
+    y, u, eps = torch.randn(3, 4, 6, generator=g), torch.randn(3, 4, 1, generator=g), torch.randn(3, 2, 4, 2, generator=g)
+    m1.filter_sequence(y[:2], u[:2], eps=eps[:2])
+    m1.freeze_decoder(True)
+    p = tmp_path / "state.npz"
+    m1.save_state(p)
+    torch.manual_seed(99)
+    m2 = vjf.VJF.make_model(6, 2, 1, 8, [5], likelihood="gaussian")
+    m2.load_state(p)
+    s1, s2 = m1.get_state(), m2.get_state()
+    assert set(s1) == set(s2) and len(s1) == 13 + 4 + 5
+    for k in s1:
+        assert np.array_equal(np.asarray(s1[k]), np.asarray(s2[k])), k
+    assert m2.likelihood.n_sample == m1.likelihood.n_sample and m2.transition.n_sample == m1.transition.n_sample
+    o1 = m1.filter_sequence(y[2:], u[2:], eps=eps[2:])
+    o2 = m2.filter_sequence(y[2:], u[2:], eps=eps[2:])
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    m3 = vjf.VJF.make_model(6, 2, 1, 9, [5], likelihood="gaussian")
+    try:
+        m3.set_state(s1)
+        assert False, "shape mismatch must raise"
+    except ValueError:
+        pass

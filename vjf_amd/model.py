@@ -291,6 +291,59 @@ class VJF(Module):
             if rc < 0:
                 N.check(rc, "vjf_set_overlap")
 
+    # ------------------------------------------------------------------ state I/O (the reference has no format)
+    _RLS_KEYS = ("w_mean", "w_chol", "w_precision", "w_pchol")
+
+    def get_state(self) -> dict:
+        """Everything a run needs to resume, as numpy arrays: the 13 `state_dict` tensors, the RLS tensors of
+        `transition.velocity` (plain attributes in the reference: vjf/module.py:45-54), the two sample counters, the
+        four group learning rates, the decoder-freeze flag and the shape of the model."""
+        import numpy as np
+        st = {k: v.detach().cpu().numpy().copy() for k, v in self.state_dict().items()}
+        lr = self.transition.velocity
+        for k in self._RLS_KEYS:
+            st["transition.velocity." + k] = getattr(lr, k).detach().cpu().numpy().copy()
+        st["likelihood.n_sample"] = np.int64(self._get_counter("lik"))
+        st["transition.n_sample"] = np.int64(self._get_counter("tr"))
+        st["optimizer.lr"] = np.array([float(g["lr"]) for g in self.optimizer.param_groups], np.float64)
+        st["decoder.frozen"] = np.int64(int(self._scalars[N.SC_FREEZE_DEC].item() != 0))
+        st["config"] = np.array([self.ydim, self.xdim, self.udim, self.n_rbf, self._lik] + list(self.hidden_sizes), np.int64)
+        return st
+
+    def set_state(self, st: dict):
+        """Inverse of `get_state` (same model shape required).  Clears the sticky status bits and marks `w_chol` /
+        `w_pchol` as possibly dense, so the first RLS update re-establishes their triangles."""
+        import numpy as np
+        cfg = [int(v) for v in np.asarray(st["config"]).tolist()]
+        mine = [self.ydim, self.xdim, self.udim, self.n_rbf, self._lik] + list(self.hidden_sizes)
+        if cfg != mine:
+            raise ValueError(f"state is for a model of shape {cfg}, this one is {mine}")
+        own = self.state_dict()
+        with torch.no_grad():
+            for k, v in own.items():
+                v.copy_(torch.as_tensor(np.asarray(st[k]), dtype=torch.float32).reshape(v.shape))
+            lr = self.transition.velocity
+            for k in self._RLS_KEYS:
+                t = getattr(lr, k)
+                t.copy_(torch.as_tensor(np.asarray(st["transition.velocity." + k]), dtype=torch.float32).reshape(t.shape))
+        self._set_counter("lik", int(st["likelihood.n_sample"]))
+        self._set_counter("tr", int(st["transition.n_sample"]))
+        for g, v in zip(self.optimizer.param_groups, np.asarray(st["optimizer.lr"]).tolist()):
+            g["lr"] = float(v)
+        self._push_lr(force=True)
+        self.freeze_decoder(bool(int(st["decoder.frozen"])))
+        self._scalars[N.SC_TRI_CLEAN] = 0.0
+        self._scalars[N.SC_STATUS] = 0.0
+
+    def save_state(self, path):
+        import numpy as np
+        np.savez(path, **self.get_state())
+
+    def load_state(self, path):
+        import numpy as np
+        with np.load(path) as z:
+            self.set_state({k: z[k] for k in z.files})
+
     def status(self) -> int:
         """Sticky VJF_STATUS_* bits raised by the device since the last call (clears them)."""
         if self._ctx is None:
