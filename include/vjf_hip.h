@@ -183,6 +183,16 @@ int vjf_rls_scratch_size(int32_t B, int32_t n, int32_t dout, int64_t* bytes);
 int vjf_blr_rls(const float* x, const float* target, const float* v, float shrink, const float* centroid,
                 const float* logwidth, float* w_mean, float* w_chol, float* w_precision, float* w_pchol,
                 void* scratch, uint32_t* status, int32_t B, int32_t n, int32_t d, int32_t dout, void* stream);
+
+/* LinearRegression.kalman (vjf/module.py:114-142 over vjf/kalman.py:15-50, 102-145), A = I, Q = diffusion I, R = v I, in
+ * n x n algebra on the Gram statistics: the reference's (samples x samples) innovation covariance is never formed (its
+ * update -- S^-1 enters the gain twice, kalman.py:134-135 -- is reproduced as it is).  w_mean (n, dout) and w_chol (n, n) in
+ * place; w_chol leaves as the lower Cholesky factor of the covariance.  status[0] (device, may
+ * be NULL): 0 or VJF_STATUS_RLS_FAILED (state untouched). */
+int vjf_kalman_scratch_size(int32_t B, int32_t n, int32_t dout, int64_t* bytes);
+int vjf_blr_kalman(const float* x, const float* target, const float* v, float diffusion, const float* centroid,
+                   const float* logwidth, float* w_mean, float* w_chol, void* scratch, uint32_t* status, int32_t B,
+                   int32_t n, int32_t d, int32_t dout, void* stream);
 /* Recognition.forward (vjf/recognition.py:31-42). Wb: pointers to layer weights/biases on device. */
 int vjf_recognition_forward(const float* y, const float* u, const float* mu_s, const float* lv_s,
                             const float* const* rec_W, const float* const* rec_b, const float* mean_W,

@@ -277,6 +277,22 @@ class FakeLib:
         np.ctypeslib.as_array((C.c_int32 * 1).from_address(status.value))[0] = 8 if st else 0
         return 0
 
+    def vjf_kalman_scratch_size(self, B, n, dout, out):
+        out._obj.value = 64
+        return 0
+
+    def vjf_blr_kalman(self, x, target, v, diffusion, cen, lw, w_mean, w_chol, scratch, status, B, n, d, dout, stream):
+        s = orc.OracleState(1, dout, 0, n, (1,), orc.GAUSSIAN)
+        s.centroid, s.logwidth = _arr(cen, n * d).reshape(n, d).astype(np.float64), _arr(lw, n).astype(np.float64)
+        s.w_mean = _arr(w_mean, n * dout).reshape(n, dout).astype(np.float64)
+        s.w_chol = _arr(w_chol, n * n).reshape(n, n).astype(np.float64)
+        orc.blr_kalman(s, _arr(x, B * d).reshape(B, d).astype(np.float64), _arr(target, B * dout).reshape(B, dout).astype(np.float64),
+                       float(_arr(v, 1)[0]), float(diffusion))
+        _arr(w_mean, n * dout).reshape(n, dout)[...] = s.w_mean
+        _arr(w_chol, n * n).reshape(n, n)[...] = s.w_chol
+        np.ctypeslib.as_array((C.c_int32 * 1).from_address(status.value))[0] = 0
+        return 0
+
     def vjf_blr_predict(self, x, cen, lw, w_mean, w_chol, mean, logvar, B, n, d, dout, stream):
         s = orc.OracleState(1, dout, 0, n, (1,), orc.GAUSSIAN)
         s.centroid, s.logwidth = _arr(cen, n * d).reshape(n, d).astype(np.float64), _arr(lw, n).astype(np.float64)

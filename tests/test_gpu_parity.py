@@ -340,6 +340,38 @@ def test_state_io_resume_is_bit_exact(vjf, tmp_path):
         assert np.array_equal(st1[kk], st2[kk]), kk
 
 
+def test_kalman_golden(vjf):
+    """LinearRegression.kalman (information form on the GPU) against the reference's Joseph-form update, fixture G7."""
+    z = gio.load("g7_kalman")
+    n, d = z["centroid"].shape
+    blr = vjf.module.LinearRegression(vjf.module.RBF(d, n), d)
+    with torch.no_grad():
+        blr.feature.centroid.copy_(torch.tensor(z["centroid"], dtype=torch.float32))
+        blr.feature.logwidth.copy_(torch.tensor(z["logwidth"], dtype=torch.float32))
+    blr.kalman(torch.tensor(z["x"]), torch.tensor(z["t"]), 0.5, diffusion=0.01)
+    close(blr.w_mean, z["W1"], rtol=2e-4, atol=2e-5)
+    close(blr.w_chol, z["L1"], rtol=2e-4, atol=2e-5)
+    blr.kalman(torch.tensor(z["t"]), torch.tensor(z["x"]), 0.25)
+    close(blr.w_mean, z["W2"], rtol=5e-4, atol=5e-5)
+    close(blr.w_chol, z["L2"], rtol=5e-4, atol=5e-5)
+    # B >> n, where the reference's (samples x samples) form is O(B^3): the same update through the oracle at a size it can do
+    g = torch.Generator().manual_seed(9)
+    B = 600
+    x, t = torch.randn(B, d, generator=g), torch.randn(B, d, generator=g)
+    s = orc.OracleState(1, d, 0, n, (1,), orc.GAUSSIAN)
+    s.centroid, s.logwidth = z["centroid"], z["logwidth"]
+    s.w_mean, s.w_chol = blr.w_mean.cpu().numpy().astype(np.float64), blr.w_chol.cpu().numpy().astype(np.float64)
+    orc.blr_kalman(s, x.numpy().astype(np.float64), t.numpy().astype(np.float64), 0.3, diffusion=0.02)
+    blr.kalman(x, t, 0.3, diffusion=0.02)
+    close(blr.w_mean, s.w_mean, rtol=1e-3, atol=1e-4)
+    close(blr.w_chol, s.w_chol, rtol=1e-3, atol=1e-5)
+    x, t = torch.randn(8192, d, generator=g), torch.randn(8192, d, generator=g)     # runs where the reference cannot
+    blr.kalman(x, t, 0.3, diffusion=0.02)
+    assert torch.isfinite(blr.w_mean).all() and torch.isfinite(blr.w_chol).all()
+    with pytest.raises(AssertionError):
+        blr.kalman(x, t, 0.3, diffusion=-1.)
+
+
 def test_bad_arguments(vjf):
     model = vjf.VJF.make_model(10, 3, 2, 16, [8], likelihood="gaussian")
     with pytest.raises(TypeError):

@@ -64,6 +64,8 @@ SIGNATURES = {
     "vjf_blr_sample": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vjf_rls_scratch_size": [_I, _I, _I, C.POINTER(C.c_int64)],
     "vjf_blr_rls": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vjf_kalman_scratch_size": [_I, _I, _I, C.POINTER(C.c_int64)],
+    "vjf_blr_kalman": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vjf_recognition_forward": [_P, _P, _P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
                                 C.POINTER(_I), _P],
     "vjf_gaussian_loss": [_P, _P, _P, _P, _P, _P, _I, _I, _P],

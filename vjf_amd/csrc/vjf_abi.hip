@@ -971,6 +971,54 @@ int vjf_blr_rls(const float* x, const float* target, const float* v, float shrin
     return 0;
 }
 
+int vjf_kalman_scratch_size(int32_t B, int32_t n, int32_t dout, int64_t* bytes) {
+    if (!bytes || B < 1 || n < 1 || dout < 1) return fail(-20, "vjf_kalman_scratch_size: bad argument");
+    const size_t nn = ((size_t)n * (n > dout ? n : dout) * 4 + 255) / 256 * 256;
+    *bytes = (int64_t)(rls_carve(B, n, dout, nullptr).total + 6 * nn);
+    return 0;
+}
+
+int vjf_blr_kalman(const float* x, const float* target, const float* v, float diffusion, const float* centroid, const float* logwidth,
+                   float* w_mean, float* w_chol, void* scratch, uint32_t* status, int32_t B, int32_t n, int32_t d, int32_t dout,
+                   void* stream) {
+    if (!x || !target || !v || !centroid || !logwidth || !w_mean || !w_chol || !scratch) return fail(-1, "vjf_blr_kalman: null tensor");
+    if (B < 1 || n < 1 || d < 1 || dout < 1) return fail(-20, "vjf_blr_kalman: bad shape");
+    if (!(diffusion >= 0.f)) return fail(-25, "vjf_blr_kalman: diffusion needs to be non-negative");   // module.py:127
+    hipStream_t s = (hipStream_t)stream;
+    VjfPlan P; rls_plan(n, dout, &P);
+    const size_t lds = vjf_serial_lds_floats(P) * 4;
+    if (lds > kMaxLds - 1024) return fail(-11, "vjf_blr_kalman: n=%d too large for the single-workgroup kernel", n);
+    std::vector<VjfJob> jobs;
+    RlsCarve c = rls_carve(B, n, dout, &jobs);
+    char* ws = (char*)scratch;
+    VJF_HIP(hipMemcpyAsync(ws + c.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, s));
+    VJF_HIP(hipStreamSynchronize(s));     // host vector goes out of scope
+    VJF_HIP(hipMemsetAsync(ws + c.partial, 0, RS_N * 4, s));
+    float* E = (float*)(ws + c.E);
+    hipLaunchKernelGGL(vjf_rls_rows_kernel, grid1d((size_t)B * P.ldE), dim3(256), 0, s, x, centroid, logwidth, target, E, B, n, d, dout, P.ldE);
+    VJF_HIP(hipGetLastError());
+    VjfGramArgs g{};
+    g.jobs = (const VjfJob*)(ws + c.jobs); g.E = E; g.ACT = E; g.DEL = E; g.slabs = (float*)(ws + c.slabs);
+    g.B = B; g.nsplit = c.nsplit; g.rows_per_split = ((B + c.nsplit - 1) / c.nsplit + 7) / 8 * 8;
+    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c.njobs * c.nsplit), dim3(256), 0, s, P, g);
+    VJF_HIP(hipGetLastError());
+    VjfReduceArgs r{};
+    r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(ws + c.partial); r.red = (float*)(ws + c.red);
+    r.njobs = c.njobs; r.nsplit = c.nsplit; r.nblocks_k1 = 1;
+    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c.njobs), dim3(256), 0, s, P, r);
+    VJF_HIP(hipGetLastError());
+    allow_lds(vjf_kalman_kernel, lds);
+    const size_t nn = ((size_t)n * (n > dout ? n : dout) * 4 + 255) / 256 * 256;
+    VjfKalmanArgs a{};
+    a.Wm = w_mean; a.Wc = w_chol; a.G = r.red + P.red_G; a.Fy = r.red + P.red_FDX; a.v = v;
+    for (int q = 0; q < 6; ++q) a.T[q] = (float*)(ws + c.total + (size_t)q * nn);
+    a.Dinv = (float*)(ws + c.work);
+    a.status = status; a.n = n; a.dout = dout; a.diffusion = diffusion;
+    hipLaunchKernelGGL(vjf_kalman_kernel, dim3(1), dim3(VJF_K2_THREADS), lds, s, a);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
 int vjf_recognition_forward(const float* y, const float* u, const float* mu_s, const float* lv_s, const float* const* rec_W,
                             const float* const* rec_b, const float* mean_W, const float* lv_W, const float* lv_b, float* mu_t,
                             float* lv_t, int32_t B, int32_t ydim, int32_t udim, int32_t xdim, int32_t n_hidden,

@@ -271,6 +271,97 @@ __global__ __launch_bounds__(VJF_K2_THREADS) void vjf_rls_kernel(VjfRlsArgs A) {
     if (threadIdx.x == 0 && A.status) A.status[0] = st;
 }
 
+// Stand-alone LinearRegression.kalman (vjf/module.py:114-142; vjf/kalman.py:15-50, 102-145) without the reference's
+// (samples x samples) innovation covariance S = H Vhat H^T + v I, which is O(B^3) and unusable at B >> n.
+// What the reference computes (A = I, Q = diffusion I, R = v I; Lhat = chol(w_chol w_chol^T + Q), Vhat = Lhat Lhat^T):
+//     Gk = Vhat H^T S^-1                                  (kalman.py:134)
+//     m  = m_prev + Gk S^-1 (y - H m_prev)                (kalman.py:135)   -- S^-1 enters twice: the effective gain is
+//     V  = (I - Gk S^-1 H) Vhat (.)^T + (Gk S^-1) R (.)^T (kalman.py:137-142)  K = Vhat H^T S^-2, not the textbook one
+// and w_chol <- chol(V).  This is the behaviour fixture G7 pins, so it is what is reproduced.  With the push-through identity
+//     H^T S^-1 = (H^T H Vhat + v I)^-1 H^T = Lhat^-T N^-1 Lhat^T H^T,     N = Lhat^T (H^T H) Lhat + v I   (n x n, SPD)
+// the gain is K = J H^T with J = Lhat N^-2 Lhat^T (symmetric), and everything reduces to n x n algebra on the Gram
+// statistics G = H^T H, Fy = H^T y:
+//     m = m_prev + J (Fy - G m_prev),    V = (I - J G) Vhat (I - J G)^T + v J G J.
+// One workgroup; six n x n scratch matrices, Dinv as vjf_trinv_blocked wants it.
+struct VjfKalmanArgs {
+    float* Wm; float* Wc;
+    const float* G; const float* Fy; const float* v;
+    float* T[6]; float* Dinv;
+    unsigned* status;
+    int n, dout; float diffusion;
+};
+__global__ __launch_bounds__(VJF_K2_THREADS) void vjf_kalman_kernel(VjfKalmanArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, n = A.n, dz = A.dout;
+    const float v = A.v[0];
+    auto fail_out = [&]() { if (tid == 0 && A.status) A.status[0] = VJF_STATUS_RLS_FAILED; };
+    // C (n x m) = op(X) op(Y): X, Y n x n row-major (tx / ty: use the transpose), or Y n x m when m != n
+    auto mm = [&](float* C, const float* X, bool tx, const float* Y, bool ty, int m) {
+        for (int e = tid; e < n * m; e += VJF_K2_THREADS) {
+            const int i = e / m, j = e - i * m;
+            float acc = 0.f;
+            for (int k = 0; k < n; ++k)
+                acc = fmaf(tx ? X[(size_t)k * n + i] : X[(size_t)i * n + k], ty ? Y[(size_t)j * n + k] : Y[(size_t)k * m + j], acc);
+            C[e] = acc;
+        }
+        __syncthreads();
+    };
+    float* Vh = A.T[0]; float* Lh = A.T[1]; float* X1 = A.T[2]; float* X2 = A.T[3]; float* X3 = A.T[4]; float* X4 = A.T[5];
+    mm(Vh, A.Wc, false, A.Wc, true, n);                            // Vhat = L L^T + Q   (kalman.py:41-44)
+    for (int e = tid; e < n * n; e += VJF_K2_THREADS) {
+        if (e / n == e % n) Vh[e] += A.diffusion;
+        Lh[e] = Vh[e];
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += VJF_K2_THREADS) if (e / n == e % n) Lh[e] = Vh[e];
+    __syncthreads();
+    if (!vjf_chol_blocked(Lh, n, lds)) { fail_out(); return; }     // Lhat (kalman.py:47)
+    __syncthreads();
+    mm(X1, A.G, false, Lh, false, n);                              // G Lhat
+    mm(X2, Lh, true, X1, false, n);                                // N = Lhat^T G Lhat + v I
+    for (int e = tid; e < n * n; e += VJF_K2_THREADS) if (e / n == e % n) X2[e] += v;
+    __syncthreads();
+    if (!vjf_chol_blocked(X2, n, lds)) { fail_out(); return; }
+    __syncthreads();
+    vjf_trinv_blocked(X2, X1, A.Dinv, n, lds);                     // X1 = C^-1, N = C C^T
+    __syncthreads();
+    mm(X2, X1, true, X1, false, n);                                // N^-1 = C^-T C^-1
+    mm(X1, X2, false, X2, false, n);                               // N^-2
+    mm(X3, Lh, false, X1, false, n);                               // Lhat N^-2
+    mm(X4, X3, false, Lh, true, n);                                // J = Lhat N^-2 Lhat^T
+    // m = m_prev + J (Fy - G m_prev)
+    for (int e = tid; e < n * dz; e += VJF_K2_THREADS) {
+        const int i = e / dz, j = e - i * dz;
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc = fmaf(A.G[(size_t)i * n + k], A.Wm[(size_t)k * dz + j], acc);
+        X1[e] = A.Fy[e] - acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * dz; e += VJF_K2_THREADS) {
+        const int i = e / dz, j = e - i * dz;
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc = fmaf(X4[(size_t)i * n + k], X1[(size_t)k * dz + j], acc);
+        X2[e] = A.Wm[e] + acc;                                     // new mean, parked until the covariance is known to be good
+    }
+    __syncthreads();
+    mm(X3, X4, false, A.G, false, n);                              // J G
+    for (int e = tid; e < n * n; e += VJF_K2_THREADS) X1[e] = ((e / n == e % n) ? 1.f : 0.f) - X3[e];   // I - J G
+    __syncthreads();
+    mm(Lh, X1, false, Vh, false, n);                               // (I - J G) Vhat          (Lhat is no longer needed)
+    mm(Vh, Lh, false, X1, true, n);                                // (I - J G) Vhat (I - J G)^T
+    mm(Lh, X3, false, X4, false, n);                               // J G J   (J symmetric)
+    for (int e = tid; e < n * n; e += VJF_K2_THREADS) Vh[e] = fmaf(v, Lh[e], Vh[e]);
+    __syncthreads();
+    // symmetrise against rounding before the factorisation reads the lower triangle
+    for (int e = tid; e < n * n; e += VJF_K2_THREADS) { const int i = e / n, j = e - i * n; Lh[e] = 0.5f * (Vh[e] + Vh[(size_t)j * n + i]); }
+    __syncthreads();
+    if (!vjf_chol_blocked(Lh, n, lds)) { fail_out(); return; }     // w_chol = chol(V)   (kalman.py:144-145)
+    __syncthreads();
+    for (int e = tid; e < n * dz; e += VJF_K2_THREADS) A.Wm[e] = X2[e];
+    for (int e = tid; e < n * n; e += VJF_K2_THREADS) A.Wc[e] = Lh[e];
+    if (tid == 0 && A.status) A.status[0] = 0u;
+}
+
 __global__ __launch_bounds__(VJF_K2_THREADS) void vjf_serial_kernel(VjfPlan P, VjfSerialArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double s_dred[VJF_K2_THREADS / 64];

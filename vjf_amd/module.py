@@ -138,8 +138,28 @@ class LinearRegression(Module):
 
     @torch.no_grad()
     def kalman(self, x: Tensor, target: Tensor, v: Union[Tensor, float], diffusion: float = 0.):
-        raise NotImplementedError("LinearRegression.kalman (vjf/module.py:114-142) is off VJF's live path (its call "
-                                  "sites are commented out) and is scheduled after the RLS path: SURVEY.md 8f-1")
+        """Update weight using Kalman   (vjf/module.py:114-142): w[t] = w[t-1] + Q, target[t] = f(x[t])'w[t] + v, Q = diffusion I.
+        The reference's update (vjf/kalman.py:102-145, where S^-1 enters the gain twice) reproduced in n x n algebra on the Gram
+        statistics H'H, H'y: the (samples x samples) innovation covariance never exists.  w_chol leaves as the lower Cholesky
+        factor of the covariance."""
+        assert diffusion >= 0., 'diffusion needs to be non-negative'
+        x, target = dev32(x), dev32(target)
+        B, n, d, dout = self._dims(x)
+        assert target.shape == (B, dout)
+        L = N.lib()
+        import ctypes
+        nbytes = ctypes.c_int64()
+        N.check(L.vjf_kalman_scratch_size(B, n, dout, ctypes.byref(nbytes)), "vjf_kalman_scratch_size")
+        if self._rls_scratch is None or self._rls_scratch.numel() < nbytes.value:
+            self._rls_scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+        vt = dev32(v, ndim2=False).reshape(1)
+        status = torch.zeros(1, dtype=torch.int32, device=x.device)
+        N.check(L.vjf_blr_kalman(N.ptr(x), N.ptr(target), N.ptr(vt), float(diffusion), N.ptr(self.feature.centroid),
+                                 N.ptr(self.feature.logwidth), N.ptr(self.w_mean), N.ptr(self.w_chol), N.ptr(self._rls_scratch),
+                                 N.ptr(status), B, n, d, dout, stream_ptr()), "vjf_blr_kalman")
+        self._w_colmajor = False
+        if int(status.item()) != 0:
+            warnings.warn('Kalman update failed.')    # covariance / precision not positive definite: state left unchanged
 
     @torch.no_grad()
     def initialize(self, x: Tensor, target: Tensor, v):
