@@ -260,7 +260,8 @@ def test_rls_failure_is_flagged_and_leaves_rls_state(vjf):
     """A precision matrix that is not positive definite: the reference's fallback raises (module.py:104-112); here the RLS
     tensors stay as they were, the status bit is raised and nothing hangs -- through the single-step path and through the
     sequence path, where the post kernel waits on the Cholesky kernel's column flags."""
-    for n_rbf, bad_from in ((16, 0), (72, 0), (72, 40)):          # 1 block; 3 blocks failing in the first / second column
+    for n_rbf, bad_from in ((16, 0), (72, 0), (72, 40), (260, 100)):   # 1 block; 3 blocks failing in the first / second column;
+                                                                        # beyond one CU's LDS (multi-launch path), failing in the 4th
         torch.manual_seed(4)
         model = vjf.VJF.make_model(10, 3, 0, n_rbf, [8], likelihood="gaussian")
         g = torch.Generator().manual_seed(5)

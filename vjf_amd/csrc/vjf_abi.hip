@@ -18,6 +18,7 @@
 #include "vjf_ops_kernels.h"
 #include "vjf_plan.h"
 #include "vjf_post_kernel.h"
+#include "vjf_rlsb_kernels.h"
 #include "vjf_serial_kernel.h"
 #include "vjf_trial_kernel.h"
 #include "vjf_trial_mfma_kernel.h"
@@ -680,6 +681,52 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
         int rc = launch_prep(c, B_total, loss4, flags, red, 0, c->stream);
         if (rc) return rc;
         return launch_rls(c, B_total, flags, red, c->stream, c->stream);
+    }
+    if (c->plan.n > 32 * VJF_CHOL_MAXBLK) {
+        // feature counts beyond one CU's LDS: clip + SGD and scalars in the prep kernel, then the RLS update as a sequence of
+        // chip-wide launches on the matrix in global memory (vjf_rlsb_kernels.h)
+        const VjfPlan& P = c->plan;
+        const float* red = (const float*)(c->ws + c->cv.red);
+        int rc = launch_prep(c, B_total, loss4, flags, red, 2, c->stream);
+        if (rc) return rc;
+        if (!(flags & VJF_FLAG_UPDATE)) return 0;
+        hipStream_t st = c->stream;
+        const int nbl = (P.n + 31) / 32;
+        float* work = (float*)(c->ws + c->cv.work);
+        VjfRlsbArgs a{};
+        a.state = c->state; a.red = red; a.Lw = (float*)(c->ws + c->cv.lscr);
+        a.X = work; a.gbuf = work + (size_t)P.n * P.n; a.ybuf = a.gbuf + (size_t)P.n * P.dz;
+        a.Dinv = (float*)(c->ws + c->cv.post);
+        a.ok = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
+        const bool rls = !(flags & VJF_FLAG_WARM_UP);
+        if (rls) {
+            const int gx = 512;
+            hipLaunchKernelGGL(vjf_rlsb_prep_kernel, dim3(gx), dim3(256), 0, st, P, a);
+            for (int k = 0; k < nbl; ++k) {
+                a.k = k;
+                hipLaunchKernelGGL(vjf_rlsb_diag_kernel, dim3(1), dim3(64), 0, st, P, a);
+                const int m = nbl - 1 - k;
+                if (m > 0) {
+                    hipLaunchKernelGGL(vjf_rlsb_panel_kernel, dim3(m), dim3(64), 0, st, P, a);
+                    hipLaunchKernelGGL(vjf_rlsb_trail_kernel, dim3(m * (m + 1) / 2), dim3(64), 0, st, P, a);
+                }
+            }
+            for (int i = 0; i < nbl; ++i) {
+                a.k = i;
+                hipLaunchKernelGGL(vjf_rlsb_inv_kernel, dim3(i + 1), dim3(64), 0, st, P, a);
+            }
+            hipLaunchKernelGGL(vjf_rlsb_y_kernel, dim3(gx), dim3(256), 0, st, P, a);
+            hipLaunchKernelGGL(vjf_rlsb_w_kernel, dim3(gx), dim3(256), 0, st, P, a);
+            hipLaunchKernelGGL(vjf_rlsb_final_kernel, dim3(gx), dim3(256), 0, st, P, a);
+            VJF_HIP(hipGetLastError());
+        }
+        VjfResidArgs ra{};
+        ra.state = c->state; ra.red = red; ra.partial = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
+        ra.B_total = B_total; ra.flags = flags;
+        hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra);
+        hipLaunchKernelGGL(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, P, ra, (const int*)nullptr);
+        VJF_HIP(hipGetLastError());
+        return 0;
     }
     VjfSerialArgs s{};
     s.state = c->state; s.red = (const float*)(c->ws + c->cv.red); s.work = (float*)(c->ws + c->cv.work);
