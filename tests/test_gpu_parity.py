@@ -187,6 +187,9 @@ CASES = [
     dict(B=77, dz=10, dy=200, du=0, n=200, hidden=[128], lik="poisson", T=2),       # config C dims
     dict(B=50, dz=5, dy=7, du=3, n=33, hidden=[40, 24, 9], lik="gaussian", T=3),     # odd sizes, 3 layers, control input
     dict(B=37, dz=64, dy=512, du=0, n=300, hidden=[512, 512], lik="gaussian", T=2),  # config E layer widths (n reduced)
+    dict(B=64, dz=6, dy=12, du=0, n=228, hidden=[16], lik="gaussian", T=3),          # just beyond one CU's LDS: multi-launch RLS
+    dict(B=40, dz=12, dy=20, du=1, n=500, hidden=[24], lik="poisson", T=2),          # 16 blocks, last one partial
+    dict(B=48, dz=4, dy=9, du=0, n=222, hidden=[12], lik="gaussian", T=3),           # n % 4 != 0: single-workgroup serial kernel
 ]
 
 
