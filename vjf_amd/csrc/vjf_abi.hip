@@ -113,9 +113,14 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
             jobs.push_back(j);
         }
     // kind 1: DEL[:, xcol..+M]^T ACT[:, ycol..+K+1]  ->  weight (M,K) + bias (M)
+    auto tensor_of = [&](int slot) {
+        for (int t = 0; t < P.n_train; ++t) if (P.tr_off[t] == P.off[slot]) return t;
+        return -1;
+    };
     auto grad = [&](int xcol, int M, int ycol, int K, int slotW, int slotB) {
         const int offW = P.off[slotW] - P.train_off;
         const int offB = slotB >= 0 ? P.off[slotB] - P.train_off : -1;
+        const int tW = tensor_of(slotW), tB = slotB >= 0 ? tensor_of(slotB) : -1;
         const int ncols = K + 1;
         for (int ri = 0; ri * VJF_TILE < M; ++ri)
             for (int ci = 0; ci * VJF_TILE < ncols; ++ci) {
@@ -128,6 +133,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
                 int nw = K - ci * VJF_TILE;
                 j.ncol_w = nw < 0 ? 0 : (nw > VJF_TILE ? VJF_TILE : nw);
                 j.dst_b = offB >= 0 ? offB + ri * VJF_TILE : -1;
+                j.tw = tW; j.tb = tB;
                 jobs.push_back(j);
             }
     };
@@ -452,7 +458,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
 
 // Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
 int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, hipEvent_t stop = nullptr,
-                int gen = 0, const unsigned* wait_count = nullptr, unsigned wait_target = 0) {
+                int gen = 0, const unsigned* wait_count = nullptr, unsigned wait_target = 0, bool no_reduce = false) {
     const VjfPlan& P = c->plan;
     const int nsplit = split_for(B);
     VjfGramArgs g{};
@@ -464,6 +470,7 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
     hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(256), 0, st, P, g);
     VJF_HIP(hipGetLastError());
+    if (no_reduce) return 0;                                   // (the consumer sums the slabs itself)
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial)); r.red = red;
     r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask;
@@ -491,6 +498,19 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
     }
     p.bid0 = p.n_rowblk;                                       // clip + SGD and the scalars
     VJF_LAUNCH(vjf_prep_kernel, dim3(p.n_sgdblk + 1), dim3(256), 0, st, stop, P, p);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
+// slab reduce + clip + SGD + scalars in one launch (see vjf_sgd_kernel); the gradient Gram must have run with no_reduce
+int launch_sgd(vjf_ctx* c, int B, int32_t B_total, float* loss4, uint32_t flags, int job0, int njobs, hipStream_t st, int gen) {
+    const VjfPlan& P = c->plan;
+    VjfSgdArgs a{};
+    a.jobs = (const VjfJob*)(c->ws + c->cv.jobs); a.slabs = (const float*)(c->ws + c->cv.slabs);
+    a.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial));
+    a.state = c->state; a.aux = (float*)(c->ws + c->cv.aux); a.loss4 = loss4;
+    a.job0 = job0; a.njobs = njobs; a.nsplit = split_for(B); a.nblocks_k1 = trial_blocks(c, B); a.B_total = B_total; a.flags = flags;
+    hipLaunchKernelGGL(vjf_sgd_kernel, dim3(njobs + 1), dim3(1024), 0, st, P, a);
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -644,7 +664,11 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, (t > 0 && !c->sb_gates) ? pd : nullptr, post_before))) return rc;
         // Cholesky on sb; the post kernel on sc beside it (it takes the columns of L as they appear)
         if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, t == T - 1 ? c->ev_s : nullptr, true, sd))) return rc;
-        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1))) return rc;
+        // (single rank only: the SGD kernel can sum the gradient slabs itself -- 7 us instead of 5 + 7 for reduce + SGD, but the
+        //  step as a whole came out 1 us SLOWER in A/B runs on one box: the forward half then starts earlier and runs
+        //  beside more of the Cholesky kernel.  Off unless VJF_FUSED_SGD is set.)
+        const bool fuse_sgd = !c->comm_a && getenv("VJF_FUSED_SGD") != nullptr;
+        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1, nullptr, 0, fuse_sgd))) return rc;
         if (c->comm_a) {                                                   // sum the gradients and the loss sums over ranks
             VJF_NCCL(nccl().group_start());
             int e1 = nccl().all_reduce(redg, redg, (size_t)P.train_len, kNcclFloat, kNcclSum, c->comm_a, sa);
@@ -653,7 +677,9 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             VJF_NCCL(e1);
             VJF_NCCL(e2);
         }
-        if ((rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa))) return rc;
+        if (fuse_sgd) rc = launch_sgd(c, B, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, ne, ng, sa, t & 1);
+        else rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa);
+        if (rc) return rc;
         if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
     }
     VJF_HIP(hipEventRecord(c->ev_c, sb));

@@ -161,7 +161,7 @@ struct VjfJob {
     int ld;            // kind 1: leading dimension of the weight matrix
     int ncol_w;        // kind 1: columns [0, ncol_w) of the tile are weights, column ncol_w is the bias
     int dst_b;         // kind 1: offset in the grad region of the bias (-1: none)
-    int row_skip;      // kind 1: first row_skip... unused, 0
+    int tw, tb;        // kind 1: rows of the plan's trainable-tensor table that the weight / the bias belong to (tb -1: none)
 };
 
 // OR status bits into the status scalar (a float holding a small integer).  Kernels of one step may run on two
