@@ -210,6 +210,7 @@ struct vjf_ctx {
                            // but then the post kernel cannot be placed before the trial kernel has drained: measured slower)
     bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
                            // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
+    bool prepg_inkernel;   // the RLS operand kernel waits for post(t-1) itself instead of behind a gate kernel
     bool overlap_serial;   // ... same kernels and hand-offs, but enqueued on ONE stream (profilers that serialise kernels)
     hipStream_t stream2, stream3, stream4;
     hipEvent_t ev_a, ev_s, ev_c, ev_d;
@@ -295,7 +296,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->n_ejobs = 0;
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
-    c->overlap_serial = false; c->gate_post = getenv("VJF_GATE_POST") != nullptr; c->sb_gates = getenv("VJF_SB_INKERNEL_WAIT") == nullptr;
+    c->overlap_serial = false; c->gate_post = getenv("VJF_GATE_POST") != nullptr; c->sb_gates = getenv("VJF_SB_INKERNEL_WAIT") == nullptr; c->prepg_inkernel = getenv("VJF_PREPG_INKERNEL") != nullptr;
     c->stream2 = c->stream3 = c->stream4 = nullptr; c->ev_a = c->ev_s = c->ev_c = c->ev_d = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1;
@@ -660,8 +661,9 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             VJF_HIP(hipGetLastError());
         }
         const unsigned* pd = (const unsigned*)((unsigned*)(c->ws + c->cv.flags) + 32);
-        if (c->sb_gates && t > 0) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, pd, post_before, stw);
-        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, (t > 0 && !c->sb_gates) ? pd : nullptr, post_before))) return rc;
+        const bool prepg_waits = !c->sb_gates || c->prepg_inkernel;      // the 13 workgroups of the operand kernel poll themselves
+        if (!prepg_waits && t > 0) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, pd, post_before, stw);
+        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, (t > 0 && prepg_waits) ? pd : nullptr, post_before))) return rc;
         // Cholesky on sb; the post kernel on sc beside it (it takes the columns of L as they appear)
         if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, t == T - 1 ? c->ev_s : nullptr, true, sd))) return rc;
         // (single rank only: the SGD kernel can sum the gradient slabs itself -- 7 us instead of 5 + 7 for reduce + SGD, but the
