@@ -190,6 +190,9 @@ CASES = [
     dict(B=64, dz=6, dy=12, du=0, n=228, hidden=[16], lik="gaussian", T=3),          # just beyond one CU's LDS: multi-launch RLS
     dict(B=40, dz=12, dy=20, du=1, n=500, hidden=[24], lik="poisson", T=2),          # 16 blocks, last one partial
     dict(B=48, dz=4, dy=9, du=0, n=222, hidden=[12], lik="gaussian", T=3),           # n % 4 != 0: single-workgroup serial kernel
+    dict(B=32, dz=20, dy=30, du=0, n=96, hidden=[32], lik="gaussian", T=3),          # 16 < dz <= 32: LDS Cholesky kernel with its own inverse / solve
+    dict(B=24, dz=40, dy=16, du=0, n=64, hidden=[16], lik="gaussian", T=2),          # dz > 32, small n: single-workgroup serial kernel
+    dict(B=20, dz=40, dy=16, du=2, n=260, hidden=[16], lik="poisson", T=2),          # dz > 32, n > 224: multi-launch RLS, wide latent
 ]
 
 

@@ -491,6 +491,13 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
     p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
     p.n_sgdblk = (P.train_len + 1023) / 1024;
     p.wait_count = wait_count; p.wait_target = wait_target;
+    if (which != 2 && P.dz > 16) {                             // (the matrix-core operand kernel holds one 16-column tile of W)
+        p.bid0 = 0;
+        const int grid = which == 1 ? p.n_rowblk : p.n_rowblk + p.n_sgdblk + 1;
+        VJF_LAUNCH(vjf_prep_kernel, dim3(grid), dim3(256), 0, st, stop, P, p);
+        VJF_HIP(hipGetLastError());
+        return 0;
+    }
     if (which != 2) {                                          // RLS operands: g and P += G/v, 16 rows per workgroup
         const size_t lds = vjf_prepg_lds_bytes(P);
         VJF_LAUNCH(vjf_prepg_kernel, dim3((P.n + 15) / 16), dim3(256), lds, st, which == 1 ? stop : (hipEvent_t) nullptr, P, p);

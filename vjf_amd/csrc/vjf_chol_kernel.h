@@ -608,7 +608,8 @@ static inline int vjf_chol_dzp(int dz) { return dz <= 4 ? 4 : dz <= 8 ? 8 : dz <
 static inline size_t vjf_chol_lds_bytes(const VjfPlan& P) {
     const int nbl = (P.n + 31) / 32;
     const size_t blocks = (size_t)(nbl * (nbl + 1) / 2 + nbl) * 1024;
-    return (blocks + (size_t)nbl * 32 * vjf_chol_dzp(P.dz) + 192) * 4;
+    const int dzp = vjf_chol_dzp(P.dz);
+    return (blocks + (size_t)nbl * 32 * dzp * (dzp <= 16 ? 1 : 2) + 192) * 4;   // dzp = 32: y = L^-1 g has a region of its own
 }
 static inline bool vjf_chol_lds_ok(const VjfPlan& P) {
     return (P.n + 31) / 32 <= VJF_CHOL_MAXBLK && P.n % 4 == 0 && P.dz <= 32 && vjf_chol_lds_bytes(P) <= 160 * 1024 - 512;
@@ -644,9 +645,10 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
     float* s_blk = lds;                               // ntri blocks: lower block triangle of P -> L -> L^-1
     float* s_aux = s_blk + (size_t)ntri * 1024;       // nbl blocks: inverted diagonal blocks of L; later scratch
     float* s_g = s_aux + (size_t)nbl * 1024;          // npad x DZP  g, later W
-    float* s_y = s_aux + (size_t)npad * DZP;          // npad x DZP  y = L^-1 g: lives in the upper part of s_aux once the
-                                                      //             inverted diagonal blocks have been copied out (2*npad*DZP <= nbl*1024)
-    int* s_flag = (int*)(s_g + (size_t)npad * DZP);   // [0] ok
+    // npad x DZP  y = L^-1 g: for DZP <= 16 in the upper part of s_aux once the inverted diagonal blocks have been copied out
+    // (2 * npad * DZP <= nbl * 1024); for DZP = 32 that does not hold and y follows g
+    float* s_y = DZP <= 16 ? s_aux + (size_t)npad * DZP : s_g + (size_t)npad * DZP;
+    int* s_flag = (int*)(s_g + (size_t)npad * DZP * (DZP <= 16 ? 1 : 2));   // [0] ok
     double* s_d = (double*)(s_flag + 8);              // 16 doubles for the final reduction
     int* s_bi = s_flag + 64;                          // block-row / block-column of lower block b
     int* s_bj = s_bi + 32;
