@@ -122,15 +122,17 @@ def test_filter_trajectory_golden(vjf, name):
     assert model.status() == 0
 
 
-def test_filter_sequence_equals_steps(vjf):
-    z, info, _ = gio.traj_case("g5_gaussian_du2_wu0_f32")
+@pytest.mark.parametrize("name", ["g5_gaussian_du2_wu0_f32", "g5_medium_poisson_f32", "g5_gaussian_h5x5_f32"])
+def test_filter_sequence_equals_steps(vjf, name):
+    z, info, _ = gio.traj_case(name)
     m1, m2 = _model_for(vjf, info), _model_for(vjf, info)
     load_fixture_state(m1, z, "s0")
     load_fixture_state(m2, z, "s0")
-    mu, lv, loss = m1.filter_sequence(torch.tensor(z["y"]), torch.tensor(z["u"]), None, eps=torch.tensor(z["eps"]))
+    u = torch.tensor(z["u"]) if info["du"] else None
+    mu, lv, loss = m1.filter_sequence(torch.tensor(z["y"]), u, None, eps=torch.tensor(z["eps"]))
     q = None
     for t in range(info["T"]):
-        q, l, *c = m2.filter(torch.tensor(z["y"][t]), torch.tensor(z["u"][t]), q, verbose=True,
+        q, l, *c = m2.filter(torch.tensor(z["y"][t]), None if u is None else u[t], q, verbose=True,
                              eps=(torch.tensor(z["eps"][t, 0]), torch.tensor(z["eps"][t, 1])))
         assert torch.equal(q.mean, mu[t]) and torch.equal(q.logvar, lv[t])      # same kernels, same order: bitwise
         assert torch.equal(torch.stack([l, *c]), loss[t])
