@@ -148,7 +148,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, work, jobs, aux, post, lscr, flags, total;
+    size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -165,6 +165,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.red = take((size_t)P.red_len * 4);
     c.red2 = take((size_t)P.red_len * 4);                  // RLS statistics of even / odd steps in the multi-stream sequence
     c.red3 = take((size_t)P.red_len * 4);
+    c.tbig = take(P.n > 32 * VJF_CHOL_MAXBLK ? (size_t)P.n * P.n * 4 : 16);   // multi-launch RLS: T of the recursive inverse
     c.work = take(vjf_serial_work_floats(P) * 4 + 256);   // + 32 u64 diagnostic stamps
     c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
     c.flags = take(256);                                   // column flags of the Cholesky -> post hand-off (a block of their own)
@@ -746,9 +747,15 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
                     hipLaunchKernelGGL(vjf_rlsb_trail_kernel, dim3(m * (m + 1) / 2), dim3(64), 0, st, P, a);
                 }
             }
-            for (int i = 0; i < nbl; ++i) {
-                a.k = i;
-                hipLaunchKernelGGL(vjf_rlsb_inv_kernel, dim3(i + 1), dim3(64), 0, st, P, a);
+            {   // X = L^-1 by recursive doubling over the inverted diagonal blocks
+                float* T = (float*)(c->ws + c->cv.tbig);
+                hipLaunchKernelGGL(vjf_rlsb_inv_diag_kernel, dim3(64), dim3(256), 0, st, P, a);
+                for (int sb = 1; sb < nbl; sb *= 2) {
+                    const int pairs = (nbl + 2 * sb - 1) / (2 * sb);
+                    VjfRlsbLevel lv{sb};
+                    hipLaunchKernelGGL(vjf_rlsb_inv_t_kernel, dim3(pairs * sb * sb), dim3(64), 0, st, P, a, lv, T);
+                    hipLaunchKernelGGL(vjf_rlsb_inv_x_kernel, dim3(pairs * sb * sb), dim3(64), 0, st, P, a, lv, (const float*)T);
+                }
             }
             hipLaunchKernelGGL(vjf_rlsb_y_kernel, dim3(gx), dim3(256), 0, st, P, a);
             hipLaunchKernelGGL(vjf_rlsb_w_kernel, dim3(gx), dim3(256), 0, st, P, a);

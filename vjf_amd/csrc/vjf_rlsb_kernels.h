@@ -172,6 +172,73 @@ __global__ __launch_bounds__(64) void vjf_rlsb_inv_kernel(VjfPlan P, VjfRlsbArgs
     rlsb_acc_out(x, A.X, n, i, j, lane, false);
 }
 
+// X = L^-1 by recursive doubling instead of block row after block row (nbl dependent launches with up to nbl - 1 chained
+// block products each): with the diagonal blocks inverted, level l joins pairs of 2^l-tile diagonal blocks,
+//     inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]],
+// as two launches of independent tiles:  T = C A^-1  (vjf_rlsb_inv_t_kernel),  X21 = -B^-1 T  (vjf_rlsb_inv_x_kernel).
+// 2 log2(nbl) launches, every tile of a level in parallel.  Tiles of `half` x `half` 32-blocks; workgroup = one output tile.
+struct VjfRlsbLevel { int sb; };      // tiles per half at this level (1, 2, 4, ..)
+__device__ __forceinline__ bool rlsb_level_tile(int nbl, int sb, int t, int& bi, int& bj, int& s0) {
+    // output tiles of a level: for every pair starting at s0 = 2 sb p: rows [s0 + sb, min(s0 + 2 sb, nbl)), columns [s0, s0 + sb)
+    const int per = sb * sb, p = t / per, r = t - p * per;
+    s0 = 2 * sb * p;
+    bi = s0 + sb + r / sb;
+    bj = s0 + r % sb;
+    return bi < nbl;
+}
+__global__ __launch_bounds__(64) void vjf_rlsb_inv_t_kernel(VjfPlan P, VjfRlsbArgs A, VjfRlsbLevel Lv, float* T) {
+    __shared__ __attribute__((aligned(16))) float s_l[1024], s_x[1024];
+    if (A.ok[0] == 0) return;
+    const int n = P.n, nbl = (n + 31) / 32, lane = threadIdx.x;
+    int bi, bj, s0;
+    if (!rlsb_level_tile(nbl, Lv.sb, blockIdx.x, bi, bj, s0)) return;
+    vjf_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = bj; k < s0 + Lv.sb; ++k) {                     // T_ij = sum_k L_ik X_kj, X11 block-lower: k >= bj
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = lane + 64 * q, r = e >> 5, c = e & 31;
+            const int li = bi * 32 + r, lj = k * 32 + c, xi = k * 32 + r, xj = bj * 32 + c;
+            s_l[vsw(r, c)] = (li < n && lj < n) ? A.Lw[(size_t)li * n + lj] : 0.f;
+            s_x[vsw(r, c)] = (xi < n && xj < n) ? A.X[(size_t)xi * n + xj] : 0.f;
+        }
+        blk_mma<false>(acc, s_l, s_x, 1.f, lane);
+    }
+    rlsb_acc_out(acc, T, n, bi, bj, lane, false);
+}
+__global__ __launch_bounds__(64) void vjf_rlsb_inv_x_kernel(VjfPlan P, VjfRlsbArgs A, VjfRlsbLevel Lv, const float* T) {
+    __shared__ __attribute__((aligned(16))) float s_l[1024], s_x[1024];
+    if (A.ok[0] == 0) return;
+    const int n = P.n, nbl = (n + 31) / 32, lane = threadIdx.x;
+    int bi, bj, s0;
+    if (!rlsb_level_tile(nbl, Lv.sb, blockIdx.x, bi, bj, s0)) return;
+    vjf_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = s0 + Lv.sb; k <= bi; ++k) {                    // X_ij = - sum_k X22_ik T_kj, X22 block-lower: k <= bi
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = lane + 64 * q, r = e >> 5, c = e & 31;
+            const int xi = bi * 32 + r, xj = k * 32 + c, ti = k * 32 + r, tj = bj * 32 + c;
+            s_l[vsw(r, c)] = (xi < n && xj < n) ? A.X[(size_t)xi * n + xj] : 0.f;
+            s_x[vsw(r, c)] = (ti < n && tj < n) ? T[(size_t)ti * n + tj] : 0.f;
+        }
+        blk_mma<false>(acc, s_l, s_x, -1.f, lane);
+    }
+    rlsb_acc_out(acc, A.X, n, bi, bj, lane, false);
+}
+// X_ii = L_ii^-1 for every diagonal block (the base of the recursion)
+__global__ __launch_bounds__(256) void vjf_rlsb_inv_diag_kernel(VjfPlan P, VjfRlsbArgs A) {
+    if (A.ok[0] == 0) return;
+    const int n = P.n, nbl = (n + 31) / 32;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nbl * 1024; e += gridDim.x * 256) {
+        const int b = e >> 10, r = (e >> 5) & 31, c = e & 31;
+        const int gi = b * 32 + r, gj = b * 32 + c;
+        if (gi < n && gj < n) A.X[(size_t)gi * n + gj] = A.Dinv[e];
+    }
+}
+
 // y = X g  (X block-lower: columns of row r up to the end of its diagonal block)
 __global__ __launch_bounds__(256) void vjf_rlsb_y_kernel(VjfPlan P, VjfRlsbArgs A) {
     if (A.ok[0] == 0) return;
