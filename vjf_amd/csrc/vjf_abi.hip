@@ -22,6 +22,7 @@
 #include "vjf_serial_kernel.h"
 #include "vjf_trial_kernel.h"
 #include "vjf_trial_mfma_kernel.h"
+#include "vjf_trial_wide.h"
 
 namespace {
 
@@ -148,7 +149,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, work, jobs, aux, post, lscr, flags, total;
+    size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -166,6 +167,8 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.red2 = take((size_t)P.red_len * 4);                  // RLS statistics of even / odd steps in the multi-stream sequence
     c.red3 = take((size_t)P.red_len * 4);
     c.tbig = take(P.n > 32 * VJF_CHOL_MAXBLK ? (size_t)P.n * P.n * 4 : 16);   // multi-launch RLS: T of the recursive inverse
+    // GEMM-per-layer trial path (working set beyond LDS): [xs|u], pt.mean, pt.logvar, decoder output, Phi w_chol per trial
+    c.wide = take(vjf_trial_mfma_lds_floats(P) * 4 > kMaxLds - 1024 ? (size_t)max_batch * (P.dxu + P.dz + 1 + P.dy + P.n) * 4 + 1024 : 16);
     c.work = take(vjf_serial_work_floats(P) * 4 + 256);   // + 32 u64 diagnostic stamps
     c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
     c.flags = take(256);                                   // column flags of the Cholesky -> post hand-off (a block of their own)
@@ -433,7 +436,7 @@ VjfTrialArgs trial_args(vjf_ctx* c, int32_t B, const float* y, const float* u, c
     return a;
 }
 
-int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16 : (B + c->TB - 1) / c->TB; }
+int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16 : (B + 3) / 4; }   // (wide path: 4 trials per loss workgroup)
 
 // K1.  part: 0 whole step, 1 forward half, 2 backward half (matrix-core kernel only)
 int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hipEvent_t stop = nullptr, bool count_fwd = false) {
@@ -448,11 +451,46 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
         m.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
         VJF_LAUNCH(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, stop, P, m);
     } else {
-        switch (c->TB) {
-            case 16: hipLaunchKernelGGL(vjf_trial_kernel<16>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, st, P, a); break;
-            case 8: hipLaunchKernelGGL(vjf_trial_kernel<8>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, st, P, a); break;
-            default: hipLaunchKernelGGL(vjf_trial_kernel<4>, dim3(nblk), dim3(VJF_K1_THREADS), c->lds_k1, st, P, a); break;
+        // working set beyond LDS: one GEMM over all trials per layer (vjf_trial_wide.h)
+        VjfWideArgs w{};
+        w.t = a;
+        float* wb = (float*)(c->ws + c->cv.wide);
+        const size_t Bz = (size_t)a.B;
+        w.XU = wb; w.PM = w.XU + Bz * P.dxu; w.PLV = w.PM + Bz * P.dz; w.PY = w.PLV + ((Bz + 3) / 4) * 4; w.Z = w.PY + Bz * P.dy;
+        const float* S = c->state;
+        auto gemm = [&](const float* A_, int lda, const float* Bm, int ldb, float* C_, int ldc, int N, int K, int nt, int epi,
+                        const float* bias = nullptr, const float* src = nullptr, int lds = 0) {
+            VjfWideGemm g{};
+            g.A = A_; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.C = C_; g.ldc = ldc; g.M = a.B; g.N = N; g.K = K; g.nt = nt; g.epi = epi;
+            g.bias = bias; g.src = src; g.lds = lds; g.eps_t = a.eps_t; g.lv_t = a.lv_t;
+            hipLaunchKernelGGL(vjf_wide_gemm_kernel, dim3((N + 63) / 64, (a.B + 63) / 64), dim3(256), 0, st, g);
+        };
+        const int gx = 1024;
+        hipLaunchKernelGGL(vjf_wide_in_kernel, dim3(gx), dim3(256), 0, st, P, w);
+        hipLaunchKernelGGL(vjf_wide_rbf_kernel, dim3((P.n + 255) / 256, (a.B + 15) / 16), dim3(256), (size_t)16 * P.dxu * 4, st, P, w);
+        int kin = P.din;
+        for (int l = 0; l < P.L; ++l) {                            // h_l = tanh(h_{l-1} W_l^T + b_l)   (recognition.py:31-36)
+            gemm(a.ACT + P.colA_act[l], P.ldA, S + P.off[VJF_SLOT_REC_W0 + 2 * l], kin, a.ACT + P.colA_act[l + 1], P.ldA, P.h[l], kin, 1,
+                 WEPI_TANH_BIAS, S + P.off[VJF_SLOT_REC_B0 + 2 * l]);
+            kin = P.h[l];
         }
+        gemm(a.ACT + P.colA_act[P.L], P.ldA, S + P.off[VJF_SLOT_MEAN_W], kin, a.mu_t, P.dz, P.dz, kin, 1, WEPI_NONE);
+        gemm(a.ACT + P.colA_act[P.L], P.ldA, S + P.off[VJF_SLOT_LV_W], kin, a.lv_t, P.dz, P.dz, kin, 1, WEPI_BIAS, S + P.off[VJF_SLOT_LV_B]);
+        hipLaunchKernelGGL(vjf_wide_mid_kernel, dim3(gx), dim3(256), 0, st, P, w);
+        gemm(a.ACT + P.colA_xt, P.ldA, S + P.off[VJF_SLOT_DEC_W], P.dz, w.PY, P.dy, P.dy, P.dz, 1, WEPI_BIAS, S + P.off[VJF_SLOT_DEC_B]);
+        gemm(a.E, P.ldE, S + P.off[VJF_SLOT_W_MEAN], P.dz, w.PM, P.dz, P.dz, P.n, 0, WEPI_ADD_SRC, nullptr, w.XU, P.dxu);
+        gemm(a.E, P.ldE, S + P.off[VJF_SLOT_W_CHOL], P.n, w.Z, P.n, P.n, P.n, 0, WEPI_NONE);
+        hipLaunchKernelGGL(vjf_wide_rownorm_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, P, w);
+        hipLaunchKernelGGL(vjf_wide_loss_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, P, w);
+        // backward: dxt = dpy C into dmu / dlv; dh_L = dmu Wm + dlv Wl; da_l = (da_{l+1} W_{l+1}) (1 - h_l^2)
+        gemm(a.DEL + P.colD_dpy, P.ldD, S + P.off[VJF_SLOT_DEC_W], P.dz, a.DEL + P.colD_dmu, P.ldD, P.dz, P.dy, 0, WEPI_SEED);
+        const int hL = P.h[P.L - 1];
+        gemm(a.DEL + P.colD_dmu, P.ldD, S + P.off[VJF_SLOT_MEAN_W], hL, a.DEL + P.colD_da[P.L - 1], P.ldD, hL, P.dz, 0, WEPI_NONE);
+        gemm(a.DEL + P.colD_dlv, P.ldD, S + P.off[VJF_SLOT_LV_W], hL, a.DEL + P.colD_da[P.L - 1], P.ldD, hL, P.dz, 0, WEPI_ADDC_DTANH, nullptr,
+             a.ACT + P.colA_act[P.L], P.ldA);
+        for (int l = P.L - 1; l >= 1; --l)
+            gemm(a.DEL + P.colD_da[l], P.ldD, S + P.off[VJF_SLOT_REC_W0 + 2 * l], P.h[l - 1], a.DEL + P.colD_da[l - 1], P.ldD, P.h[l - 1], P.h[l], 0,
+                 WEPI_DTANH, nullptr, a.ACT + P.colA_act[l], P.ldA);
     }
     VJF_HIP(hipGetLastError());
     return 0;
