@@ -462,7 +462,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
                         const float* bias = nullptr, const float* src = nullptr, int lds = 0) {
             VjfWideGemm g{};
             g.A = A_; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.C = C_; g.ldc = ldc; g.M = a.B; g.N = N; g.K = K; g.nt = nt; g.epi = epi;
-            g.bias = bias; g.src = src; g.lds = lds; g.eps_t = a.eps_t; g.lv_t = a.lv_t;
+            g.bias = bias; g.src = src; g.lds = lds; g.src_scale = 1.f; g.eps_t = a.eps_t; g.lv_t = a.lv_t;
             hipLaunchKernelGGL(vjf_wide_gemm_kernel, dim3((N + 63) / 64, (a.B + 63) / 64), dim3(256), 0, st, g);
         };
         const int gx = 1024;
@@ -775,6 +775,14 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
         const bool rls = !(flags & VJF_FLAG_WARM_UP);
         if (rls) {
             const int gx = 512;
+            auto gemm = [&](const float* A_, int lda, int ta, const float* Bm, int ldb, float* C_, int ldc, int M, int N, int K, const int* ok) {
+                VjfWideGemm g{};
+                g.A = A_; g.lda = lda; g.ta = ta; g.Bm = Bm; g.ldb = ldb; g.C = C_; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.nt = 0;
+                g.epi = WEPI_NONE; g.ok = ok;
+                hipLaunchKernelGGL(vjf_wide_gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
+            };
+            const float* Sx = c->state;
+            gemm(Sx + P.off[VJF_SLOT_W_PREC], P.n, 0, Sx + P.off[VJF_SLOT_W_MEAN], P.dz, a.gbuf, P.dz, P.n, P.dz, P.n, nullptr);   // P W
             hipLaunchKernelGGL(vjf_rlsb_prep_kernel, dim3(gx), dim3(256), 0, st, P, a);
             for (int k = 0; k < nbl; ++k) {
                 a.k = k;
@@ -785,8 +793,9 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
                     hipLaunchKernelGGL(vjf_rlsb_trail_kernel, dim3(m * (m + 1) / 2), dim3(64), 0, st, P, a);
                 }
             }
-            {   // X = L^-1 by recursive doubling over the inverted diagonal blocks
+            {   // X = L^-1 by recursive doubling over the inverted diagonal blocks (block-upper part: zero)
                 float* T = (float*)(c->ws + c->cv.tbig);
+                VJF_HIP(hipMemsetAsync(a.X, 0, (size_t)P.n * P.n * 4, st));
                 hipLaunchKernelGGL(vjf_rlsb_inv_diag_kernel, dim3(64), dim3(256), 0, st, P, a);
                 for (int sb = 1; sb < nbl; sb *= 2) {
                     const int pairs = (nbl + 2 * sb - 1) / (2 * sb);
@@ -795,8 +804,8 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
                     hipLaunchKernelGGL(vjf_rlsb_inv_x_kernel, dim3(pairs * sb * sb), dim3(64), 0, st, P, a, lv, (const float*)T);
                 }
             }
-            hipLaunchKernelGGL(vjf_rlsb_y_kernel, dim3(gx), dim3(256), 0, st, P, a);
-            hipLaunchKernelGGL(vjf_rlsb_w_kernel, dim3(gx), dim3(256), 0, st, P, a);
+            gemm(a.X, P.n, 0, a.gbuf, P.dz, a.ybuf, P.dz, P.n, P.dz, P.n, a.ok);                                      // y = X g
+            gemm(a.X, P.n, 1, a.ybuf, P.dz, c->state + P.off[VJF_SLOT_W_MEAN], P.dz, P.n, P.dz, P.n, a.ok);          // W = X^T y
             hipLaunchKernelGGL(vjf_rlsb_final_kernel, dim3(gx), dim3(256), 0, st, P, a);
             VJF_HIP(hipGetLastError());
         }

@@ -3,12 +3,12 @@
 // LDS-resident kernels, but with the matrix in global memory (L2-resident: 4 MB at n = 1000) and one launch per phase,
 // so that the trailing updates and the block rows of the inverse spread over the whole chip.
 //
-//   vjf_rlsb_prep_kernel    g = P W + Phi^T dx / v (module.py:94);  A := P + Phi^T Phi / v into a work buffer (module.py:96)
+//   GEMM + vjf_rlsb_prep_kernel   g = P W + Phi^T dx / v (module.py:94);  A := P + Phi^T Phi / v into a work buffer (module.py:96)
 //   per block column k:     vjf_rlsb_diag_kernel   L_kk, L_kk^-1      (one wavefront: the rank-2 column chain)
 //                           vjf_rlsb_panel_kernel  L_ik = A_ik L_kk^-T (one wavefront per block)
 //                           vjf_rlsb_trail_kernel  A_ij -= L_ik L_jk^T (one wavefront per lower block)
 //   per block row i:        vjf_rlsb_inv_kernel    X_ij = -L_ii^-1 sum_k L_ik X_kj   (X = L^-1, module.py:102)
-//   vjf_rlsb_y_kernel, vjf_rlsb_w_kernel   y = X g,  W = X^T y                      (module.py:101)
+//   two GEMMs (vjf_wide_gemm_kernel)        y = X g,  W = X^T y                      (module.py:101)
 //   vjf_rlsb_final_kernel   w_chol = X^T, w_pchol = L, P += Phi^T Phi / v -- or, after a failed pivot, nothing but the status
 // All block products on v_mfma_f32_32x32x2_f32 through the helpers of vjf_chol_kernel.h.  Matrices are padded to a
 // multiple of 32 with the identity on the fly (loads) and never stored outside n x n.
@@ -53,18 +53,12 @@ __global__ __launch_bounds__(256) void vjf_rlsb_prep_kernel(VjfPlan P, VjfRlsbAr
     float* S = A.state;
     const float inv_v = expf(-S[P.off[VJF_SLOT_TR_LOGVAR]]);
     const float* Pm = S + P.off[VJF_SLOT_W_PREC];
-    const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
     float* Lm = A.Lw;
     const float* G = A.red + P.red_G;
     const float* FDX = A.red + P.red_FDX;
     const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
     if (gid == 0) A.ok[0] = 1;
-    for (int e = gid; e < n * dz; e += gsz) {
-        const int i = e / dz, j = e - i * dz;
-        float acc = 0.f;
-        for (int k = 0; k < n; ++k) acc = fmaf(Pm[(size_t)i * n + k], Wm[(size_t)k * dz + j], acc);
-        A.gbuf[e] = acc + FDX[e] * inv_v;
-    }
+    for (int e = gid; e < n * dz; e += gsz) A.gbuf[e] = A.gbuf[e] + FDX[e] * inv_v;   // gbuf holds P W (the GEMM before this kernel)
     for (int e = gid; e < n * n; e += gsz) Lm[e] = Pm[e] + G[e] * inv_v;
 }
 

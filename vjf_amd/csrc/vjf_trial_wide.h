@@ -19,16 +19,20 @@ struct VjfWideGemm {
     const float* Bm; int ldb;      // nt: (N, K) row-major [a torch Linear weight]; else (K, N) row-major
     float* C; int ldc;             // (M, N)
     int M, N, K, nt, epi;
+    int ta;                        // 1: A is given transposed, (K, M) row-major
+    float src_scale;               // WEPI_ADD_SRC: C = acc + src_scale * src
     const float* bias;             // WEPI_BIAS / WEPI_TANH_BIAS: [N]
     const float* src; int lds;     // WEPI_ADD_SRC: added;  WEPI_DTANH / WEPI_ADDC_DTANH: h of (1 - h^2)
     // WEPI_SEED (dxt = dpy C):  dmu += dxt;  dlv += dxt * eps_t * exp(lv_t / 2) / 2   (C -> dmu, C + N -> dlv; ldc = ldD)
     const float* eps_t; const float* lv_t;
+    const int* ok;                 // non-null: nothing is done when ok[0] == 0 (the RLS path after a failed factorisation)
 };
 
 #define VJF_WG_KC 16
 __global__ __launch_bounds__(256) void vjf_wide_gemm_kernel(VjfWideGemm g) {
     __shared__ float s_a[64][VJF_WG_KC + 1];
     __shared__ float s_b[VJF_WG_KC][64 + 1];
+    if (g.ok && g.ok[0] == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int wr = wave >> 1, wc = wave & 1;
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(256) void vjf_wide_gemm_kernel(VjfWideGemm g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k = k0 + kq + q;
-                s_a[row][kq + q] = (m < g.M && k < g.K) ? g.A[(size_t)m * g.lda + k] : 0.f;
+                s_a[row][kq + q] = (m < g.M && k < g.K) ? (g.ta ? g.A[(size_t)k * g.lda + m] : g.A[(size_t)m * g.lda + k]) : 0.f;
             }
         }
         if (g.nt) {   // B chunk from (N, K): 64 n x 16 k
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void vjf_wide_gemm_kernel(VjfWideGemm g) {
         switch (g.epi) {
             case WEPI_BIAS: v += g.bias[n]; break;
             case WEPI_TANH_BIAS: v = tanhf(v + g.bias[n]); break;
-            case WEPI_ADD_SRC: v += g.src[(size_t)m * g.lds + n]; break;
+            case WEPI_ADD_SRC: v = fmaf(g.src_scale, g.src[(size_t)m * g.lds + n], v); break;
             case WEPI_DTANH: { const float hv = g.src[(size_t)m * g.lds + n]; v *= (1.f - hv * hv); break; }
             case WEPI_ADDC_DTANH: { const float hv = g.src[(size_t)m * g.lds + n]; v = (*c + v) * (1.f - hv * hv); break; }
             case WEPI_SEED: {
