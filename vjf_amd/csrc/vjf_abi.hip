@@ -198,8 +198,7 @@ struct vjf_ctx {
     hipStream_t stream;
     Carve cv;
     int njobs;
-    int TB;
-    size_t lds_k1, lds_k2;
+    size_t lds_k2;
     bool post_kernels;     // RLS tail (inverse, solve, residual) on many CUs after the Cholesky kernel
     size_t lds_post;
     bool mfma_trial;       // 16 trials' working set fits LDS: matrix-core trial kernel
@@ -274,10 +273,6 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     Carve cv = carve_ws(P, cfg->max_batch, (int)jobs.size());
     if ((int64_t)cv.total > workspace_bytes)
         return fail(-9, "vjf_ctx_create: workspace too small (%lld < %zu bytes)", (long long)workspace_bytes, cv.total);
-    int TB = 0;
-    for (int t : {16, 8, 4})
-        if (vjf_trial_lds_floats(P, t) * 4 <= kMaxLds - 1024) { TB = t; break; }
-    if (!TB) return fail(-10, "vjf_ctx_create: per-trial working set does not fit LDS (dims too large)");
     const size_t lds_k2 = vjf_serial_lds_floats(P) * 4;
     const bool fast_chol = vjf_chol_lds_ok(P);
     if (!fast_chol && lds_k2 > kMaxLds - 1024)
@@ -286,8 +281,8 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     vjf_ctx* c = new (std::nothrow) vjf_ctx();
     if (!c) return fail(-12, "vjf_ctx_create: out of host memory");
     c->cfg = *cfg; c->plan = P; c->state = state; c->ws = (char*)workspace; c->ws_bytes = workspace_bytes;
-    c->stream = (hipStream_t)stream; c->cv = cv; c->njobs = (int)jobs.size(); c->TB = TB;
-    c->lds_k1 = vjf_trial_lds_floats(P, TB) * 4; c->lds_k2 = lds_k2;
+    c->stream = (hipStream_t)stream; c->cv = cv; c->njobs = (int)jobs.size();
+    c->lds_k2 = lds_k2;
     c->fast_chol = fast_chol; c->lds_chol = vjf_chol_lds_bytes(P); c->stamps = false; c->stamps_keep_overlap = false;
     c->lds_post = vjf_post_lds_bytes(P);
     c->post_kernels = fast_chol && P.dz <= 16 && c->lds_post <= kMaxLds - 1024;
@@ -311,7 +306,6 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.flags, 0, 256, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs` (host) must outlive the copy
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
-    allow_lds(vjf_trial_kernel<16>, c->lds_k1); allow_lds(vjf_trial_kernel<8>, c->lds_k1); allow_lds(vjf_trial_kernel<4>, c->lds_k1);
     allow_lds(vjf_serial_kernel, c->lds_k2);
     allow_lds(vjf_rls_post_kernel, c->lds_post);
     allow_lds(vjf_prepg_kernel, vjf_prepg_lds_bytes(P));
