@@ -27,7 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CFG = dict(B=4096, dz=10, dy=50, du=0, n=200, hidden=[128], lik="gaussian")
+CFG = dict(B=4096, dz=10, dy=50, du=0, n=200, hidden=[128], lik="gaussian")     # BASELINE.json configs[1]: the headline workload
+OTHER_CFGS = {"C": dict(B=4096, dz=10, dy=200, du=0, n=200, hidden=[128], lik="poisson"),          # configs[2]
+              "E": dict(B=4096, dz=64, dy=512, du=0, n=1000, hidden=[512, 512], lik="gaussian")}   # configs[4]
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 vector == f32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic_current.json")   # tools/pmc_traffic.sh on this build
@@ -64,6 +66,8 @@ def synth_data(c, T, seed, device):
         d2 = torch.cdist(x, cen) ** 2
         x = x + torch.exp(-0.5 * d2 / w2) @ Wt + 0.1 * torch.randn(B, dz, device=device, generator=gd)
         y[t] = x @ C + d + 0.1 * torch.randn(B, dy, device=device, generator=gd)
+    if c["lik"] == "poisson":                                   # spike counts with log-rate = the linear read-out (clamped)
+        y = torch.poisson(torch.exp(torch.clamp(0.5 * y - 1.0, max=3.0)), generator=gd)
     return y
 
 
@@ -112,6 +116,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown-steps", type=int, default=20)
     ap.add_argument("--no-overlap", action="store_true", help="one-stream order inside filter_sequence (A/B of the schedule)")
+    ap.add_argument("--config", default="B", choices=sorted(OTHER_CFGS) + ["B"],
+                    help="B: the headline workload (BASELINE configs[1]); C / E: configs[2] / [4], extra lines, not the headline")
     ap.add_argument("--serial-schedule", action="store_true",
                     help="the multi-stream schedule's kernels on ONE stream: use under rocprofv3 --pmc, which serialises kernels")
     ap.add_argument("--force-dist", action="store_true",
@@ -137,8 +143,10 @@ def main():
 
     import vjf_amd
     from vjf_amd import _native as N
-    c = dict(CFG)
+    c = dict(CFG if a.config == "B" else OTHER_CFGS[a.config])
     K, W = a.steps, a.warmup
+    if a.config == "E" and a.steps == 500:
+        K, W = 40, 5                                            # ms-scale steps: keep the default run short
     T = W + K
     torch.manual_seed(0)                                       # identical parameters on every rank
     model = vjf_amd.VJF.make_model(c["dy"], c["dz"], c["du"], c["n"], c["hidden"], likelihood=c["lik"], noise="device")
@@ -228,8 +236,8 @@ def main():
             "metric": "trial-timesteps/sec", "value": value, "unit": "trial-timesteps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": wall_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: VJF.filter, 4096 trials/GPU, d_z=10, d_y=50, RBF(200), "
-                                   "hidden=[128], Gaussian likelihood, sgd+update, explicit noise",
+            "config": {"workload": (f"BASELINE configs[{dict(B=1, C=2, E=4)[a.config]}]: VJF.filter, {c['B']} trials/GPU, d_z={c['dz']}, d_y={c['dy']}, "
+                                    f"RBF({c['n']}), hidden={c['hidden']}, {c['lik'].capitalize()} likelihood, sgd+update, explicit noise"),
                        "global_batch": c["B"] * world, "trials_per_gpu": c["B"], "parallelism": f"trial-shard x{world}"},
             "elbo": elbo, "status_bits": status,
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
