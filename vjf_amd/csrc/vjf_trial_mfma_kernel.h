@@ -91,7 +91,11 @@ struct VjfTrialMfmaArgs {
     } while (0)
 
 static inline size_t vjf_trial_mfma_lds_floats(const VjfPlan& P) {
-    const size_t feat = (size_t)P.din + P.dxu + P.n + P.hsum + 2 * (size_t)P.hmax + 8 * (size_t)P.dz + 2 * (size_t)P.dy;
+    // Wide observations (dy >= hmax): the first delta buffer lives in the (by then dead) decoder-mean rows and the
+    // second one exists only for networks with more than one hidden layer -- two workgroups per CU at dy = 200.
+    const bool compact = P.dy >= P.hmax;
+    const size_t nd = compact ? (P.L > 1 ? 1 : 0) : 2;
+    const size_t feat = (size_t)P.din + P.dxu + P.n + P.hsum + nd * (size_t)P.hmax + 8 * (size_t)P.dz + 2 * (size_t)P.dy;
     return feat * VJF_LDT + 16 * RS_N + VJF_K1M_WAVES * 16 + 16 + 64;
 }
 
@@ -115,9 +119,9 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     float* s_xu = s_in + din * LD;               // dxu   [xs | u]
     float* s_phi = s_xu + dxu * LD;              // n
     float* s_act = s_phi + n * LD;               // hsum  hidden activations, layer after layer
-    float* s_d0 = s_act + P.hsum * LD;           // hmax  deltas (ping)
-    float* s_d1 = s_d0 + P.hmax * LD;            // hmax  deltas (pong)
-    float* s_mu = s_d1 + P.hmax * LD;            // dz    mu_t
+    const bool compact = dy >= P.hmax;           // see vjf_trial_mfma_lds_floats
+    float* s_dd = s_act + P.hsum * LD;           // hmax  deltas (ping), hmax deltas (pong) unless compact
+    float* s_mu = s_dd + (compact ? (P.L > 1 ? 1 : 0) : 2) * P.hmax * LD;   // dz    mu_t
     float* s_lv = s_mu + dz * LD;                // dz    lv_t   (directly after s_mu: the heads write 2dz rows)
     float* s_xt = s_lv + dz * LD;                // dz
     float* s_e2 = s_xt + dz * LD;                // dz    eps_t
@@ -127,6 +131,8 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     float* s_dxt = s_dlv + dz * LD;              // dz
     float* s_py = s_dxt + dz * LD;               // dy
     float* s_dpy = s_py + dy * LD;               // dy
+    float* s_d0 = compact ? s_py : s_dd;         // compact: written only after the losses have consumed s_py
+    float* s_d1 = compact ? s_dd : s_dd + P.hmax * LD;   // used only when n_hidden > 1
     float* s_sc = s_dpy + dy * LD;               // 16 x RS_N per-trial scalars
     float* s_red = s_sc + 16 * RS_N;             // 4 x 16 variance partials
     float* s_plv = s_red + 16 * NW;              // 16 pt.logvar
@@ -171,9 +177,9 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         // centroids and -1/(2 w^2) staged in LDS (the delta buffers are free until the backward pass)
         const float* cen = S + P.off[VJF_SLOT_CENTROID];
         const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
-        float* s_cen = s_d0;                       // n * dxu + n floats needed; available: 2 * hmax * 17
+        float* s_cen = s_d0;                       // n * dxu + n floats needed; available: 2 * hmax * 17, or s_py + s_dpy
         float* s_iw = s_cen + n * dxu;
-        const bool stage_c = (n * dxu + n) <= 2 * P.hmax * LD;
+        const bool stage_c = (n * dxu + n) <= 2 * (compact ? dy : P.hmax) * LD;
         if (stage_c) {
             for (int e = tid; e < n * dxu; e += VJF_K1M_THREADS) s_cen[e] = cen[e];
             for (int e = tid; e < n; e += VJF_K1M_THREADS) { const float w = expf(lw[e]); s_iw[e] = -0.5f / (w * w); }
