@@ -213,6 +213,8 @@ struct vjf_ctx {
                            // but then the post kernel cannot be placed before the trial kernel has drained: measured slower)
     bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
                            // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
+    bool k1_inkernel;      // the trial kernel's backward half waits for post(t-1) itself, behind its reloads (default), instead of
+                           // starting behind a gate kernel (VJF_K1_GATE)
     bool prepg_inkernel;   // the RLS operand kernel waits for post(t-1) itself instead of behind a gate kernel
     bool overlap_serial;   // ... same kernels and hand-offs, but enqueued on ONE stream (profilers that serialise kernels)
     hipStream_t stream2, stream3, stream4;
@@ -296,6 +298,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
     c->overlap_serial = false; c->gate_post = getenv("VJF_GATE_POST") != nullptr; c->sb_gates = getenv("VJF_SB_INKERNEL_WAIT") == nullptr; c->prepg_inkernel = getenv("VJF_PREPG_INKERNEL") != nullptr;
+    c->k1_inkernel = getenv("VJF_K1_GATE") == nullptr;
     c->stream2 = c->stream3 = c->stream4 = nullptr; c->ev_a = c->ev_s = c->ev_c = c->ev_d = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1;
@@ -433,12 +436,14 @@ VjfTrialArgs trial_args(vjf_ctx* c, int32_t B, const float* y, const float* u, c
 int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16 : (B + 3) / 4; }   // (wide path: 4 trials per loss workgroup)
 
 // K1.  part: 0 whole step, 1 forward half, 2 backward half (matrix-core kernel only)
-int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hipEvent_t stop = nullptr, bool count_fwd = false) {
+int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hipEvent_t stop = nullptr, bool count_fwd = false,
+                 const unsigned* rls_done = nullptr, unsigned rls_target = 0) {
     const VjfPlan& P = c->plan;
     const int nblk = trial_blocks(c, a.B);
     if (c->mfma_trial) {
         VjfTrialMfmaArgs m{};
         m.t = a; m.aux = (const float*)(c->ws + c->cv.aux); m.part = part;
+        m.rls_done = rls_done; m.rls_target = rls_target;
         m.done = (unsigned*)(c->ws + c->cv.flags) + 16;
         if (part != 1) c->k1_count += (unsigned)nblk;
         if (part == 1 && count_fwd) { m.fwd_done = (unsigned*)(c->ws + c->cv.flags) + 48; c->fwd_count += (unsigned)nblk; }
@@ -508,14 +513,15 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial)); r.red = red;
     r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask;
-    VJF_LAUNCH(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(256), 0, st, stop, P, r);
+    VJF_LAUNCH(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(VJF_REDUCE_THREADS), 0, st, stop, P, r);
     VJF_HIP(hipGetLastError());
     return 0;
 }
 
 // which: 0 whole prep grid, 1 RLS operand rows only, 2 SGD + scalars only
 int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const float* red, int which, hipStream_t st,
-                hipEvent_t stop = nullptr, const unsigned* wait_count = nullptr, unsigned wait_target = 0) {
+                hipEvent_t stop = nullptr, const unsigned* wait_count = nullptr, unsigned wait_target = 0,
+                const unsigned* run_word = nullptr, unsigned run_epoch = 0, const unsigned* start_count = nullptr, unsigned start_target = 0) {
     const VjfPlan& P = c->plan;
     VjfPrepArgs p{};
     p.state = c->state; p.red = red; p.gbuf = (float*)(c->ws + c->cv.work);
@@ -524,6 +530,7 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
     p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
     p.n_sgdblk = (P.train_len + 1023) / 1024;
     p.wait_count = wait_count; p.wait_target = wait_target;
+    p.run_word = run_word; p.run_epoch = run_epoch; p.start_count = start_count; p.start_target = start_target;
     if (which != 2 && P.dz > 16) {                             // (the matrix-core operand kernel holds one 16-column tile of W)
         p.bid0 = 0;
         const int grid = which == 1 ? p.n_rowblk : p.n_rowblk + p.n_sgdblk + 1;
@@ -597,7 +604,7 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
             pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.lscr = a.lscr;
             pa.flags = colflags; pa.epoch = a.epoch; pa.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
             pa.k1_done = c->mfma_trial ? colflags + 16 : nullptr; pa.k1_target = c->k1_count;
-            pa.done = colflags + 32; c->post_count += (unsigned)(2 * nbl + 1);
+            pa.done = colflags + 32; pa.started = colflags + 24; c->post_count += (unsigned)(2 * nbl + 1);
             pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
             if (st_inv && st_inv != st_post) {
                 // two launches: the inverse workgroups keep one column of L in LDS and share their CUs with the trial kernel;
@@ -685,14 +692,17 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         if (c->comm_b)                                                     // trials are sharded over ranks: sum [G | FDX | sums]
             VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum,
                                        c->comm_b, sb));
-        if (t > 0) {
-            // backward half(t) and P += G/v, g (t) read W, w_chol, sigma of step t-1: a gate kernel on each stream ends when
-            // every workgroup of post(t-1) has its outputs in memory
-            unsigned* pdone = (unsigned*)(c->ws + c->cv.flags) + 32;
-            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sa, (const unsigned*)pdone, c->post_count, stw);
+        // backward half(t) and P += G/v, g (t) read W, w_chol, sigma of step t-1, ready when every workgroup of post(t-1) has
+        // its outputs in memory: the backward half waits for that count itself, behind the reloads of its forward half's rows
+        // (or starts behind a gate kernel: VJF_K1_GATE)
+        const unsigned* pdone = (const unsigned*)((unsigned*)(c->ws + c->cv.flags) + 32);
+        const bool fuse_sgd = !c->comm_a && getenv("VJF_FUSED_SGD") != nullptr;   // (see below)
+        const bool k1_waits = c->k1_inkernel && c->mfma_trial && !c->overlap_serial && !fuse_sgd;
+        if (t > 0 && !k1_waits) {
+            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sa, pdone, c->post_count, stw);
             VJF_HIP(hipGetLastError());
         }
-        if ((rc = launch_trial(c, args(t), 2, sa))) return rc;
+        if ((rc = launch_trial(c, args(t), 2, sa, nullptr, false, (t > 0 && k1_waits) ? pdone : nullptr, c->post_count))) return rc;
         if (t == 0) {
             // the post kernel writes only the block-upper half of w_chol (block-lower of w_pchol): the other halves are cleared
             // once per blob (VJF_SC_TRI_CLEAN), here behind the backward half that may still read a full w_chol
@@ -709,7 +719,6 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         // (single rank only: the SGD kernel can sum the gradient slabs itself -- 7 us instead of 5 + 7 for reduce + SGD, but the
         //  step as a whole came out 1 us SLOWER in A/B runs on one box: the forward half then starts earlier and runs
         //  beside more of the Cholesky kernel.  Off unless VJF_FUSED_SGD is set.)
-        const bool fuse_sgd = !c->comm_a && getenv("VJF_FUSED_SGD") != nullptr;
         if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1, nullptr, 0, fuse_sgd))) return rc;
         if (c->comm_a) {                                                   // sum the gradients and the loss sums over ranks
             VJF_NCCL(nccl().group_start());
@@ -720,7 +729,12 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             VJF_NCCL(e2);
         }
         if (fuse_sgd) rc = launch_sgd(c, B, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, ne, ng, sa, t & 1);
-        else rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa);
+        else {
+            // (k1_waits: the scalar workgroup ends once Cholesky(t) and post(t) are resident, see VjfPrepArgs::run_word)
+            const unsigned* fl = (const unsigned*)(c->ws + c->cv.flags);
+            rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, nullptr, nullptr, 0,
+                             k1_waits ? fl + VJF_CHOL_MAXBLK + 2 : nullptr, c->epoch, fl + 24, c->post_count);
+        }
         if (rc) return rc;
         if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
     }
@@ -1089,7 +1103,7 @@ int vjf_blr_rls(const float* x, const float* target, const float* v, float shrin
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(ws + c.partial); r.red = (float*)(ws + c.red);
     r.njobs = c.njobs; r.nsplit = c.nsplit; r.nblocks_k1 = 1;
-    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c.njobs), dim3(256), 0, s, P, r);   // sc_mask = 0: no loss sums here
+    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c.njobs), dim3(VJF_REDUCE_THREADS), 0, s, P, r);   // sc_mask = 0: no loss sums here
     VJF_HIP(hipGetLastError());
     allow_lds(vjf_rls_kernel, lds);
     VjfRlsArgs a{};
@@ -1135,7 +1149,7 @@ int vjf_blr_kalman(const float* x, const float* target, const float* v, float di
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(ws + c.partial); r.red = (float*)(ws + c.red);
     r.njobs = c.njobs; r.nsplit = c.nsplit; r.nblocks_k1 = 1;
-    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c.njobs), dim3(256), 0, s, P, r);
+    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(c.njobs), dim3(VJF_REDUCE_THREADS), 0, s, P, r);
     VJF_HIP(hipGetLastError());
     allow_lds(vjf_kalman_kernel, lds);
     const size_t nn = ((size_t)n * (n > dout ? n : dout) * 4 + 255) / 256 * 256;

@@ -37,6 +37,11 @@ struct VjfPrepArgs {
     unsigned wait_target;         //   until *wait_count has reached wait_target, then acquire at agent scope
     int bid0;             // first logical workgroup of this launch: 0 (whole grid, or the RLS-operand rows only)
                           // or n_rowblk (SGD + scalars only) -- the two halves run on different streams in vjf_filter_seq
+    // scalar workgroup, vjf_filter_seq only: it ends only when this step's Cholesky kernel (run_word >= run_epoch) and all of its
+    // post kernel's workgroups (*start_count >= start_target) are RESIDENT.  The next backward half of the trial kernel waits
+    // in-kernel for their results: it must not take the CUs they need before they are placed.
+    const unsigned* run_word; unsigned run_epoch;
+    const unsigned* start_count; unsigned start_target;
 };
 
 // logical grid = n_rowblk + n_sgdblk + 1
@@ -125,6 +130,16 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
                 SC[VJF_SC_N_LIK] = tot;
             }
             S[P.off[VJF_SLOT_LIK_LOGVAR]] = rho;
+        }
+        if (A.run_word) {
+            bool there = false;
+            for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+                const unsigned r = __hip_atomic_load(A.run_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned q = __hip_atomic_load(A.start_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(r - A.run_epoch) >= 0 && (int)(q - A.start_target) >= 0) { there = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!there) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
         }
     }
 }

@@ -105,18 +105,22 @@ struct VjfReduceArgs {
     unsigned sc_mask;         // which of K1's loss sums the extra workgroup reduces (bit per RS_* index)
 };
 
-// grid = njobs + 1 workgroups of 256 threads; the extra workgroup sums K1's loss partials (sc_mask == 0: grid = njobs).
-__global__ __launch_bounds__(256) void vjf_gram_reduce_kernel(VjfPlan P, VjfReduceArgs A) {
+// grid = njobs + 1 workgroups of 1024 threads (one tile element each: all of a thread's slab loads are in flight at once);
+// the extra workgroup sums K1's loss partials (sc_mask == 0: grid = njobs).
+#define VJF_REDUCE_THREADS 1024
+__global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(VjfPlan P, VjfReduceArgs A) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x == A.njobs) {
         __shared__ double s_part[256];
         // RS_N scalars; 32 threads per scalar accumulate strided partials in double, fixed order
-        const int sc = tid >> 5, l = tid & 31;
+        const int sc = (tid >> 5) & 7, l = tid & 31;
         double v = 0.0;
-        for (int b = l; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
-        s_part[tid] = v;
+        if (tid < 256) {
+            for (int b = l; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
+            s_part[tid] = v;
+        }
         __syncthreads();
-        if (l == 0 && ((A.sc_mask >> sc) & 1u)) {
+        if (tid < 256 && l == 0 && ((A.sc_mask >> sc) & 1u)) {
             double t = 0.0;
             for (int i = 0; i < 32; ++i) t += s_part[sc * 32 + i];
             A.red[P.red_SC + sc] = (float)t;
@@ -125,10 +129,17 @@ __global__ __launch_bounds__(256) void vjf_gram_reduce_kernel(VjfPlan P, VjfRedu
     }
     const VjfJob job = A.jobs[A.job0 + blockIdx.x];
     const float* slab = A.slabs + (size_t)(A.job0 + blockIdx.x) * A.nsplit * 1024;
-    for (int e = tid; e < 1024; e += 256) {
+    for (int e = tid; e < 1024; e += (int)blockDim.x) {
         float v = 0.f;
         int s = 0;
-        for (; s + 8 <= A.nsplit; s += 8) {                      // 8 independent loads, summed in split order
+        for (; s + 16 <= A.nsplit; s += 16) {                    // 16 independent loads, summed in split order
+            float t[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t[q] = slab[(size_t)(s + q) * 1024 + e];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v += t[q];
+        }
+        for (; s + 8 <= A.nsplit; s += 8) {
             float t[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) t[q] = slab[(size_t)(s + q) * 1024 + e];

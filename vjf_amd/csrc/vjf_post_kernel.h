@@ -35,6 +35,7 @@ struct VjfPostArgs {
     float* status;          // the status scalar of the state blob (time-out of the wait below)
     const unsigned* k1_done;  // workgroups of the trial kernel that have finished reading W, w_chol, sigma (null: not needed);
     unsigned k1_target;       //   nothing of those is written before the count reaches k1_target
+    unsigned* started;        // += 1 per workgroup as it starts (it is resident from then on; see VjfPrepArgs::start_count)
     unsigned* done;           // += 1 per workgroup when its outputs (W, w_chol, sigma: write-through stores) are in memory:
                               //   vjf_gate_kernel on another stream lets the readers of the next step start on it
     const float* red;       // reduce buffer (G, FDX, sum|dx|^2) of this step
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     auto lblk = [&](int bi, int bj) { return s_L + (size_t)(col_only ? bi - bj - 1 : tri(bi, bj)) * 32 * LB; };   // block (bi, bj), bi > bj
     auto dblk = [&](int k) { return s_D + (size_t)(col_only ? 0 : k) * 32 * LB; };
 
+    if (tid == 0 && A.started) __hip_atomic_fetch_add(A.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float pre_sdx2 = 0.f, pre_old = 0.f, pre_tot = 1.f;         // sum|dx|^2, old share of the running variance, new count
     double pre_scale = 0.0;                                     // mse -> new share of the running variance
     VJF_POST_STAMP(16);

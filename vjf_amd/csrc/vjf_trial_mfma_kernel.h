@@ -75,6 +75,8 @@ struct VjfTrialMfmaArgs {
                            //   the post kernel, on another stream, waits for the count before it overwrites them
     unsigned* fwd_done;    // forward half: += 1 per workgroup once its E / ACT rows and posterior are written back to memory
                            //   (release at agent scope): the statistics Gram on another stream starts behind vjf_gate_kernel on it
+    const unsigned* rls_done;  // backward half: workgroups of the previous step's post kernel that have their W, w_chol, sigma in
+    unsigned rls_target;       //   memory; non-null -> the workgroup waits (bounded) for the count before stage 2, its reloads done
     int part;              // 0: whole step; 1: forward half (features, recognition, E / ACT rows, posterior);
                            // 2: backward half (predictive mean / variance, losses, backward, DEL rows) -- reloads the
                            //    forward half's rows, so that it can run after the RLS update of the previous step while
@@ -200,6 +202,21 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     __syncthreads();
 
+    if (AA.rls_done && bwd) {
+        // W, w_chol, sigma come from the post kernel of the previous step on another stream: the host only lets this kernel
+        // start once that kernel's workgroups are resident (vjf_prep_kernel's last workgroup checks), so the wait cannot starve it
+        if (tid == 0) {
+            bool there = false;
+            for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+                if ((int)(__hip_atomic_load(AA.rls_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - AA.rls_target) >= 0) { there = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!there) vjf_status_or(const_cast<float*>(A.state) + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
     VJF_K1_STAMP(24);
     // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
     if (bwd) {
@@ -342,7 +359,8 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         constexpr int LPT = VJF_K1M_THREADS / 16;          // lanes per trial
         const int b = tid / LPT, s = tid % LPT;
         const float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
-        const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
+        // (sigma may have been written while this kernel was already running: a load that bypasses L1 / the scalar cache)
+        const float sig = __hip_atomic_load(S + P.off[VJF_SLOT_TR_LOGVAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float lrec = 0.f, ssey = 0.f;
         if (P.lik == VJF_LIK_GAUSSIAN) {                               // likelihood.py:19-26, functional.py:54-73
             const float p = expf(-0.5f * rho), e = expf(-rho);
