@@ -149,7 +149,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t pscr; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -173,6 +173,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
     c.flags = take(256);                                   // column flags of the Cholesky -> post hand-off (a block of their own)
     c.lscr = take((size_t)P.n * P.n * 4);                  // L, column by column, from the Cholesky kernel to the post kernel
+    c.pscr = take((size_t)(VJF_CHOL_MAXBLK * (VJF_CHOL_MAXBLK + 1) / 2) * 1024 * 4);   // lower blocks of P, from one Cholesky kernel to the next
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
     c.total = o;
@@ -213,6 +214,7 @@ struct vjf_ctx {
                            // but then the post kernel cannot be placed before the trial kernel has drained: measured slower)
     bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
                            // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
+    bool self_prep;        // vjf_filter_seq: the Cholesky kernel forms P + G/v itself (default; VJF_NO_SELF_PREP turns it off)
     bool k1_inkernel;      // the trial kernel's backward half waits for post(t-1) itself, behind its reloads (default), instead of
                            // starting behind a gate kernel (VJF_K1_GATE)
     bool prepg_inkernel;   // the RLS operand kernel waits for post(t-1) itself instead of behind a gate kernel
@@ -299,6 +301,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
     c->overlap_serial = false; c->gate_post = getenv("VJF_GATE_POST") != nullptr; c->sb_gates = getenv("VJF_SB_INKERNEL_WAIT") == nullptr; c->prepg_inkernel = getenv("VJF_PREPG_INKERNEL") != nullptr;
     c->k1_inkernel = getenv("VJF_K1_GATE") == nullptr;
+    c->self_prep = getenv("VJF_NO_SELF_PREP") == nullptr;
     c->stream2 = c->stream3 = c->stream4 = nullptr; c->ev_a = c->ev_s = c->ev_c = c->ev_d = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1;
@@ -564,8 +567,12 @@ int launch_sgd(vjf_ctx* c, int B, int32_t B_total, float* loss4, uint32_t flags,
 }
 
 // Cholesky + RLS tail + state-noise update.  `before_chol` / `before_post`: events the stream waits for first (or null).
+// `self_prep`: the Cholesky kernel forms P_new itself from the copy the previous Cholesky kernel left and waits in-kernel for
+// sigma (`wait_count` >= `wait_target`: post kernel of the previous step done); the operand kernel (state's P, g) then runs on
+// `st_post`, behind a gate on the same count and in front of the y / W workgroup that consumes g.
 int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, hipStream_t st_post,
-               hipEvent_t stop = nullptr, bool no_triclean = false, hipStream_t st_inv = nullptr) {
+               hipEvent_t stop = nullptr, bool no_triclean = false, hipStream_t st_inv = nullptr, bool self_prep = false,
+               const unsigned* wait_count = nullptr, unsigned wait_target = 0) {
     // `st_post` may differ from `st`: the post kernel's workgroups then start beside the Cholesky kernel and take each
     // column of L as the flag for it appears (the Cholesky kernel is always enqueued first, so even on one hardware queue
     // nothing waits for a kernel behind it).  What the post kernel needs from elsewhere it waits for itself: g through the
@@ -583,6 +590,7 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
     unsigned* colflags = (unsigned*)(c->ws + c->cv.flags);
     a.post = c->post_kernels ? 1 : 0; a.dinv_out = dinv; a.ok_out = okflag; a.lscr = (float*)(c->ws + c->cv.lscr);
     a.flags_out = colflags; a.epoch = ++c->epoch; a.no_triclean = no_triclean ? 1 : 0;
+    a.pscr = (float*)(c->ws + c->cv.pscr); a.self_prep = self_prep ? 1 : 0; a.wait_count = wait_count; a.wait_target = wait_target;
     switch (vjf_chol_dzp(P.dz)) {
         case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
         case 8: hipLaunchKernelGGL(vjf_chol_lds_kernel<8>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
@@ -598,9 +606,19 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
                                c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS);
             VJF_HIP(hipGetLastError());
         }
+        if (rls && self_prep) {
+            // (the operand kernel reads this step's statistics too: they are complete once the Cholesky kernel, which follows
+            //  their reduction in its stream, says it is running)
+            hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, st_post, wait_count, wait_target,
+                               (const unsigned*)(colflags + VJF_CHOL_MAXBLK + 2), a.epoch, c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS);
+            VJF_HIP(hipGetLastError());
+            int rc = launch_prep(c, B_total, nullptr, flags, red, 1, st_post);
+            if (rc) return rc;
+        }
         if (rls) {
             // inverse column halves + the y / W workgroup, which also carries the state-noise update
             VjfPostArgs pa{};
+            pa.undo_P = self_prep ? 1 : 0;
             pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.lscr = a.lscr;
             pa.flags = colflags; pa.epoch = a.epoch; pa.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
             pa.k1_done = c->mfma_trial ? colflags + 16 : nullptr; pa.k1_target = c->k1_count;
@@ -712,10 +730,16 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         }
         const unsigned* pd = (const unsigned*)((unsigned*)(c->ws + c->cv.flags) + 32);
         const bool prepg_waits = !c->sb_gates || c->prepg_inkernel;      // the 13 workgroups of the operand kernel poll themselves
-        if (!prepg_waits && t > 0) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, pd, post_before, stw);
-        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, (t > 0 && prepg_waits) ? pd : nullptr, post_before))) return rc;
+        // t > 0: the Cholesky kernel prepares its own operand (launch_rls, self_prep) -- gate + operand kernel leave the cycle
+        // post(t-1) -> Cholesky(t) -> post(t).  It then spins on a whole CU until post(t-1) is done: that kernel is resident by
+        // then (the scalar workgroup of SGD(t-1) saw to it, and this kernel follows the forward half(t) that came after it).
+        const bool self_prep = c->self_prep && t > 0 && !c->overlap_serial && P.dz <= 16 && k1_waits;
+        if (!self_prep) {
+            if (!prepg_waits && t > 0) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, pd, post_before, stw);
+            if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, (t > 0 && prepg_waits) ? pd : nullptr, post_before))) return rc;
+        }
         // Cholesky on sb; the post kernel on sc beside it (it takes the columns of L as they appear)
-        if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, t == T - 1 ? c->ev_s : nullptr, true, sd))) return rc;
+        if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, t == T - 1 ? c->ev_s : nullptr, true, sd, self_prep, pd, post_before))) return rc;
         // (single rank only: the SGD kernel can sum the gradient slabs itself -- 7 us instead of 5 + 7 for reduce + SGD, but the
         //  step as a whole came out 1 us SLOWER in A/B runs on one box: the forward half then starts earlier and runs
         //  beside more of the Cholesky kernel.  Off unless VJF_FUSED_SGD is set.)

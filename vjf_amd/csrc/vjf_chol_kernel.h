@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void vjf_prepg_kernel(VjfPlan P, VjfPrepArgs A
             d[0] = in ? p[q].x : 0.f; d[1] = in ? p[q].y : 0.f; d[2] = in ? p[q].z : 0.f; d[3] = in ? p[q].w : 0.f;
             if (in) {
                 float4 o;
-                o.x = p[q].x + g[q].x * inv_v; o.y = p[q].y + g[q].y * inv_v; o.z = p[q].z + g[q].z * inv_v; o.w = p[q].w + g[q].w * inv_v;
+                o.x = fmaf(g[q].x, inv_v, p[q].x); o.y = fmaf(g[q].y, inv_v, p[q].y); o.z = fmaf(g[q].z, inv_v, p[q].z); o.w = fmaf(g[q].w, inv_v, p[q].w);
                 *reinterpret_cast<float4*>(Pm + (size_t)(i0 + row) * n + c4) = o;
             }
         }
@@ -606,6 +606,12 @@ struct VjfCholArgs {
     float* lscr;           // post mode: (n, n) scratch that receives L column by column while the factorisation runs
     unsigned* flags_out;   // post mode: flags_out[k] = (epoch << 1) | failed once column k of L and Dinv_k are in global memory:
     unsigned epoch;        //   vjf_rls_post_kernel, launched beside this kernel, consumes the columns as they appear
+    float* pscr;           // post mode: lower 32x32 blocks of P (with the identity padding), block after block, row-major: written
+                           //   here with P_new; self_prep reads P_old from it (the copy a Cholesky kernel left for the next one)
+    int self_prep;         // post mode: 1 = P_new = P_old (pscr) + Phi^T Phi / v is formed HERE, in registers, once sigma of the
+                           //   previous step is there (wait_count reaches wait_target): the operand kernel that updates the state's
+                           //   P and forms g runs beside this kernel, on the post kernel's stream, instead of before it
+    const unsigned* wait_count; unsigned wait_target;
     int no_triclean;       // post mode: the caller clears the zero halves of w_chol / w_pchol itself (vjf_triclean_kernel)
                            //            (vjf_rls_post_kernel copies it to w_pchol once the factor is known to be good)
 };
@@ -674,9 +680,10 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
     float* Lm = S + P.off[VJF_SLOT_W_PCHOL];
     const float* G = A.red + P.red_G;
     const float* FDX = A.red + P.red_FDX;
-    const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
+    float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
     const float Bf = (float)A.B_total;
     unsigned st = 0;
+    const bool sp = A.post && A.self_prep;
     VJF_STAMP(0);
     if (tid < ntri) {
         int bi = 0;
@@ -698,48 +705,66 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
         auto pad4 = [](int gi, int gj) {                                // identity padding outside the matrix
             return make_float4(gi == gj ? 1.f : 0.f, gi == gj + 1 ? 1.f : 0.f, gi == gj + 2 ? 1.f : 0.f, gi == gj + 3 ? 1.f : 0.f);
         };
-        if (wave == 0) {
-            float4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = lane + 64 * q, r = idx >> 3, c4 = (idx & 7) * 4;
-                v[q] = (r < n && c4 < n) ? *reinterpret_cast<const float4*>(Pm + (size_t)r * n + c4) : pad4(r, c4);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = lane + 64 * q, r = idx >> 3, c4 = (idx & 7) * 4;
-                s_blk[vsw(r, c4)] = v[q].x; s_blk[vsw(r, c4 + 1)] = v[q].y; s_blk[vsw(r, c4 + 2)] = v[q].z; s_blk[vsw(r, c4 + 3)] = v[q].w;
-            }
-            diag_chain(0);
-        } else {
-            constexpr int NT = VJF_CHOL_THREADS - 64, NQ = ((VJF_CHOL_MAXBLK * (VJF_CHOL_MAXBLK + 1) / 2 - 1) * 256 + NT - 1) / NT;
-            const int t2 = tid - 64;
-            float4 v[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int idx = 256 + t2 + q * NT;
-                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < ntri * 256) {
-                    const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
-                    const int gi = s_bi[b] * 32 + r, gj = s_bj[b] * 32 + c4;
-                    v[q] = (gi < n && gj < n) ? *reinterpret_cast<const float4*>(Pm + (size_t)gi * n + gj) : pad4(gi, gj);
+        // self_prep: every thread first issues its loads of P_old (pscr) and of G, then the workgroup waits for sigma of the
+        // previous step, and P_new = P_old + G / v is formed in the registers (fmaf, as vjf_prepg_kernel forms the state's P).
+        // Either way the blocks of P_new go to pscr for the next step's kernel.
+        auto sigma_wait = [&]() {
+            if (tid == 0) {
+                bool there = false;
+                for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+                    if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.wait_target) >= 0) { there = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
+                if (!there) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            __syncthreads();
+            sig = __hip_atomic_load(S + P.off[VJF_SLOT_TR_LOGVAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto g4 = [&](int gi, int gj) {                                 // 4 entries of G, zero outside the matrix
+            return (gi < n && gj < n) ? *reinterpret_cast<const float4*>(G + (size_t)gi * n + gj) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        constexpr int NT = VJF_CHOL_THREADS - 64, NQ = ((VJF_CHOL_MAXBLK * (VJF_CHOL_MAXBLK + 1) / 2 - 1) * 256 + NT - 1) / NT;
+        const int t2 = tid - 64;
+        float4 v[NQ], g[NQ];                                            // (wavefront 0 uses the first four)
+        auto idx_of = [&](int q) { return wave == 0 ? (q < 4 ? lane + 64 * q : ntri * 256) : 256 + t2 + q * NT; };
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int idx = 256 + t2 + q * NT;
-                if (idx < ntri * 256) {
-                    const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
-                    float* blk = s_blk + (size_t)b * 1024;
-                    blk[vsw(r, c4)] = v[q].x; blk[vsw(r, c4 + 1)] = v[q].y; blk[vsw(r, c4 + 2)] = v[q].z; blk[vsw(r, c4 + 3)] = v[q].w;
-                }
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = idx_of(q);
+            v[q] = make_float4(0.f, 0.f, 0.f, 0.f); g[q] = v[q];
+            if (idx < ntri * 256) {
+                const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
+                const int gi = s_bi[b] * 32 + r, gj = s_bj[b] * 32 + c4;
+                if (sp) { v[q] = *reinterpret_cast<const float4*>(A.pscr + (size_t)idx * 4); g[q] = g4(gi, gj); }
+                else v[q] = (gi < n && gj < n) ? *reinterpret_cast<const float4*>(Pm + (size_t)gi * n + gj) : pad4(gi, gj);
             }
-            if (!A.post)                                                // (post mode: g goes to vjf_rls_post_kernel, not here)
-                for (int e = t2; e < npad * DZP; e += NT) {
-                    const int r = e / DZP, j = e - r * DZP;
-                    s_g[e] = (r < n && j < dz) ? A.gbuf[(size_t)r * dz + j] : 0.f;
-                }
         }
+        if (sp) {
+            sigma_wait();
+            const float inv_v = expf(-sig);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                v[q].x = fmaf(g[q].x, inv_v, v[q].x); v[q].y = fmaf(g[q].y, inv_v, v[q].y);
+                v[q].z = fmaf(g[q].z, inv_v, v[q].z); v[q].w = fmaf(g[q].w, inv_v, v[q].w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = idx_of(q);
+            if (idx < ntri * 256) {
+                const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
+                float* blk = s_blk + (size_t)b * 1024;
+                blk[vsw(r, c4)] = v[q].x; blk[vsw(r, c4 + 1)] = v[q].y; blk[vsw(r, c4 + 2)] = v[q].z; blk[vsw(r, c4 + 3)] = v[q].w;
+                if (A.post) *reinterpret_cast<float4*>(A.pscr + (size_t)idx * 4) = v[q];
+            }
+        }
+        if (wave == 0) diag_chain(0);
+        else if (!A.post)                                               // (post mode: g goes to vjf_rls_post_kernel, not here)
+            for (int e = t2; e < npad * DZP; e += NT) {
+                const int r = e / DZP, j = e - r * DZP;
+                s_g[e] = (r < n && j < dz) ? A.gbuf[(size_t)r * dz + j] : 0.f;
+            }
         __syncthreads();
         VJF_STAMP(1);
 
@@ -822,8 +847,20 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
             // undo P += G / v (exact up to one rounding) and leave W, w_chol, w_pchol as they were.
             st |= VJF_STATUS_RLS_FAILED;
             const float inv_v = expf(-sig);
-            for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) Pm[e] = Pm[e] - G[e] * inv_v;
+            // (self_prep: the state's P is in the hands of the operand kernel on the post kernel's stream; that kernel's y / W
+            //  workgroup, which follows it there, takes the update back)
+            if (!sp) for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) Pm[e] = fmaf(-G[e], inv_v, Pm[e]);
             if (A.post) {
+                for (int idx = tid; idx < ntri * 256; idx += VJF_CHOL_THREADS) {   // the copy for the next kernel, likewise
+                    const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
+                    const int gi = s_bi[b] * 32 + r, gj = s_bj[b] * 32 + c4;
+                    if (gi < n && gj < n) {
+                        float4 pv = *reinterpret_cast<const float4*>(A.pscr + (size_t)idx * 4);
+                        const float4 gv = *reinterpret_cast<const float4*>(G + (size_t)gi * n + gj);
+                        pv.x = fmaf(-gv.x, inv_v, pv.x); pv.y = fmaf(-gv.y, inv_v, pv.y); pv.z = fmaf(-gv.z, inv_v, pv.z); pv.w = fmaf(-gv.w, inv_v, pv.w);
+                        *reinterpret_cast<float4*>(A.pscr + (size_t)idx * 4) = pv;
+                    }
+                }
                 // columns published so far are those of iterations that completed; every other flag says "failed"
                 if (wave == 4) {
                     if (kdone > 0) publish(kdone - 1, kdone, 0u);      // (stored in the last completed phase, flag still due)

@@ -43,6 +43,8 @@ struct VjfPostArgs {
     int role;               // 0: one launch, 2 nbl + 1 workgroups; 1: the 2 nbl inverse workgroups alone -- they keep only the
                             //    current column of L in LDS (48 KB: they fit beside a trial-kernel workgroup on its CU);
                             //    2: the y / W workgroup alone (it needs all of L for the backward substitution)
+    int undo_P;             // 1: the operand kernel that ran before this one on its stream added Phi^T Phi / v to the state's P without
+                            //    knowing whether the factorisation would succeed: on failure the y / W workgroup takes it back
     int fold_sigma;         // 1: the y / W workgroup goes on to the state-noise update (no vjf_resid / vjf_sigma launch)
     unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memtime of the y / W workgroup, slots 16..21
 };
@@ -336,6 +338,12 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
                 s_x[r * LX + c] = (r < n && c < dz) ? Wold[(size_t)r * dz + c] : 0.f;
             }
             prefetch_tail();                                   // (the failure may have come before the first column)
+            if (A.undo_P) {                                    // exact up to one rounding, as the Cholesky kernel does on its own path
+                float* Pm = A.state + P.off[VJF_SLOT_W_PREC];
+                const float* G = A.red + P.red_G;
+                const float inv_v = expf(-S[P.off[VJF_SLOT_TR_LOGVAR]]);
+                for (int e = tid; e < n * n; e += VJF_POST_THREADS) Pm[e] = fmaf(-G[e], inv_v, Pm[e]);
+            }
         }
         __syncthreads();
         VJF_POST_STAMP(20);
@@ -404,6 +412,19 @@ __global__ __launch_bounds__(64) void vjf_gate_kernel(const unsigned* count, uns
     for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
         const unsigned v = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(v - target) >= 0) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    vjf_status_or(status, VJF_STATUS_RLS_FAILED);
+}
+
+// The same with two counts (both must have reached their targets).
+__global__ __launch_bounds__(64) void vjf_gate2_kernel(const unsigned* count, unsigned target, const unsigned* count2, unsigned target2,
+                                                       float* status) {
+    if (threadIdx.x != 0) return;
+    for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
+        const unsigned v = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned w = __hip_atomic_load(count2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - target) >= 0 && (int)(w - target2) >= 0) return;
         __builtin_amdgcn_s_sleep(2);
     }
     vjf_status_or(status, VJF_STATUS_RLS_FAILED);
