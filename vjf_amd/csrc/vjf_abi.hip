@@ -214,6 +214,9 @@ struct vjf_ctx {
                            // but then the post kernel cannot be placed before the trial kernel has drained: measured slower)
     bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
                            // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
+    bool persistent;       // vjf_filter_seq: the RLS chain as persistent kernels (default; VJF_NO_PERSISTENT turns it off)
+    unsigned start_count;  // host mirror of the post kernel's "workgroups started" count
+    unsigned stat_count, prep_count;   // host mirrors of the "statistics reduced" / "operand rows done" workgroup counts
     bool self_prep;        // vjf_filter_seq: the Cholesky kernel forms P + G/v itself (default; VJF_NO_SELF_PREP turns it off)
     bool k1_inkernel;      // the trial kernel's backward half waits for post(t-1) itself, behind its reloads (default), instead of
                            // starting behind a gate kernel (VJF_K1_GATE)
@@ -292,8 +295,9 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->post_kernels = fast_chol && P.dz <= 16 && c->lds_post <= kMaxLds - 1024;
     // the single-workgroup chain kernels ask for the whole LDS of their compute unit: nothing else (every other kernel of
     // a step uses some LDS) is then placed beside them to share their SIMDs' issue slots and matrix cores
-    if (fast_chol) c->lds_chol = kMaxLds;
-    if (c->post_kernels) c->lds_post = kMaxLds;
+    // (minus the few static bytes of their wrappers)
+    if (fast_chol) c->lds_chol = kMaxLds - 256;
+    if (c->post_kernels) c->lds_post = kMaxLds - 256;
     c->lds_k1m = vjf_trial_mfma_lds_floats(P) * 4;
     c->mfma_trial = c->lds_k1m <= kMaxLds - 1024;
     c->n_ejobs = 0;
@@ -301,7 +305,9 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
     c->overlap_serial = false; c->gate_post = getenv("VJF_GATE_POST") != nullptr; c->sb_gates = getenv("VJF_SB_INKERNEL_WAIT") == nullptr; c->prepg_inkernel = getenv("VJF_PREPG_INKERNEL") != nullptr;
     c->k1_inkernel = getenv("VJF_K1_GATE") == nullptr;
-    c->self_prep = getenv("VJF_NO_SELF_PREP") == nullptr;
+    c->self_prep = getenv("VJF_SELF_PREP") != nullptr;
+    c->persistent = getenv("VJF_NO_PERSISTENT") == nullptr;
+    c->stat_count = 0; c->prep_count = 0; c->start_count = 0;
     c->stream2 = c->stream3 = c->stream4 = nullptr; c->ev_a = c->ev_s = c->ev_c = c->ev_d = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1;
@@ -319,6 +325,8 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     allow_lds(vjf_chol_lds_kernel<4>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<8>, c->lds_chol);
     allow_lds(vjf_chol_lds_kernel<12>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<16>, c->lds_chol);
     allow_lds(vjf_chol_lds_kernel<32>, c->lds_chol);
+    allow_lds(vjf_rls_pair_kernel<4>, c->lds_chol); allow_lds(vjf_rls_pair_kernel<8>, c->lds_chol);
+    allow_lds(vjf_rls_pair_kernel<12>, c->lds_chol); allow_lds(vjf_rls_pair_kernel<16>, c->lds_chol);
     *out = c;
     return 0;
 }
@@ -500,7 +508,8 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
 
 // Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
 int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, hipEvent_t stop = nullptr,
-                int gen = 0, const unsigned* wait_count = nullptr, unsigned wait_target = 0, bool no_reduce = false) {
+                int gen = 0, const unsigned* wait_count = nullptr, unsigned wait_target = 0, bool no_reduce = false,
+                unsigned* done_count = nullptr) {
     const VjfPlan& P = c->plan;
     const int nsplit = split_for(B);
     VjfGramArgs g{};
@@ -516,6 +525,7 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial)); r.red = red;
     r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask;
+    r.done_count = done_count;
     VJF_LAUNCH(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(VJF_REDUCE_THREADS), 0, st, stop, P, r);
     VJF_HIP(hipGetLastError());
     return 0;
@@ -524,7 +534,8 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
 // which: 0 whole prep grid, 1 RLS operand rows only, 2 SGD + scalars only
 int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const float* red, int which, hipStream_t st,
                 hipEvent_t stop = nullptr, const unsigned* wait_count = nullptr, unsigned wait_target = 0,
-                const unsigned* run_word = nullptr, unsigned run_epoch = 0, const unsigned* start_count = nullptr, unsigned start_target = 0) {
+                const unsigned* run_word = nullptr, unsigned run_epoch = 0, const unsigned* start_count = nullptr, unsigned start_target = 0,
+                unsigned* done_count = nullptr) {
     const VjfPlan& P = c->plan;
     VjfPrepArgs p{};
     p.state = c->state; p.red = red; p.gbuf = (float*)(c->ws + c->cv.work);
@@ -534,6 +545,7 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
     p.n_sgdblk = (P.train_len + 1023) / 1024;
     p.wait_count = wait_count; p.wait_target = wait_target;
     p.run_word = run_word; p.run_epoch = run_epoch; p.start_count = start_count; p.start_target = start_target;
+    p.done_count = done_count;
     if (which != 2 && P.dz > 16) {                             // (the matrix-core operand kernel holds one 16-column tile of W)
         p.bid0 = 0;
         const int grid = which == 1 ? p.n_rowblk : p.n_rowblk + p.n_sgdblk + 1;
@@ -623,6 +635,7 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
             pa.flags = colflags; pa.epoch = a.epoch; pa.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
             pa.k1_done = c->mfma_trial ? colflags + 16 : nullptr; pa.k1_target = c->k1_count;
             pa.done = colflags + 32; pa.started = colflags + 24; c->post_count += (unsigned)(2 * nbl + 1);
+            c->start_count += (unsigned)(2 * nbl + 1);
             pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
             if (st_inv && st_inv != st_post) {
                 // two launches: the inverse workgroups keep one column of L in LDS and share their CUs with the trial kernel;
@@ -676,8 +689,16 @@ int ensure_stream2(vjf_ctx* c) {
 // forward half's E rows.  So chain A of step t runs beside chain B of step t, and a step costs max(A, B) instead of A + B.
 // Results are those of the one-stream order bit for bit (same kernels, same sums).  RLS statistics alternate between two
 // reduce buffers so that chain A may produce step t+1's while chain B still reads step t's.
+int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
+                       const float* lv0, float* mu, float* lv, float* loss, uint32_t flags);
+
 int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
                        const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
+    // (single rank only: a collective library may synchronise the device when it sets something up lazily, which kernels that
+    //  stay resident for the whole sequence would turn into a time-out; VJF_PERSISTENT_DIST=1 tries it anyway)
+    if (c->persistent && !c->overlap_serial && c->mfma_trial && c->post_kernels && c->plan.dz <= 16 && !getenv("VJF_FUSED_SGD") &&
+        (!c->comm_a || getenv("VJF_PERSISTENT_DIST")))
+        return filter_seq_persist(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
     int rc = ensure_stream2(c);
     if (rc) return rc;
     const VjfPlan& P = c->plan;
@@ -757,7 +778,7 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             // (k1_waits: the scalar workgroup ends once Cholesky(t) and post(t) are resident, see VjfPrepArgs::run_word)
             const unsigned* fl = (const unsigned*)(c->ws + c->cv.flags);
             rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, nullptr, nullptr, 0,
-                             k1_waits ? fl + VJF_CHOL_MAXBLK + 2 : nullptr, c->epoch, fl + 24, c->post_count);
+                             k1_waits ? fl + VJF_CHOL_MAXBLK + 2 : nullptr, c->epoch, fl + 24, c->start_count);
         }
         if (rc) return rc;
         if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
@@ -769,6 +790,119 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         VJF_HIP(hipEventRecord(c->ev_d, sd));
         VJF_HIP(hipStreamWaitEvent(sa, c->ev_d, 0));
     }
+    return 0;
+}
+
+// The sequence with the RLS chain as persistent kernels.  Per step the host enqueues only
+//   sa (caller's stream): K1 backward half(t) [waits in-kernel for post(t-1)] -> gradient Gram -> reduce -> clip + SGD -> K1 forward half(t+1)
+//   sb:                   [gate: forward half(t) done] statistics Gram -> reduce (-> all-reduce) -> [gate: post(t-1) done, Cholesky(t) has
+//                         its operands] operand kernel (state's P += G/v, g)
+// and, once per sequence, on sc the Cholesky + y / W pair (two workgroups, a CU each) and on sd the 2 nbl inverse workgroups, each of
+// which loops over the T steps, taking its inputs as the counts say they are there.
+int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
+                       const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
+    int rc = ensure_stream2(c);
+    if (rc) return rc;
+    const VjfPlan& P = c->plan;
+    const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
+    hipStream_t sa = c->stream, sb = c->stream2, sc = c->stream3, sd = c->stream4;
+    float* redg = (float*)(c->ws + c->cv.red);
+    float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};
+    const int Bt = B * c->world;
+    auto args = [&](int t) {
+        return trial_args(c, B, y + t * sy, u ? u + t * su : nullptr, t ? mu + (t - 1) * sz : mu0, t ? lv + (t - 1) * sz : lv0,
+                          eps + (size_t)t * 2 * sz, eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags, t & 1);
+    };
+    rc = check_step_args(c, B, y, u, mu0, lv0, eps, eps + sz, mu, lv);
+    if (rc) return rc;
+    rc = refresh_aux(c);
+    if (rc) return rc;
+    const int ne = c->n_ejobs, ng = c->njobs - ne;
+    unsigned* fl = (unsigned*)(c->ws + c->cv.flags);
+    unsigned* k1done = fl + 16; unsigned* started = fl + 24; unsigned* pdone = fl + 32; unsigned* statc = fl + 40; unsigned* prepc = fl + 44;
+    unsigned* fdone = fl + 48; unsigned* runw = fl + VJF_CHOL_MAXBLK + 2;
+    float* stw = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
+    const int nbl = (P.n + 31) / 32;
+    const unsigned npost = (unsigned)(2 * nbl + 1), nblk = (unsigned)trial_blocks(c, B), nred = (unsigned)(ne + 1), nprep = (unsigned)((P.n + 15) / 16);
+    {   // ---- the persistent kernels of this sequence
+        VjfCholArgs a{};
+        a.state = c->state; a.red = rede[0]; a.red2 = rede[1]; a.gbuf = (const float*)(c->ws + c->cv.work); a.B_total = Bt; a.flags = flags;
+        a.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
+        float* dinv = (float*)(c->ws + c->cv.post);
+        a.post = 1; a.dinv_out = dinv; a.ok_out = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
+        a.lscr = (float*)(c->ws + c->cv.lscr); a.flags_out = fl; a.epoch = c->epoch + 1; a.no_triclean = 1;
+        a.pscr = (float*)(c->ws + c->cv.pscr); a.self_prep = 1; a.src_state = 1;
+        a.wait_count = pdone; a.wait_target = c->post_count; a.wait_stride = npost;
+        a.stat_count = statc; a.stat_target = c->stat_count + nred; a.stat_stride = nred;
+        a.nsteps = T; a.step0 = 0;
+        VjfPostArgs pa{};
+        pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.lscr = a.lscr; pa.flags = fl; pa.epoch = a.epoch; pa.status = stw;
+        pa.k1_done = k1done; pa.k1_target = c->k1_count + nblk; pa.k1_stride = nblk;
+        pa.done = pdone; pa.started = started;
+        pa.red = rede[0]; pa.red2 = rede[1]; pa.B_total = Bt; pa.fold_sigma = 1; pa.stamps = a.stamps; pa.undo_P = 1;
+        pa.prep_count = prepc; pa.prep_target = c->prep_count + nprep; pa.prep_stride = nprep;
+        pa.nsteps = T; pa.step0 = 0;
+        pa.role = 2;
+        switch (vjf_chol_dzp(P.dz)) {
+            case 4: hipLaunchKernelGGL(vjf_rls_pair_kernel<4>, dim3(2), dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
+            case 8: hipLaunchKernelGGL(vjf_rls_pair_kernel<8>, dim3(2), dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
+            case 12: hipLaunchKernelGGL(vjf_rls_pair_kernel<12>, dim3(2), dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
+            default: hipLaunchKernelGGL(vjf_rls_pair_kernel<16>, dim3(2), dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
+        }
+        VJF_HIP(hipGetLastError());
+        pa.role = 1; pa.prep_count = nullptr;                           // (the inverse workgroups do not read g)
+        hipLaunchKernelGGL(vjf_rls_post_kernel, dim3(2 * nbl), dim3(VJF_POST_THREADS), vjf_post_inv_lds_bytes(P), sd, P, pa);
+        VJF_HIP(hipGetLastError());
+    }
+    const unsigned epoch0 = c->epoch + 1;
+    c->epoch += (unsigned)T;
+    c->start_count += npost;
+    if ((rc = launch_trial(c, args(0), 1, sa, nullptr, true))) return rc;   // prologue: forward half of step 0
+    for (int t = 0; t < T; ++t) {
+        const unsigned post_before = c->post_count;                      // workgroups of post(0 .. t-1)
+        // sb: statistics of step t as soon as its forward half is done ...
+        hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
+        if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, c->comm_b ? nullptr : statc))) return rc;
+        if (c->comm_b) {                                                 // trials are sharded over ranks: sum [G | FDX | sums]
+            VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum,
+                                       c->comm_b, sb));
+            hipLaunchKernelGGL(vjf_count_kernel, dim3(1), dim3(64), 0, sb, statc, nred);
+        }
+        c->stat_count += nred;
+        // ... then, behind W and sigma of step t-1 and once the Cholesky loop holds P_old in registers, the state's P and g
+        hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)pdone, post_before, (const unsigned*)runw, epoch0 + (unsigned)t, stw);
+        VJF_HIP(hipGetLastError());
+        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, prepc))) return rc;
+        c->prep_count += nprep;
+        // sa: backward half(t); it waits in-kernel for post(t-1), whose workgroups are resident
+        if ((rc = launch_trial(c, args(t), 2, sa, nullptr, false, t > 0 ? pdone : nullptr, post_before))) return rc;
+        c->post_count += npost;
+        if (t == 0) {
+            hipLaunchKernelGGL(vjf_triclean_kernel, dim3(64), dim3(256), 0, sa, P, c->state);
+            hipLaunchKernelGGL(vjf_triclean_done_kernel, dim3(1), dim3(1), 0, sa, P, c->state);
+            VJF_HIP(hipGetLastError());
+        }
+        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1))) return rc;
+        if (c->comm_a) {
+            VJF_NCCL(nccl().group_start());
+            int e1 = nccl().all_reduce(redg, redg, (size_t)P.train_len, kNcclFloat, kNcclSum, c->comm_a, sa);
+            int e2 = nccl().all_reduce(redg + P.red_SC, redg + P.red_SC, (size_t)RS_N, kNcclFloat, kNcclSum, c->comm_a, sa);
+            VJF_NCCL(nccl().group_end());
+            VJF_NCCL(e1);
+            VJF_NCCL(e2);
+        }
+        // (t == 0: the scalar workgroup ends once the persistent workgroups are resident -- before any backward half spins on them)
+        rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, nullptr, nullptr, 0,
+                         t == 0 ? runw : nullptr, epoch0, started, c->start_count);
+        if (rc) return rc;
+        if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
+    }
+    VJF_HIP(hipEventRecord(c->ev_c, sb));
+    VJF_HIP(hipEventRecord(c->ev_s, sc));
+    VJF_HIP(hipEventRecord(c->ev_d, sd));
+    VJF_HIP(hipStreamWaitEvent(sa, c->ev_c, 0));                           // join: the caller's stream sees the final state
+    VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));
+    VJF_HIP(hipStreamWaitEvent(sa, c->ev_d, 0));
     return 0;
 }
 }  // namespace

@@ -42,6 +42,7 @@ struct VjfPrepArgs {
     // in-kernel for their results: it must not take the CUs they need before they are placed.
     const unsigned* run_word; unsigned run_epoch;
     const unsigned* start_count; unsigned start_target;
+    unsigned* done_count;         // vjf_prepg_kernel: non-null -> += 1 per workgroup once its rows of P and g are in memory
 };
 
 // logical grid = n_rowblk + n_sgdblk + 1
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(256) void vjf_prepg_kernel(VjfPlan P, VjfPrepArgs A
             A.gbuf[(size_t)(i0 + r) * dz + c] = v + FDX[(size_t)(i0 + r) * dz + c] * inv_v;
         }
     }
+    if (A.done_count) vjf_wg_signal(A.done_count, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -612,6 +614,14 @@ struct VjfCholArgs {
                            //   previous step is there (wait_count reaches wait_target): the operand kernel that updates the state's
                            //   P and forms g runs beside this kernel, on the post kernel's stream, instead of before it
     const unsigned* wait_count; unsigned wait_target;
+    int src_state;         // self_prep: P_old comes from the state's P (first step of a sequence) instead of pscr
+    // persistent form (vjf_filter_seq): nsteps > 0 -> ONE launch runs the factorisations of nsteps consecutive steps on its CU
+    // (a kernel of this size is not placed while trial-kernel workgroups hold LDS on every CU; resident, it starts the moment
+    // sigma arrives).  Step `it`: epoch + it, statistics in red (even step0 + it) or red2 (odd), ready when *stat_count has
+    // reached stat_target + it * stat_stride; sigma when *wait_count has reached wait_target + it * wait_stride.
+    int nsteps, step0;
+    const float* red2;
+    const unsigned* stat_count; unsigned stat_target, stat_stride, wait_stride;
     int no_triclean;       // post mode: the caller clears the zero halves of w_chol / w_pchol itself (vjf_triclean_kernel)
                            //            (vjf_rls_post_kernel copies it to w_pchol once the factor is known to be good)
 };
@@ -650,9 +660,14 @@ __device__ __forceinline__ void axpy_row(float (&acc)[DZP], float x, const float
 }
 
 template <int DZP>
-__global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan P, VjfCholArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArgs& A, float* lds, int* s_dead, const unsigned it_epoch,
+                                              const float* it_red, const unsigned it_wait_target, const unsigned it_stat_target,
+                                              const bool it_src_state) {
+    int tid = threadIdx.x;
+    // (the persistent loop calls this body once per step: without the barrier the compiler hoists every lane-dependent address
+    //  of the body out of that loop and spills hundreds of registers)
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int n = P.n, dz = P.dz;
     const int nbl = (n + 31) / 32, npad = nbl * 32, ntri = nbl * (nbl + 1) / 2;
     float* S = A.state;
@@ -662,7 +677,9 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
     if (A.post && warm) return;                      // no RLS in warm-up; the residual / sigma kernels run on their own
     // "running": the caller keeps the post kernel (2 nbl + 1 workgroups that each take a whole CU's LDS) behind a one-wavefront
     // gate on this word, so that they do not sit on 15 CUs before there is anything for them to do
-    if (A.post && tid == 0) __hip_atomic_store(A.flags_out + VJF_CHOL_MAXBLK + 2, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (self_prep: the word is stored once this step's operands are in registers -- the operand kernel, which overwrites the
+    //  state's P, starts behind a gate on it)
+    if (A.post && !A.self_prep && tid == 0) __hip_atomic_store(A.flags_out + VJF_CHOL_MAXBLK + 2, it_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float* s_blk = lds;                               // ntri blocks: lower block triangle of P -> L -> L^-1
     float* s_aux = s_blk + (size_t)ntri * 1024;       // nbl blocks: inverted diagonal blocks of L; later scratch
     float* s_g = s_aux + (size_t)nbl * 1024;          // npad x DZP  g, later W
@@ -678,8 +695,8 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
     float* Wc = S + P.off[VJF_SLOT_W_CHOL];
     float* Pm = S + P.off[VJF_SLOT_W_PREC];
     float* Lm = S + P.off[VJF_SLOT_W_PCHOL];
-    const float* G = A.red + P.red_G;
-    const float* FDX = A.red + P.red_FDX;
+    const float* G = it_red + P.red_G;
+    const float* FDX = it_red + P.red_FDX;
     float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
     const float Bf = (float)A.B_total;
     unsigned st = 0;
@@ -693,6 +710,7 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
     }
     if (tid == 0) s_flag[0] = 1;
     __syncthreads();
+    if (A.stat_count && !vjf_wg_wait(A.stat_count, it_stat_target, tid)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED); *s_dead = 1; }
 
     if (!warm) {
         // ---- load the lower block triangle of P_new (vjf_prep_kernel already added Phi^T Phi / v).  Wavefront 0 takes the
@@ -709,17 +727,10 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
         // previous step, and P_new = P_old + G / v is formed in the registers (fmaf, as vjf_prepg_kernel forms the state's P).
         // Either way the blocks of P_new go to pscr for the next step's kernel.
         auto sigma_wait = [&]() {
-            if (tid == 0) {
-                bool there = false;
-                for (unsigned spins = 0; spins < (1u << 19); ++spins) {
-                    if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.wait_target) >= 0) { there = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (!there) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // operands in registers: the state's P may now be overwritten
             __syncthreads();
+            if (tid == 0) __hip_atomic_store(A.flags_out + VJF_CHOL_MAXBLK + 2, it_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!vjf_wg_wait(A.wait_count, it_wait_target, tid)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED); *s_dead = 1; }
             sig = __hip_atomic_load(S + P.off[VJF_SLOT_TR_LOGVAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto g4 = [&](int gi, int gj) {                                 // 4 entries of G, zero outside the matrix
@@ -736,8 +747,9 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
             if (idx < ntri * 256) {
                 const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
                 const int gi = s_bi[b] * 32 + r, gj = s_bj[b] * 32 + c4;
-                if (sp) { v[q] = *reinterpret_cast<const float4*>(A.pscr + (size_t)idx * 4); g[q] = g4(gi, gj); }
+                if (sp && !it_src_state) v[q] = *reinterpret_cast<const float4*>(A.pscr + (size_t)idx * 4);
                 else v[q] = (gi < n && gj < n) ? *reinterpret_cast<const float4*>(Pm + (size_t)gi * n + gj) : pad4(gi, gj);
+                if (sp) g[q] = g4(gi, gj);
             }
         }
         if (sp) {
@@ -799,7 +811,7 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
         };
         auto publish = [&](int k0, int k1, unsigned fail) {             // one wavefront: its stores drained, then the flags
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane >= k0 && lane < k1) __hip_atomic_store(A.flags_out + lane, (A.epoch << 1) | fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane >= k0 && lane < k1) __hip_atomic_store(A.flags_out + lane, (it_epoch << 1) | fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         int kdone = 0;                                                  // iterations completed = columns published
         for (int k = 0; k < nbl; ++k) {
@@ -1090,7 +1102,7 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
     if (lane == 0) s_d[wave] = part_sum;
     __syncthreads();
     if (tid == 0) {
-        double t = (double)A.red[P.red_SC + RS_SDX2];
+        double t = (double)it_red[P.red_SC + RS_SDX2];
         for (int w = 0; w < VJF_CHOL_THREADS / 64; ++w) t += s_d[w];
         if (t < 0.0) t = 0.0;
         const float mse = (float)(t / ((double)Bf * (double)dz));
@@ -1104,6 +1116,29 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan 
 
 // One-time clearing of the halves that the post kernel never writes (block-lower part of w_chol, block-upper part of
 // w_pchol), for callers that run the Cholesky kernel beside a reader of w_chol (vjf_filter_seq).  grid-stride.
+// One pass (nsteps <= 0) or the persistent form: nsteps factorisations, one after the other (see VjfCholArgs::nsteps).  The
+// per-step values travel as scalars beside the kernel arguments, which stay in scalar registers.
+template <int DZP>
+__device__ __forceinline__ void vjf_chol_loop(const VjfPlan& P, const VjfCholArgs& A, float* lds, int* s_dead) {
+    const int steps = A.nsteps > 0 ? A.nsteps : 1;
+    for (int it = 0; it < steps; ++it) {
+        const float* red = ((A.step0 + it) & 1) ? A.red2 : A.red;
+        vjf_chol_body<DZP>(P, A, lds, s_dead, A.epoch + (unsigned)it, red, A.wait_target + (unsigned)it * A.wait_stride,
+                           A.stat_target + (unsigned)it * A.stat_stride, it == 0 && A.src_state != 0);
+        __syncthreads();
+        if (*s_dead) break;
+    }
+}
+
+template <int DZP>
+__global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan P, VjfCholArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_dead;                             // a wait timed out: the persistent form stops (status says so)
+    if (threadIdx.x == 0) s_dead = 0;
+    __syncthreads();
+    vjf_chol_loop<DZP>(P, A, lds, &s_dead);
+}
+
 __global__ void vjf_triclean_kernel(VjfPlan P, float* state) {
     float* SC = state + P.off[VJF_SLOT_SCALARS];
     if (SC[VJF_SC_TRI_CLEAN] != 0.f) return;

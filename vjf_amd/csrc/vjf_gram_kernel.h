@@ -103,6 +103,8 @@ struct VjfReduceArgs {
     int njobs, nsplit, nblocks_k1;
     int job0;                 // first job of this launch; njobs = jobs in this launch
     unsigned sc_mask;         // which of K1's loss sums the extra workgroup reduces (bit per RS_* index)
+    unsigned* done_count;     // non-null: += 1 per workgroup once its sums are in memory (consumers that are already running wait
+                              //   for njobs + 1 of them: the persistent RLS kernels of vjf_filter_seq)
 };
 
 // grid = njobs + 1 workgroups of 1024 threads (one tile element each: all of a thread's slab loads are in flight at once);
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
             for (int i = 0; i < 32; ++i) t += s_part[sc * 32 + i];
             A.red[P.red_SC + sc] = (float)t;
         }
+        if (A.done_count) vjf_wg_signal(A.done_count, tid);
         return;
     }
     const VjfJob job = A.jobs[A.job0 + blockIdx.x];
@@ -164,4 +167,5 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
             else if (j == job.ncol_w && job.dst_b >= 0) A.red[job.dst_b + i] = v;
         }
     }
+    if (A.done_count) vjf_wg_signal(A.done_count, tid);
 }

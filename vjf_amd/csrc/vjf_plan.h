@@ -164,6 +164,39 @@ struct VjfJob {
     int tw, tb;        // kind 1: rows of the plan's trainable-tensor table that the weight / the bias belong to (tb -1: none)
 };
 
+#define VJF_WAIT_SPINS (1u << 19)
+#ifdef __HIPCC__
+// Hand-offs between kernels that run beside each other on different streams (no kernel boundary between producer and
+// consumer).  Producer, whole workgroup: every storing wavefront drains its stores, the workgroup barrier, one lane releases
+// at agent scope (L2 write-back), drains again, then the relaxed agent-scope count.  Consumer, whole workgroup: one lane
+// polls (relaxed, bounded), acquires at agent scope, its vmcnt drained, the workgroup barrier, and only then the plain loads
+// (MI355X guide, visibility across XCDs, valid forms).
+__device__ __forceinline__ void vjf_wg_signal(unsigned* count, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// returns false (lane 0 only; the others get true) when the count did not arrive within the bound
+__device__ __forceinline__ bool vjf_wg_wait(const unsigned* count, unsigned target, int tid) {
+    bool there = true;
+    if (tid == 0) {
+        there = false;
+        for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
+            if ((int)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { there = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    return there;
+}
+#endif
+
 // OR status bits into the status scalar (a float holding a small integer).  Kernels of one step may run on two
 // streams (vjf_filter_seq), so the read-modify-write is a compare-and-swap loop.
 __device__ __forceinline__ void vjf_status_or(float* p, unsigned bits) {

@@ -43,6 +43,12 @@ struct VjfPostArgs {
     int role;               // 0: one launch, 2 nbl + 1 workgroups; 1: the 2 nbl inverse workgroups alone -- they keep only the
                             //    current column of L in LDS (48 KB: they fit beside a trial-kernel workgroup on its CU);
                             //    2: the y / W workgroup alone (it needs all of L for the backward substitution)
+    // persistent form (vjf_filter_seq): nsteps > 0 -> one launch serves nsteps consecutive steps (its workgroups stay on their
+    // CUs).  Step `it`: epoch + it, statistics in red / red2 by the parity of step0 + it, k1_target + it * k1_stride, and g
+    // (from the operand kernel, another stream) is there when *prep_count has reached prep_target + it * prep_stride.
+    int nsteps, step0;
+    const float* red2;
+    const unsigned* prep_count; unsigned prep_target, prep_stride, k1_stride;
     int undo_P;             // 1: the operand kernel that ran before this one on its stream added Phi^T Phi / v to the state's P without
                             //    knowing whether the factorisation would succeed: on failure the y / W workgroup takes it back
     int fold_sigma;         // 1: the y / W workgroup goes on to the state-noise update (no vjf_resid / vjf_sigma launch)
@@ -106,9 +112,12 @@ __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned 
     return st;
 }
 
-__global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan P, VjfPostArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPostArgs& A, float* lds, int* s_dead, const unsigned it_epoch,
+                                                  const float* it_red, const unsigned it_k1_target, const unsigned it_prep_target,
+                                                  const bool it_first) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                               // (see vjf_chol_body: nothing lane-dependent is hoisted out of the step loop)
+    const int lane = tid & 63, wave = tid >> 6;
     const int n = P.n, dz = P.dz, nbl = (n + 31) / 32, ntri = nbl * (nbl + 1) / 2, nlow = ntri - nbl;
     const bool solve = A.role == 2 || (int)blockIdx.x == 2 * nbl;   // the y / W workgroup
     const bool col_only = A.role == 1;                         // LDS holds the current column of L only
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     auto lblk = [&](int bi, int bj) { return s_L + (size_t)(col_only ? bi - bj - 1 : tri(bi, bj)) * 32 * LB; };   // block (bi, bj), bi > bj
     auto dblk = [&](int k) { return s_D + (size_t)(col_only ? 0 : k) * 32 * LB; };
 
-    if (tid == 0 && A.started) __hip_atomic_fetch_add(A.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && A.started && it_first) __hip_atomic_fetch_add(A.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float pre_sdx2 = 0.f, pre_old = 0.f, pre_tot = 1.f;         // sum|dx|^2, old share of the running variance, new count
     double pre_scale = 0.0;                                     // mse -> new share of the running variance
     VJF_POST_STAMP(16);
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     float gpre[4][16], fpre[8];
     auto prefetch_tail = [&]() {
         // scalars of the state-noise update, fetched now so that the tail does not wait for them
-        pre_sdx2 = A.red[P.red_SC + RS_SDX2];
+        pre_sdx2 = it_red[P.red_SC + RS_SDX2];
         const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
         const float Bf = (float)A.B_total;
         const float acc = fminf(S[P.off[VJF_SLOT_SCALARS] + VJF_SC_N_TR], 500.f);   // running_var, size_cap=500 (model.py:375)
@@ -162,8 +171,8 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         pre_scale = 1.0 / ((double)Bf * (double)P.dz);
         // wavefront w: the lower 32x32 tiles w, w + 8, .. of G in the matrix-core accumulator layout, and FDX
         // (plain loads from clamped addresses: the tail masks what lies outside the matrix)
-        const float* G = A.red + P.red_G;
-        const float* FDX = A.red + P.red_FDX;
+        const float* G = it_red + P.red_G;
+        const float* FDX = it_red + P.red_FDX;
         const int c = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -187,11 +196,18 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     const int tile = wave & 1, grp = wave >> 1;                // owner of tile `tile` of blocks first + grp, first + grp + 4, ..
     const int xr = 4 * (lane >> 4), xc = lane & 15;            // accumulator element (row xr + r, column xc) of a 16x16 tile
     int bad = 0;
+    bool g_there = A.prep_count == nullptr;                    // g (and the state's P) from the operand kernel on another stream
+    auto wait_g = [&]() {
+        if (g_there) return;
+        g_there = true;
+        if (!vjf_wg_wait(A.prep_count, it_prep_target, tid)) { vjf_status_or(A.status, VJF_STATUS_RLS_FAILED); *s_dead = 1; }
+    };
     // ---- forward  Y_k = Dinv_k R_k ;  R_i -= L_ik Y_k  (i > k),   k = j0 .. nbl-1, column k of L staged when it appears
     for (int k = j0; k < nbl; ++k) {
-        bad = post_wait_column(A.flags, A.epoch, k, s_ctl, tid);
+        bad = post_wait_column(A.flags, it_epoch, k, s_ctl, tid);
         if (bad) break;
         if (solve && k == 0) {
+            wait_g();
             // Everything this workgroup takes from the kernels that precede the Cholesky kernel in its stream (g, the RLS
             // statistics) is read behind the first column flag of this epoch: the flag says those kernels are complete.
             for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
@@ -248,13 +264,13 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         }
         __syncthreads();
     }
-    if (!bad) bad = post_wait_column(A.flags, A.epoch, VJF_CHOL_MAXBLK, s_ctl, tid);   // the factor as a whole
+    if (!bad) bad = post_wait_column(A.flags, it_epoch, VJF_CHOL_MAXBLK, s_ctl, tid);   // the factor as a whole
     if (A.k1_done) {                                           // readers of W, w_chol, sigma on another stream: all done?
         if (tid == 0) {
             int st = 2;
             for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
                 const unsigned v = __hip_atomic_load(A.k1_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(v - A.k1_target) >= 0) { st = 0; break; }
+                if ((int)(v - it_k1_target) >= 0) { st = 0; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
             s_ctl[0] = st;
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         __syncthreads();
     }
     VJF_POST_STAMP(18);
-    if (bad == 2 && tid == 0) vjf_status_or(A.status, VJF_STATUS_RLS_FAILED);
+    if (bad == 2 && tid == 0) { vjf_status_or(A.status, VJF_STATUS_RLS_FAILED); *s_dead = 1; }
     const bool failed = bad != 0;                              // factorisation failed: RLS state stays as it was
     if (failed && !(solve && A.fold_sigma)) { leave(); return; }
 
@@ -332,6 +348,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     {
         double* s_p = reinterpret_cast<double*>(lds);          // one partial per wavefront (over s_L: the substitutions are done)
         if (failed) {                                          // sigma still moves, on the W that stays
+            wait_g();
             const float* Wold = A.state + P.off[VJF_SLOT_W_MEAN];
             for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
                 const int r = e >> 4, c = e & 15;
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
             prefetch_tail();                                   // (the failure may have come before the first column)
             if (A.undo_P) {                                    // exact up to one rounding, as the Cholesky kernel does on its own path
                 float* Pm = A.state + P.off[VJF_SLOT_W_PREC];
-                const float* G = A.red + P.red_G;
+                const float* G = it_red + P.red_G;
                 const float inv_v = expf(-S[P.off[VJF_SLOT_TR_LOGVAR]]);
                 for (int e = tid; e < n * n; e += VJF_POST_THREADS) Pm[e] = fmaf(-G[e], inv_v, Pm[e]);
             }
@@ -402,6 +419,47 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
         VJF_POST_STAMP(21);
     }
     leave();
+}
+
+// One pass (nsteps <= 0) or the persistent form: nsteps steps, one after the other (see VjfPostArgs::nsteps)
+__device__ __forceinline__ void vjf_rls_post_loop(const VjfPlan& P, const VjfPostArgs& A, float* lds, int* s_dead) {
+    const int steps = A.nsteps > 0 ? A.nsteps : 1;
+    for (int it = 0; it < steps; ++it) {
+        const float* red = ((A.step0 + it) & 1) ? A.red2 : A.red;
+        vjf_rls_post_body(P, A, lds, s_dead, A.epoch + (unsigned)it, red, A.k1_target + (unsigned)it * A.k1_stride,
+                          A.prep_target + (unsigned)it * A.prep_stride, it == 0);
+        __syncthreads();
+        if (*s_dead) break;
+    }
+}
+
+__global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan P, VjfPostArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_dead;                                     // a wait timed out: the persistent form stops (status says so)
+    if (threadIdx.x == 0) s_dead = 0;
+    __syncthreads();
+    vjf_rls_post_loop(P, A, lds, &s_dead);
+}
+
+// vjf_filter_seq, persistent RLS chain: workgroup 0 is the Cholesky kernel's loop, workgroup 1 the y / W workgroup's loop, for all
+// the steps of the sequence in ONE launch.  Each asks for a CU's whole LDS, so they sit on two CUs of their own from the first
+// step to the last: no launch, no gate and -- what decided it -- no waiting for a CU without trial-kernel workgroups on it between
+// sigma(t-1) and the first column of step t.  The 2 nbl inverse workgroups (one column of L in LDS, they share their CUs with the
+// trial kernel) are a second persistent launch of vjf_rls_post_kernel with role 1.
+template <int DZP>
+__global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_rls_pair_kernel(VjfPlan P, VjfCholArgs C, VjfPostArgs Q) {
+    static_assert(VJF_CHOL_THREADS == VJF_POST_THREADS, "one workgroup size for both halves");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_dead;
+    if (threadIdx.x == 0) s_dead = 0;
+    __syncthreads();
+    if (blockIdx.x == 0) vjf_chol_loop<DZP>(P, C, lds, &s_dead);
+    else vjf_rls_post_loop(P, Q, lds, &s_dead);
+}
+
+// += add, behind whatever precedes it in its stream (a collective that the consumers of *count wait for)
+__global__ void vjf_count_kernel(unsigned* count, unsigned add) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_fetch_add(count, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One wavefront that ends when `*count` has reached `target` (bounded): the next kernel of its stream then starts behind the
