@@ -696,8 +696,7 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
                        const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
     // (single rank only: a collective library may synchronise the device when it sets something up lazily, which kernels that
     //  stay resident for the whole sequence would turn into a time-out; VJF_PERSISTENT_DIST=1 tries it anyway)
-    if (c->persistent && !c->overlap_serial && c->mfma_trial && c->post_kernels && c->plan.dz <= 16 && !getenv("VJF_FUSED_SGD") &&
-        (!c->comm_a || getenv("VJF_PERSISTENT_DIST")))
+    if (c->persistent && !c->overlap_serial && c->mfma_trial && c->post_kernels && c->plan.dz <= 16 && (!c->comm_a || getenv("VJF_PERSISTENT_DIST")))
         return filter_seq_persist(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
     int rc = ensure_stream2(c);
     if (rc) return rc;
@@ -882,7 +881,9 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             hipLaunchKernelGGL(vjf_triclean_done_kernel, dim3(1), dim3(1), 0, sa, P, c->state);
             VJF_HIP(hipGetLastError());
         }
-        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1))) return rc;
+        // single rank: the SGD kernel sums the gradient slabs itself (one launch instead of reduce + SGD; VJF_NO_FUSED_SGD: two)
+        const bool fuse_sgd = !c->comm_a && getenv("VJF_NO_FUSED_SGD") == nullptr;
+        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1, nullptr, 0, fuse_sgd))) return rc;
         if (c->comm_a) {
             VJF_NCCL(nccl().group_start());
             int e1 = nccl().all_reduce(redg, redg, (size_t)P.train_len, kNcclFloat, kNcclSum, c->comm_a, sa);
@@ -891,9 +892,14 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             VJF_NCCL(e1);
             VJF_NCCL(e2);
         }
-        // (t == 0: the scalar workgroup ends once the persistent workgroups are resident -- before any backward half spins on them)
-        rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, nullptr, nullptr, 0,
-                         t == 0 ? runw : nullptr, epoch0, started, c->start_count);
+        // (t == 0: nothing of step 1 starts before the persistent workgroups are resident -- a backward half spins on them)
+        if (fuse_sgd) {
+            if (t == 0) hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, sa, (const unsigned*)runw, epoch0, (const unsigned*)started, c->start_count, stw);
+            rc = launch_sgd(c, B, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, ne, ng, sa, t & 1);
+        } else {
+            rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, nullptr, nullptr, 0,
+                             t == 0 ? runw : nullptr, epoch0, started, c->start_count);
+        }
         if (rc) return rc;
         if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
     }
