@@ -169,7 +169,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.tbig = take(P.n > 32 * VJF_CHOL_MAXBLK ? (size_t)P.n * P.n * 4 : 16);   // multi-launch RLS: T of the recursive inverse
     // GEMM-per-layer trial path (working set beyond LDS): [xs|u], pt.mean, pt.logvar, decoder output, Phi w_chol per trial
     c.wide = take(vjf_trial_mfma_lds_floats(P) * 4 > kMaxLds - 1024 ? (size_t)max_batch * (P.dxu + P.dz + 1 + P.dy + P.n) * 4 + 1024 : 16);
-    c.work = take(vjf_serial_work_floats(P) * 4 + 256);   // + 32 u64 diagnostic stamps
+    c.work = take(vjf_serial_work_floats(P) * 4 + 10 * 256);  // + 10 x 32 u64 diagnostic stamps (a ring over the steps of a sequence)
     c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
     c.flags = take(256);                                   // column flags of the Cholesky -> post hand-off (a block of their own)
     c.lscr = take((size_t)P.n * P.n * 4);                  // L, column by column, from the Cholesky kernel to the post kernel
@@ -214,6 +214,7 @@ struct vjf_ctx {
                            // but then the post kernel cannot be placed before the trial kernel has drained: measured slower)
     bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
                            // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
+    unsigned epoch_k1;     // diagnostic: epoch of the step whose backward half is launched next (ring entry of its stamps)
     bool persistent;       // vjf_filter_seq: the RLS chain as persistent kernels (default; VJF_NO_PERSISTENT turns it off)
     unsigned start_count;  // host mirror of the post kernel's "workgroups started" count
     unsigned stat_count, prep_count;   // host mirrors of the "statistics reduced" / "operand rows done" workgroup counts
@@ -397,10 +398,21 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status) {
 
 int vjf_debug_stamps(vjf_ctx* ctx, int enable, uint64_t* out32) {
     if (!ctx) return fail(-1, "vjf_debug_stamps: null context");
-    ctx->stamps = enable != 0;
-    ctx->stamps_keep_overlap = enable == 2;
+    int ring = 0;
+    if (enable >= 64) {                                      // 64 + k: 256-byte chunk k of the trial kernel's per-workgroup partials (even steps)
+        if (out32) {
+            VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.partial + (size_t)(enable - 64) * 256, 256, hipMemcpyDeviceToHost, ctx->stream));
+            VJF_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return 0;
+    }
+    if (enable >= 16) ring = (enable - 16) % 10;             // 16 + k: ring entry k (steps with epoch % 8 == k; 8: forward halves), mode unchanged
+    else {
+        ctx->stamps = enable != 0;
+        ctx->stamps_keep_overlap = enable == 2;
+    }
     if (out32) {
-        VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.work + vjf_serial_work_floats(ctx->plan) * 4, 256, hipMemcpyDeviceToHost, ctx->stream));
+        VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.work + vjf_serial_work_floats(ctx->plan) * 4 + ring * 256, 256, hipMemcpyDeviceToHost, ctx->stream));
         VJF_HIP(hipStreamSynchronize(ctx->stream));
     }
     return 0;
@@ -459,6 +471,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
         if (part != 1) c->k1_count += (unsigned)nblk;
         if (part == 1 && count_fwd) { m.fwd_done = (unsigned*)(c->ws + c->cv.flags) + 48; c->fwd_count += (unsigned)nblk; }
         m.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
+        if (m.stamps && c->stamps_keep_overlap) m.stamps += part == 1 ? 8 * 32 : (rls_done ? (c->epoch_k1 & 7u) * 32 : 0);   // ring entry (diagnostic)
         VJF_LAUNCH(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, stop, P, m);
     } else {
         // working set beyond LDS: one GEMM over all trials per layer (vjf_trial_wide.h)
@@ -874,6 +887,7 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, prepc))) return rc;
         c->prep_count += nprep;
         // sa: backward half(t); it waits in-kernel for post(t-1), whose workgroups are resident
+        c->epoch_k1 = epoch0 + (unsigned)t;
         if ((rc = launch_trial(c, args(t), 2, sa, nullptr, false, t > 0 ? pdone : nullptr, post_before))) return rc;
         c->post_count += npost;
         if (t == 0) {

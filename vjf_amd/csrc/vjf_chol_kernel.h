@@ -601,7 +601,7 @@ struct VjfCholArgs {
     const float* gbuf;     // from vjf_prep_kernel
     int B_total;
     unsigned flags;
-    unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memtime at phase boundaries
+    unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memrealtime (100 MHz, one clock for the whole device) at phase boundaries
     float* dinv_out;       // post mode: nbl blocks (32x32 row-major) of inverted diagonal blocks for vjf_rls_post_kernel
     int* ok_out;           // post mode: 1 = factor valid
     int post;              // 1: stop after L and the inverted diagonal blocks; the many-CU post kernels do the rest
@@ -630,8 +630,8 @@ struct VjfCholArgs {
     do {                                                                                    \
         if (A.stamps && tid == 0) {                                                         \
             unsigned long long t_;                                                          \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
-            A.stamps[i] = t_;                                                               \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+            A.stamps[((it_epoch & 7u) << 5) * (A.nsteps > 0 ? 1 : 0) + (i)] = t_;              \
         }                                                                                   \
     } while (0)
 

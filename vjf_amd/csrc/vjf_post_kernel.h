@@ -52,15 +52,15 @@ struct VjfPostArgs {
     int undo_P;             // 1: the operand kernel that ran before this one on its stream added Phi^T Phi / v to the state's P without
                             //    knowing whether the factorisation would succeed: on failure the y / W workgroup takes it back
     int fold_sigma;         // 1: the y / W workgroup goes on to the state-noise update (no vjf_resid / vjf_sigma launch)
-    unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memtime of the y / W workgroup, slots 16..21
+    unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memrealtime of the y / W workgroup, slots 16..21
 };
 
 #define VJF_POST_STAMP(i)                                                                   \
     do {                                                                                    \
         if (A.stamps && solve && tid == 0) {                                                \
             unsigned long long t_;                                                          \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
-            A.stamps[i] = t_;                                                               \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+            A.stamps[((it_epoch & 7u) << 5) * (A.nsteps > 0 ? 1 : 0) + (i)] = t_;              \
         }                                                                                   \
     } while (0)
 

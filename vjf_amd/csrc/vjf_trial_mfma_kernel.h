@@ -87,7 +87,7 @@ struct VjfTrialMfmaArgs {
     do {                                                                                    \
         if (AA.stamps && blockIdx.x == 0 && threadIdx.x == 0) {                             \
             unsigned long long t_;                                                          \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
             AA.stamps[i] = t_;                                                              \
         }                                                                                   \
     } while (0)
@@ -140,6 +140,8 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     float* s_plv = s_red + 16 * NW;              // 16 pt.logvar
 
     VJF_K1_STAMP(22);
+    unsigned long long t_begin_ = 0;
+    if (AA.stamps && tid == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin_)::"memory");
     // ---- stage 0: inputs (coalesced global reads, transposed LDS writes), eps_t, xs
     for (int b = wave; b < 16; b += NW) {            // wavefront w stages trials w, w+4, ..; the lane walks the columns
         const bool ok = b < nb;
@@ -484,7 +486,6 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         }
     }
 
-    VJF_K1_STAMP(29);
     // ---- stage 7: rows of E = [Phi | dx | 0], ACT = [in|1|h_1|1|..|h_L|1|xt|1|0], DEL = [.. | dmu | dlv | dpy].
     //      wavefront w writes the rows of trials w, w+4, ...; the lane walks the columns (coalesced, no divisions)
     for (int b = wave; b < nb; b += NW) {
@@ -511,6 +512,19 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         for (int c = lane; c < 2 * dz + dy; c += 64) drow[c] = c < 2 * dz ? s_dmu[c * LD + b] : s_dpy[(c - 2 * dz) * LD + b];   // s_dlv follows s_dmu
     }
     VJF_K1_STAMP(30);
+    if (AA.stamps && tid == 0) {
+        // diagnostic: when the LAST workgroup ends (slot 29), and per workgroup its start / end (10 ns ticks after block 0's start)
+        // and placement, in the unused columns of its loss partials (tools/k1_tail.py)
+        unsigned long long t_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        atomicMax(AA.stamps + 29, t_);
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        A.partial[(size_t)blockIdx.x * RS_N + 7] = (float)(long long)(t_ - AA.stamps[22]);
+        A.partial[(size_t)blockIdx.x * RS_N + 5] = (float)(long long)(t_begin_ - AA.stamps[22]);
+        A.partial[(size_t)blockIdx.x * RS_N + 6] = (float)(((xcc & 15u) << 8) | ((hw >> 8) & 15u) | (((hw >> 13) & 7u) << 4));   // xcc | se | cu
+    }
     if (AA.done && bwd && tid == 0) __hip_atomic_fetch_add(AA.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (AA.fwd_done && !bwd) {
         // producer side of a hand-off between launches on different streams (MI355X guide, visibility, valid forms): every
