@@ -176,10 +176,38 @@ __global__ __launch_bounds__(1024) void vjf_sgd_kernel(VjfPlan P, VjfSgdArgs A) 
 #pragma unroll
         for (int q = 0; q < 16; ++q) sv[q] = q < A.nsplit ? slab[(size_t)q * 1024 + tid] : 0.f;
     }
+    // ... and so is everything else the update needs: the job, the learning rates, the parameter itself
+    bool valid = false, dec = false;
+    int tens = 0, pidx = 0;
+    float w_old = 0.f, lr = 0.f;
+    if (tile) {
+        const VjfJob job = A.jobs[A.job0 + blockIdx.x];
+        const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
+        const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
+        const int i = tid >> 5, j = tid & 31;
+        if (i < job.xn && j < job.yn) {
+            if (j < job.ncol_w) { tens = job.tw; pidx = job.dst + i * job.ld + j; valid = true; }
+            else if (j == job.ncol_w && job.dst_b >= 0) { tens = job.tb; pidx = job.dst_b + i; valid = true; }
+        }
+        if (valid) {
+            dec = P.tr_dec[tens] != 0;
+            if (dec && freeze) valid = false;
+            lr = dec ? lr_dec : lr_rec;
+        }
+        if (valid) w_old = S[P.train_off + pidx];
+    }
     if (tid < 256) {
         const int sc = tid >> 5, l = tid & 31;
         double v = 0.0;
-        for (int b = l; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
+        int b = l;
+        for (; b + 7 * 32 < A.nblocks_k1; b += 8 * 32) {           // 8 loads in flight, summed in the same order
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = A.partial[(size_t)(b + 32 * q) * RS_N + sc];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += (double)t[q];
+        }
+        for (; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
         s_part[tid] = v;
     }
     __syncthreads();
@@ -197,9 +225,6 @@ __global__ __launch_bounds__(1024) void vjf_sgd_kernel(VjfPlan P, VjfSgdArgs A) 
     const bool grad_ok = ok_r && ok_h && (warm || ok_d);
     if ((int)blockIdx.x < A.njobs) {
         if (!(do_sgd && grad_ok)) return;
-        const VjfJob job = A.jobs[A.job0 + blockIdx.x];
-        const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
-        const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
         {
             const int e = tid;
             float v = 0.f;
@@ -209,18 +234,12 @@ __global__ __launch_bounds__(1024) void vjf_sgd_kernel(VjfPlan P, VjfSgdArgs A) 
             } else {
                 for (int s2 = 0; s2 < A.nsplit; ++s2) v += slab[(size_t)s2 * 1024 + e];
             }
-            const int i = e >> 5, j = e & 31;
-            if (i >= job.xn || j >= job.yn) return;
-            int tens, pidx;
-            if (j < job.ncol_w) { tens = job.tw; pidx = job.dst + i * job.ld + j; }
-            else if (j == job.ncol_w && job.dst_b >= 0) { tens = job.tb; pidx = job.dst_b + i; }
-            else return;
-            if (P.tr_dec[tens] && freeze) return;
+            if (!valid) return;
             const int cols = P.tr_cols[tens], rel = pidx - (P.tr_off[tens] - P.train_off);
             const int r = rel / cols, c = rel - r * cols;
             float g = v * invB;
             g = fminf(fmaxf(g, -1.f), 1.f);
-            const float w = S[P.train_off + pidx] - (P.tr_dec[tens] ? lr_dec : lr_rec) * g;
+            const float w = w_old - lr * g;
             S[P.train_off + pidx] = w;
             if (P.tr_aux[tens] >= 0) A.aux[P.tr_aux[tens] + (size_t)c * P.tr_auxld[tens] + P.tr_auxcol[tens] + r] = w;
         }

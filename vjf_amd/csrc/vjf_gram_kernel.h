@@ -118,7 +118,15 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
         const int sc = (tid >> 5) & 7, l = tid & 31;
         double v = 0.0;
         if (tid < 256) {
-            for (int b = l; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
+            int b = l;
+            for (; b + 7 * 32 < A.nblocks_k1; b += 8 * 32) {       // 8 loads in flight, summed in the same order
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = A.partial[(size_t)(b + 32 * q) * RS_N + sc];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v += (double)t[q];
+            }
+            for (; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
             s_part[tid] = v;
         }
         __syncthreads();
