@@ -29,7 +29,7 @@ __device__ __forceinline__ void mma_tile(vjf_f32x4& acc, const float* __restrict
     const bool rv = (m0 + i) < M;
     const float* ap = Ag + m0 + i + (size_t)kk * lda;
     const float* xp = Xs + kk * VJF_LDT + i;
-    const int K4 = K & ~3, K32 = K & ~31;
+    const int K32 = K & ~31;
     int k0 = 0;
     if (K32 > 0) {                                     // batches of 8 steps, the next batch's 16 operand loads in flight
         float a0[8], x0[8], a1[8], x1[8];              // while the current batch's MFMAs issue
@@ -54,16 +54,22 @@ __device__ __forceinline__ void mma_tile(vjf_f32x4& acc, const float* __restrict
             if (!more0) { k0 += 64; break; }
         }
     }
-    for (; k0 < K4; k0 += 4) {
-        const float a = rv ? ap[(size_t)k0 * lda] : 0.f;
-        const float x = xp[k0 * VJF_LDT];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x, acc, 0, 0, 0);
-    }
-    if (K4 < K) {
-        const bool kv = (K4 + kk) < K;
-        const float a = (rv && kv) ? ap[(size_t)K4 * lda] : 0.f;
-        const float x = kv ? xp[K4 * VJF_LDT] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x, acc, 0, 0, 0);
+    // remainder (< 32 rows): its up to 8 steps' operands in flight together (clamped addresses, masked at use), then the same
+    // MFMA steps in the same order as a step-by-step loop would issue them
+    if (k0 < K) {
+        const float* apc = Ag + (rv ? m0 + i : 0) + (size_t)kk * lda;   // (rows beyond M: a valid address, masked below)
+        float ar[8], xr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + 4 * q + kk;
+            const bool kv = k < K;
+            const float av = apc[(size_t)(kv ? k0 + 4 * q : 0) * lda], xv = xp[(kv ? k0 + 4 * q : 0) * VJF_LDT];
+            ar[q] = (rv && kv) ? av : 0.f;
+            xr[q] = kv ? xv : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (k0 + 4 * q < K) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[q], xr[q], acc, 0, 0, 0);   // (uniform)
     }
 }
 
