@@ -30,6 +30,9 @@ if ROOT not in sys.path:
 CFG = dict(B=4096, dz=10, dy=50, du=0, n=200, hidden=[128], lik="gaussian")     # BASELINE.json configs[1]: the headline workload
 OTHER_CFGS = {"C": dict(B=4096, dz=10, dy=200, du=0, n=200, hidden=[128], lik="poisson"),          # configs[2]
               "E": dict(B=4096, dz=64, dy=512, du=0, n=1000, hidden=[512, 512], lik="gaussian")}   # configs[4]
+# torch.distributed is the control plane only (rendezvous, barrier, max of the wall times, the RCCL ids): the data path's two
+# all-reduces per step are RCCL calls inside vjf_filter_seq on its own streams
+CTRL_BACKEND = os.environ.get("VJF_BENCH_BACKEND", "nccl")
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 vector == f32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic_current.json")   # tools/pmc_traffic.sh on this build
@@ -134,12 +137,12 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(CTRL_BACKEND, **({"device_id": dev} if CTRL_BACKEND == "nccl" else {}))
     elif a.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ["VJF_FORCE_DIST"] = "1"
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group(CTRL_BACKEND, rank=0, world_size=1, **({"device_id": dev} if CTRL_BACKEND == "nccl" else {}))
 
     import vjf_amd
     from vjf_amd import _native as N
@@ -176,7 +179,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     dev_s = ev0.elapsed_time(ev1) * 1e-3
-    tt = torch.tensor([wall], device=dev, dtype=torch.float64)
+    tt = torch.tensor([wall], device=dev if CTRL_BACKEND == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wall_max = float(tt.item())
@@ -225,7 +228,8 @@ def main():
             import csv
             ks = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_kernel_stats.csv")))
             rows = list(csv.DictReader(open(ks[-1])))
-            steps_in_profile = max(int(r["Calls"]) for r in rows if "chol" in r["Name"] or "serial" in r["Name"])
+            # (one operand kernel / Cholesky / serial kernel per step; the persistent RLS kernels are one launch per sequence)
+            steps_in_profile = max(int(r["Calls"]) for r in rows if "prepg" in r["Name"] or "chol" in r["Name"] or "serial" in r["Name"])
             kstats = {"file": "profiles/" + os.path.basename(ks[-1]),
                       "kernels": [{"name": r["Name"].split("(")[0].replace("void ", ""), "avg_us": float(r["AverageNs"]) / 1e3,
                                    "launches_per_step": round(int(r["Calls"]) / steps_in_profile, 2)}
@@ -246,8 +250,9 @@ def main():
                                          "summed over the kernels of a step (profiles/pmc_traffic_current.json); algorithmic bytes "
                                          "per step = bytes_per_trial_step x trials",
                          "kernel": "one filter step = vjf_trial_mfma_kernel (forward + backward half), vjf_gram_kernel x2, "
-                                   "vjf_gram_reduce_kernel x2, vjf_prep_kernel x2, vjf_chol_lds_kernel, vjf_rls_post_kernel on three "
-                                   "streams (HIP events around the timed region / steps)",
+                                   "vjf_gram_reduce_kernel, vjf_sgd_kernel, vjf_prepg_kernel, two gate kernels, and one step's share "
+                                   "of the persistent vjf_rls_pair_kernel (Cholesky + y/W) and vjf_rls_post_kernel (inverse) that "
+                                   "serve the whole sequence; four streams (HIP events around the timed region / steps)",
                          "flops_per_trial_step": flops, "serial_flops_per_step": serial_flops,
                          "rocprof_kernel_averages": kstats,
                          "step_us": step_s * 1e6, "host_enqueue_us_per_step": enq / K * 1e6, "trial_half_us": loc, "serial_half_us": glob,

@@ -415,11 +415,14 @@ class VJF(Module):
         ids = (ctypes.c_char * 256)()
         ok = (os.environ.get("VJF_NATIVE_RCCL", "1") != "0" and self._overlap_flag() and L.vjf_set_overlap(self._ctx, int(getattr(self, "_overlap", 1))) >= 1
               and L.vjf_comm_unique_id(ids) == 0)
-        flag = torch.tensor([1 if ok else 0], device=self._blob.device, dtype=torch.int32)
+        # (control plane only: with a gloo group the two exchanges go through host tensors and no collective stream of
+        #  torch's is created beside the four of vjf_filter_seq)
+        cdev = "cpu" if dist.get_backend() == "gloo" else self._blob.device
+        flag = torch.tensor([1 if ok else 0], device=cdev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # every rank takes the same route
         if int(flag.item()) == 0:
             return False
-        t = torch.frombuffer(bytearray(bytes(ids)), dtype=torch.uint8).to(self._blob.device)
+        t = torch.frombuffer(bytearray(bytes(ids)), dtype=torch.uint8).to(cdev)
         dist.broadcast(t, src=0)
         buf = (ctypes.c_char * 256).from_buffer_copy(t.cpu().numpy().tobytes())
         N.check(L.vjf_comm_init(self._ctx, buf, dist.get_rank(), world), "vjf_comm_init")
