@@ -616,12 +616,20 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
     a.post = c->post_kernels ? 1 : 0; a.dinv_out = dinv; a.ok_out = okflag; a.lscr = (float*)(c->ws + c->cv.lscr);
     a.flags_out = colflags; a.epoch = ++c->epoch; a.no_triclean = no_triclean ? 1 : 0;
     a.pscr = (float*)(c->ws + c->cv.pscr); a.self_prep = self_prep ? 1 : 0; a.wait_count = wait_count; a.wait_target = wait_target;
-    switch (vjf_chol_dzp(P.dz)) {
-        case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
-        case 8: hipLaunchKernelGGL(vjf_chol_lds_kernel<8>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
-        case 12: hipLaunchKernelGGL(vjf_chol_lds_kernel<12>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
-        case 16: hipLaunchKernelGGL(vjf_chol_lds_kernel<16>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
-        default: hipLaunchKernelGGL(vjf_chol_lds_kernel<32>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+    // Sequence with a collective library in the process (sharded trials): the whole RLS update -- Cholesky workgroup, y / W
+    // workgroup, inverse workgroups -- goes out as ONE launch on `st` (the operand kernel precedes it there, so g is in place).
+    // With the library's streams beside ours, a third or fourth stream of ours ends up sharing a hardware queue with the
+    // caller's stream, and its spinning kernel then sits in front of the trial / SGD chain (measured: 119 us/step).
+    const bool pair = c->post_kernels && !(flags & VJF_FLAG_WARM_UP) && st_inv && st_inv != st_post && st_post != st && P.dz <= 16 && !self_prep &&
+                      (c->comm_a ? getenv("VJF_NO_PAIR") == nullptr : getenv("VJF_PAIR") != nullptr);
+    if (!pair) {
+        switch (vjf_chol_dzp(P.dz)) {
+            case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+            case 8: hipLaunchKernelGGL(vjf_chol_lds_kernel<8>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+            case 12: hipLaunchKernelGGL(vjf_chol_lds_kernel<12>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+            case 16: hipLaunchKernelGGL(vjf_chol_lds_kernel<16>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+            default: hipLaunchKernelGGL(vjf_chol_lds_kernel<32>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
+        }
     }
     VJF_HIP(hipGetLastError());
     if (c->post_kernels) {
@@ -650,7 +658,18 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
             pa.done = colflags + 32; pa.started = colflags + 24; c->post_count += (unsigned)(2 * nbl + 1);
             c->start_count += (unsigned)(2 * nbl + 1);
             pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
-            if (st_inv && st_inv != st_post) {
+            if (pair) {
+                // (every workgroup of the launch asks for the Cholesky workgroup's LDS; the inverse workgroups keep trial-kernel
+                //  workgroups off their CUs anyway, through their registers)
+                pa.role = 2;
+                const dim3 grid(2 + 2 * nbl);
+                switch (vjf_chol_dzp(P.dz)) {
+                    case 4: VJF_LAUNCH(vjf_rls_pair_kernel<4>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
+                    case 8: VJF_LAUNCH(vjf_rls_pair_kernel<8>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
+                    case 12: VJF_LAUNCH(vjf_rls_pair_kernel<12>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
+                    default: VJF_LAUNCH(vjf_rls_pair_kernel<16>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
+                }
+            } else if (st_inv && st_inv != st_post) {
                 // two launches: the inverse workgroups keep one column of L in LDS and share their CUs with the trial kernel;
                 // the y / W workgroup (all of L in LDS) runs beside them on its own stream
                 pa.role = 1;

@@ -114,13 +114,13 @@ __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned 
 
 __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPostArgs& A, float* lds, int* s_dead, const unsigned it_epoch,
                                                   const float* it_red, const unsigned it_k1_target, const unsigned it_prep_target,
-                                                  const bool it_first) {
+                                                  const bool it_first, const int role, const int bix) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));                               // (see vjf_chol_body: nothing lane-dependent is hoisted out of the step loop)
     const int lane = tid & 63, wave = tid >> 6;
     const int n = P.n, dz = P.dz, nbl = (n + 31) / 32, ntri = nbl * (nbl + 1) / 2, nlow = ntri - nbl;
-    const bool solve = A.role == 2 || (int)blockIdx.x == 2 * nbl;   // the y / W workgroup
-    const bool col_only = A.role == 1;                         // LDS holds the current column of L only
+    const bool solve = role == 2 || bix == 2 * nbl;            // the y / W workgroup
+    const bool col_only = role == 1;                           // LDS holds the current column of L only
     constexpr int LB = VJF_POST_LDB, LX = VJF_POST_LDX;
     float* s_L = lds;                                          // strictly-lower blocks [32][33] of L (bi > bj); col_only: (i - k - 1)
     float* s_D = s_L + (size_t)(col_only ? nbl - 1 : nlow) * 32 * LB;   // nbl blocks [32][33]: inverted diagonal blocks; col_only: one
@@ -135,8 +135,8 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
     };
     const float* S = A.state;
     const float* Lm = A.lscr;
-    const int j0 = solve ? 0 : (int)blockIdx.x >> 1;           // first block row of the substitution
-    const int c0 = solve ? 0 : 16 * ((int)blockIdx.x & 1);
+    const int j0 = solve ? 0 : bix >> 1;                       // first block row of the substitution
+    const int c0 = solve ? 0 : 16 * (bix & 1);
     auto tri = [](int bi, int bj) { return bi * (bi - 1) / 2 + bj; };       // strictly lower: bi > bj
     auto lblk = [&](int bi, int bj) { return s_L + (size_t)(col_only ? bi - bj - 1 : tri(bi, bj)) * 32 * LB; };   // block (bi, bj), bi > bj
     auto dblk = [&](int k) { return s_D + (size_t)(col_only ? 0 : k) * 32 * LB; };
@@ -290,7 +290,7 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
             {
                 float* Ls = A.state + P.off[VJF_SLOT_W_PCHOL];
                 const int nq = n * n / 4, per = (nq + 2 * nbl - 1) / (2 * nbl);
-                const int q0 = (int)blockIdx.x * per, q1 = min(nq, q0 + per);
+                const int q0 = bix * per, q1 = min(nq, q0 + per);
                 for (int q = q0 + tid; q < q1; q += VJF_POST_THREADS) {
                     const int e = 4 * q, i = e / n, j = e - i * n;
                     if ((j >> 5) <= (i >> 5)) *reinterpret_cast<float4*>(Ls + e) = *reinterpret_cast<const float4*>(A.lscr + e);
@@ -422,12 +422,12 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
 }
 
 // One pass (nsteps <= 0) or the persistent form: nsteps steps, one after the other (see VjfPostArgs::nsteps)
-__device__ __forceinline__ void vjf_rls_post_loop(const VjfPlan& P, const VjfPostArgs& A, float* lds, int* s_dead) {
+__device__ __forceinline__ void vjf_rls_post_loop(const VjfPlan& P, const VjfPostArgs& A, float* lds, int* s_dead, const int role, const int bix) {
     const int steps = A.nsteps > 0 ? A.nsteps : 1;
     for (int it = 0; it < steps; ++it) {
         const float* red = ((A.step0 + it) & 1) ? A.red2 : A.red;
         vjf_rls_post_body(P, A, lds, s_dead, A.epoch + (unsigned)it, red, A.k1_target + (unsigned)it * A.k1_stride,
-                          A.prep_target + (unsigned)it * A.prep_stride, it == 0);
+                          A.prep_target + (unsigned)it * A.prep_stride, it == 0, role, bix);
         __syncthreads();
         if (*s_dead) break;
     }
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan 
     __shared__ int s_dead;                                     // a wait timed out: the persistent form stops (status says so)
     if (threadIdx.x == 0) s_dead = 0;
     __syncthreads();
-    vjf_rls_post_loop(P, A, lds, &s_dead);
+    vjf_rls_post_loop(P, A, lds, &s_dead, A.role, (int)blockIdx.x);
 }
 
 // vjf_filter_seq, persistent RLS chain: workgroup 0 is the Cholesky kernel's loop, workgroup 1 the y / W workgroup's loop, for all
@@ -453,8 +453,10 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_rls_pair_kernel(VjfPlan 
     __shared__ int s_dead;
     if (threadIdx.x == 0) s_dead = 0;
     __syncthreads();
+    // (gridDim.x > 2: workgroups 2.. are the inverse workgroups -- the whole RLS update in one launch, one stream)
     if (blockIdx.x == 0) vjf_chol_loop<DZP>(P, C, lds, &s_dead);
-    else vjf_rls_post_loop(P, Q, lds, &s_dead);
+    else if (blockIdx.x == 1) vjf_rls_post_loop(P, Q, lds, &s_dead, 2, 0);
+    else vjf_rls_post_loop(P, Q, lds, &s_dead, 1, (int)blockIdx.x - 2);
 }
 
 // += add, behind whatever precedes it in its stream (a collective that the consumers of *count wait for)
