@@ -215,6 +215,7 @@ struct vjf_ctx {
     bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
                            // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
     unsigned epoch_k1;     // diagnostic: epoch of the step whose backward half is launched next (ring entry of its stamps)
+    bool queues_ok;        // the four streams of vjf_filter_seq run beside each other (probed when they are created)
     bool persistent;       // vjf_filter_seq: the RLS chain as persistent kernels (default; VJF_NO_PERSISTENT turns it off)
     unsigned start_count;  // host mirror of the post kernel's "workgroups started" count
     unsigned stat_count, prep_count;   // host mirrors of the "statistics reduced" / "operand rows done" workgroup counts
@@ -711,6 +712,31 @@ int ensure_stream2(vjf_ctx* c) {
     VJF_HIP(hipEventCreate(&c->ev_c));
     VJF_HIP(hipEventCreate(&c->ev_a));          // (default flags: the events are attached to kernel launches)
     VJF_HIP(hipEventCreate(&c->ev_s));
+    // Do the four streams run beside each other?  Consumers first (the worst case): a waiter on sd, sc, sb, each followed in its
+    // stream by the setter of the next one's flag; the caller's stream sets the first flag.  On hardware queues of their own
+    // all of it completes in microseconds; if two of the streams share a queue a waiter sits in front of the setter it waits
+    // for and times out (~1 ms): the persistent kernels are then not used (the per-step launches only get slower).
+    {
+        unsigned* f = (unsigned*)(c->ws + c->cv.flags) + 56;                   // [56..58] flags, [59] time-outs
+        const unsigned tag = 0x5eed0000u + (unsigned)c->epoch;
+        VJF_HIP(hipMemsetAsync(f, 0, 16, c->stream));
+        VJF_HIP(hipStreamSynchronize(c->stream));
+        hipLaunchKernelGGL(vjf_probe_wait_kernel, dim3(1), dim3(64), 0, c->stream4, (const unsigned*)(f + 2), tag, f + 3);
+        hipLaunchKernelGGL(vjf_probe_wait_kernel, dim3(1), dim3(64), 0, c->stream3, (const unsigned*)(f + 1), tag, f + 3);
+        hipLaunchKernelGGL(vjf_probe_set_kernel, dim3(1), dim3(64), 0, c->stream3, f + 2, tag);
+        hipLaunchKernelGGL(vjf_probe_wait_kernel, dim3(1), dim3(64), 0, c->stream2, (const unsigned*)f, tag, f + 3);
+        hipLaunchKernelGGL(vjf_probe_set_kernel, dim3(1), dim3(64), 0, c->stream2, f + 1, tag);
+        hipLaunchKernelGGL(vjf_probe_set_kernel, dim3(1), dim3(64), 0, c->stream, f, tag);
+        VJF_HIP(hipGetLastError());
+        unsigned timed_out = 0;
+        VJF_HIP(hipStreamSynchronize(c->stream2));
+        VJF_HIP(hipStreamSynchronize(c->stream3));
+        VJF_HIP(hipStreamSynchronize(c->stream4));
+        VJF_HIP(hipMemcpyAsync(&timed_out, f + 3, 4, hipMemcpyDeviceToHost, c->stream));
+        VJF_HIP(hipStreamSynchronize(c->stream));
+        c->queues_ok = timed_out == 0;
+        if (getenv("VJF_VERBOSE")) fprintf(stderr, "vjf: stream probe: %s\n", c->queues_ok ? "four independent queues" : "streams share a hardware queue");
+    }
     return 0;
 }
 
@@ -728,7 +754,8 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
                        const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
     // (single rank only: a collective library may synchronise the device when it sets something up lazily, which kernels that
     //  stay resident for the whole sequence would turn into a time-out; VJF_PERSISTENT_DIST=1 tries it anyway)
-    if (c->persistent && !c->overlap_serial && c->mfma_trial && c->post_kernels && c->plan.dz <= 16 && (!c->comm_a || getenv("VJF_PERSISTENT_DIST")))
+    if (c->persistent && !c->overlap_serial) { int rc0 = ensure_stream2(c); if (rc0) return rc0; }
+    if (c->persistent && c->queues_ok && !c->overlap_serial && c->mfma_trial && c->post_kernels && c->plan.dz <= 16 && (!c->comm_a || getenv("VJF_PERSISTENT_DIST")))
         return filter_seq_persist(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
     int rc = ensure_stream2(c);
     if (rc) return rc;

@@ -459,6 +459,21 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_rls_pair_kernel(VjfPlan 
     else vjf_rls_post_loop(P, Q, lds, &s_dead, 1, (int)blockIdx.x - 2);
 }
 
+// Queue probe (vjf_filter_seq, once per context): a kernel that waits (bounded, ~1 ms) for *flag to become `want` and reports
+// a time-out, and one that sets it.  Kernels that spin on kernels of other streams need those streams on hardware queues of
+// their own; the runtime multiplexes streams onto a few queues, so that is checked, not assumed.
+__global__ void vjf_probe_wait_kernel(const unsigned* flag, unsigned want, unsigned* timed_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (unsigned spins = 0; spins < (1u << 12); ++spins) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __hip_atomic_fetch_add(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void vjf_probe_set_kernel(unsigned* flag, unsigned value) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // += add, behind whatever precedes it in its stream (a collective that the consumers of *count wait for)
 __global__ void vjf_count_kernel(unsigned* count, unsigned add) {
     if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_fetch_add(count, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
