@@ -140,6 +140,27 @@ def test_filter_sequence_equals_steps(vjf, name):
     close(mu, z["out.mu"], **POST)
 
 
+def test_filter_sequence_persistent_equals_per_step_launches(vjf, monkeypatch):
+    """vjf_filter_seq's persistent RLS kernels (one launch per sequence, the Cholesky loop forms P + G/v itself) against the
+    same sequence with a Cholesky / post launch per step: every output and the whole state blob bit for bit."""
+    z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
+    y, eps = torch.tensor(z["y"]), torch.tensor(z["eps"])
+    outs = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("VJF_NO_PERSISTENT", env)     # (read when the context is created)
+        m = _model_for(vjf, info)
+        load_fixture_state(m, z, "s0")
+        o = m.filter_sequence(y, None, None, eps=eps)
+        o2 = m.filter_sequence(y, None, None, eps=eps)       # a second sequence: the persistent kernels start from the state's P again
+        assert m.status() == 0
+        outs.append((o, o2, m._blob.clone()))
+    monkeypatch.delenv("VJF_NO_PERSISTENT", raising=False)
+    for a, b in zip(outs[0][0] + outs[0][1], outs[1][0] + outs[1][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][2], outs[1][2])
+
+
 def test_filter_sequence_two_stream_equals_one_stream(vjf):
     """vjf_filter_seq's two-stream schedule (RLS chain beside the trial / SGD chain) is a re-ordering of independent
     kernels only: every output and the whole state blob match the one-stream order bit for bit."""
@@ -295,6 +316,8 @@ def test_rls_failure_is_flagged_and_leaves_rls_state(vjf):
             assert model.status() & 8
             for k in ("w_mean", "w_chol", "w_pchol"):
                 assert torch.equal(getattr(lr, k), keep[k]), k
+            # (sequence path: the operand kernel adds G / v beside the Cholesky loop, the y / W loop takes it back on failure)
+            close(lr.w_precision, keep["w_precision"], rtol=1e-5, atol=5e-2)
             assert torch.isfinite(model.transition.logvar).all()
 
 
