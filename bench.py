@@ -251,8 +251,8 @@ def main():
                                          "per step = bytes_per_trial_step x trials",
                          "kernel": "one filter step = vjf_trial_mfma_kernel (forward + backward half), vjf_gram_kernel x2, "
                                    "vjf_gram_reduce_kernel, vjf_sgd_kernel, vjf_prepg_kernel, two gate kernels, and one step's share "
-                                   "of the persistent vjf_rls_pair_kernel (Cholesky + y/W) and vjf_rls_post_kernel (inverse) that "
-                                   "serve the whole sequence; four streams (HIP events around the timed region / steps)",
+                                   "of the persistent vjf_rls_pair_kernel (Cholesky, y/W and inverse workgroups) that "
+                                   "serve the whole sequence; three streams (HIP events around the timed region / steps)",
                          "flops_per_trial_step": flops, "serial_flops_per_step": serial_flops,
                          "rocprof_kernel_averages": kstats,
                          "step_us": step_s * 1e6, "host_enqueue_us_per_step": enq / K * 1e6, "trial_half_us": loc, "serial_half_us": glob,

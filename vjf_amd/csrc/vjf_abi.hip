@@ -712,8 +712,8 @@ int ensure_stream2(vjf_ctx* c) {
     VJF_HIP(hipEventCreate(&c->ev_c));
     VJF_HIP(hipEventCreate(&c->ev_a));          // (default flags: the events are attached to kernel launches)
     VJF_HIP(hipEventCreate(&c->ev_s));
-    // Do the four streams run beside each other?  Consumers first (the worst case): a waiter on sd, sc, sb, each followed in its
-    // stream by the setter of the next one's flag; the caller's stream sets the first flag.  On hardware queues of their own
+    // Do the streams run beside each other?  Consumers first (the worst case): a waiter on sc and on sb, the latter followed in its
+    // stream by the setter of the former's flag; the caller's stream sets the first flag.  On hardware queues of their own
     // all of it completes in microseconds; if two of the streams share a queue a waiter sits in front of the setter it waits
     // for and times out (~1 ms): the persistent kernels are then not used (the per-step launches only get slower).
     {
@@ -721,9 +721,8 @@ int ensure_stream2(vjf_ctx* c) {
         const unsigned tag = 0x5eed0000u + (unsigned)c->epoch;
         VJF_HIP(hipMemsetAsync(f, 0, 16, c->stream));
         VJF_HIP(hipStreamSynchronize(c->stream));
-        hipLaunchKernelGGL(vjf_probe_wait_kernel, dim3(1), dim3(64), 0, c->stream4, (const unsigned*)(f + 2), tag, f + 3);
+        // (the persistent kernels and their feeders use the caller's stream, stream2 and stream3)
         hipLaunchKernelGGL(vjf_probe_wait_kernel, dim3(1), dim3(64), 0, c->stream3, (const unsigned*)(f + 1), tag, f + 3);
-        hipLaunchKernelGGL(vjf_probe_set_kernel, dim3(1), dim3(64), 0, c->stream3, f + 2, tag);
         hipLaunchKernelGGL(vjf_probe_wait_kernel, dim3(1), dim3(64), 0, c->stream2, (const unsigned*)f, tag, f + 3);
         hipLaunchKernelGGL(vjf_probe_set_kernel, dim3(1), dim3(64), 0, c->stream2, f + 1, tag);
         hipLaunchKernelGGL(vjf_probe_set_kernel, dim3(1), dim3(64), 0, c->stream, f, tag);
@@ -735,7 +734,7 @@ int ensure_stream2(vjf_ctx* c) {
         VJF_HIP(hipMemcpyAsync(&timed_out, f + 3, 4, hipMemcpyDeviceToHost, c->stream));
         VJF_HIP(hipStreamSynchronize(c->stream));
         c->queues_ok = timed_out == 0;
-        if (getenv("VJF_VERBOSE")) fprintf(stderr, "vjf: stream probe: %s\n", c->queues_ok ? "four independent queues" : "streams share a hardware queue");
+        if (getenv("VJF_VERBOSE")) fprintf(stderr, "vjf: stream probe: %s\n", c->queues_ok ? "independent queues" : "streams share a hardware queue");
     }
     return 0;
 }
@@ -900,17 +899,18 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         pa.red = rede[0]; pa.red2 = rede[1]; pa.B_total = Bt; pa.fold_sigma = 1; pa.stamps = a.stamps; pa.undo_P = 1;
         pa.prep_count = prepc; pa.prep_target = c->prep_count + nprep; pa.prep_stride = nprep;
         pa.nsteps = T; pa.step0 = 0;
+        // ONE launch: workgroup 0 the Cholesky loop, 1 the y / W loop, 2.. the inverse loops (three streams in all: a fourth
+        // tends to share a hardware queue with the caller's stream when other libraries hold streams of their own)
         pa.role = 2;
+        const dim3 grid(2 + 2 * nbl);
         switch (vjf_chol_dzp(P.dz)) {
-            case 4: hipLaunchKernelGGL(vjf_rls_pair_kernel<4>, dim3(2), dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
-            case 8: hipLaunchKernelGGL(vjf_rls_pair_kernel<8>, dim3(2), dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
-            case 12: hipLaunchKernelGGL(vjf_rls_pair_kernel<12>, dim3(2), dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
-            default: hipLaunchKernelGGL(vjf_rls_pair_kernel<16>, dim3(2), dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
+            case 4: hipLaunchKernelGGL(vjf_rls_pair_kernel<4>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
+            case 8: hipLaunchKernelGGL(vjf_rls_pair_kernel<8>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
+            case 12: hipLaunchKernelGGL(vjf_rls_pair_kernel<12>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
+            default: hipLaunchKernelGGL(vjf_rls_pair_kernel<16>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
         }
         VJF_HIP(hipGetLastError());
-        pa.role = 1; pa.prep_count = nullptr;                           // (the inverse workgroups do not read g)
-        hipLaunchKernelGGL(vjf_rls_post_kernel, dim3(2 * nbl), dim3(VJF_POST_THREADS), vjf_post_inv_lds_bytes(P), sd, P, pa);
-        VJF_HIP(hipGetLastError());
+        (void)sd;
     }
     const unsigned epoch0 = c->epoch + 1;
     c->epoch += (unsigned)T;
