@@ -161,6 +161,26 @@ def test_filter_sequence_persistent_equals_per_step_launches(vjf, monkeypatch):
     assert torch.equal(outs[0][2], outs[1][2])
 
 
+def test_filter_sequence_in_chunks(vjf, monkeypatch):
+    """Long sequences are enqueued in chunks (one set of persistent kernels per chunk): same bits as one piece."""
+    z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
+    y, eps = torch.tensor(z["y"]), torch.tensor(z["eps"])
+    outs = []
+    for chunk in (None, "3", "2"):
+        if chunk:
+            monkeypatch.setenv("VJF_SEQ_CHUNK", chunk)
+        m = _model_for(vjf, info)
+        load_fixture_state(m, z, "s0")
+        o = m.filter_sequence(y, None, None, eps=eps)
+        assert m.status() == 0
+        outs.append((o, m._blob.clone()))
+    monkeypatch.delenv("VJF_SEQ_CHUNK", raising=False)
+    for k in (1, 2):
+        for a, b in zip(outs[0][0], outs[k][0]):
+            assert torch.equal(a, b)
+        assert torch.equal(outs[0][1], outs[k][1])
+
+
 def test_filter_sequence_two_stream_equals_one_stream(vjf):
     """vjf_filter_seq's two-stream schedule (RLS chain beside the trial / SGD chain) is a re-ordering of independent
     kernels only: every output and the whole state blob match the one-stream order bit for bit."""

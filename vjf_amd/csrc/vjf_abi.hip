@@ -1069,8 +1069,23 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
     if (!c) return fail(-1, "vjf_filter_seq: null context");
     if (T < 1) return fail(-23, "vjf_filter_seq: T=%d", T);
     if (!y || !eps || !mu || !lv) return fail(-1, "vjf_filter_seq: null tensor");
-    if (c->overlap && (!c->stamps || c->stamps_keep_overlap) && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP))
-        return filter_seq_overlap(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
+    if (c->overlap && (!c->stamps || c->stamps_keep_overlap) && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP)) {
+        // Long sequences go in chunks: the persistent RLS kernels of one chunk run for its whole length, and a compute kernel
+        // that stays on the device for a minute is what drivers' lockup timers are for (16384 steps ~ 1.2 s at config B).
+        const char* ce = getenv("VJF_SEQ_CHUNK");                          // (tests)
+        const int32_t chunk = ce && atoi(ce) > 1 ? atoi(ce) : 16384;
+        const size_t sy = (size_t)B * c->plan.dy, su = (size_t)B * c->plan.du, sz = (size_t)B * c->plan.dz;
+        for (int32_t t0 = 0; t0 < T; t0 += chunk) {
+            int32_t n = T - t0 < chunk ? T - t0 : chunk;
+            if (T - t0 - n == 1) n += 1;                                   // (no chunk of a single step)
+            int rc = filter_seq_overlap(c, n, B, y + t0 * sy, u ? u + t0 * su : nullptr, eps + (size_t)t0 * 2 * sz,
+                                        t0 ? mu + (size_t)(t0 - 1) * sz : mu0, t0 ? lv + (size_t)(t0 - 1) * sz : lv0,
+                                        mu + (size_t)t0 * sz, lv + (size_t)t0 * sz, loss ? loss + 4 * (size_t)t0 : nullptr, flags);
+            if (rc) return rc;
+            if (n > chunk) break;
+        }
+        return 0;
+    }
     if (c->world > 1)
         return fail(-24, "vjf_filter_seq: with communicators only the multi-stream schedule exists (update, no warm-up, T > 1, "
                          "fast kernels); use vjf_filter_local / vjf_filter_global around your own all-reduce otherwise");
