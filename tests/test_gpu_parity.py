@@ -341,7 +341,8 @@ def test_rls_failure_is_flagged_and_leaves_rls_state(vjf):
             assert torch.isfinite(model.transition.logvar).all()
 
 
-def test_sharded_path_one_rank_nccl(vjf):
+@pytest.mark.parametrize("persistent", [False, True])
+def test_sharded_path_one_rank_nccl(vjf, monkeypatch, persistent):
     """The multi-GPU protocol (local half -> all-reduce of the reduce buffer over RCCL -> global half) with ONE rank on
     this GPU: a one-rank sum is the identity, so the trajectory must match the plain path (same kernels: bitwise)."""
     import os
@@ -351,6 +352,8 @@ def test_sharded_path_one_rank_nccl(vjf):
     load_fixture_state(m1, z, "s0")
     load_fixture_state(m2, z, "s0")
     y, eps = torch.tensor(z["y"][:4]), torch.tensor(z["eps"][:4])
+    if persistent:                                           # the persistent RLS kernels beside the communicators (opt-in there)
+        monkeypatch.setenv("VJF_PERSISTENT_DIST", "1")
     m1.set_overlap(False)
     o1 = m1.filter_sequence(y, None, None, eps=eps)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

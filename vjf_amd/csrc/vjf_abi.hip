@@ -364,6 +364,9 @@ int vjf_comm_unique_id(void* ids256) {
     return 0;
 }
 
+}  // extern "C"
+namespace { int ensure_stream2(vjf_ctx* c); }
+extern "C" {
 int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world) {
     if (!ctx || !ids256) return fail(-1, "vjf_comm_init: null argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(-20, "vjf_comm_init: rank %d of %d", rank, world);
@@ -377,6 +380,25 @@ int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world)
     int e = nccl().comm_init_rank(&cb, world, ids[1], rank);
     if (e != 0) { (void)nccl().comm_destroy(ca); return fail(-110, "ncclCommInitRank failed: %s", nccl().err ? nccl().err(e) : "rccl error"); }
     ctx->comm_a = ca; ctx->comm_b = cb; ctx->world = world;
+    if (getenv("VJF_PERSISTENT_DIST")) {
+        // The persistent RLS kernels must never meet a collective library that still has something to set up (a lazy connect may
+        // synchronise the device, which kernels that stay resident for a whole sequence turn into a time-out): run the two
+        // all-reduces of a step once now, on the streams and with the sizes the sequence uses (the buffers are scratch).
+        const VjfPlan& P = ctx->plan;
+        int rc = ensure_stream2(ctx);
+        if (rc) return rc;
+        float* redg = (float*)(ctx->ws + ctx->cv.red);
+        float* rede = (float*)(ctx->ws + ctx->cv.red2);
+        VJF_NCCL(nccl().group_start());
+        int e1 = nccl().all_reduce(redg, redg, (size_t)P.train_len, kNcclFloat, kNcclSum, ctx->comm_a, ctx->stream);
+        int e2 = nccl().all_reduce(redg + P.red_SC, redg + P.red_SC, (size_t)RS_N, kNcclFloat, kNcclSum, ctx->comm_a, ctx->stream);
+        VJF_NCCL(nccl().group_end());
+        VJF_NCCL(e1);
+        VJF_NCCL(e2);
+        VJF_NCCL(nccl().all_reduce(rede + P.red_G, rede + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum, ctx->comm_b, ctx->stream2));
+        VJF_HIP(hipStreamSynchronize(ctx->stream));
+        VJF_HIP(hipStreamSynchronize(ctx->stream2));
+    }
     return 0;
 }
 
