@@ -555,7 +555,7 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     g.B = B; g.nsplit = nsplit; g.job0 = job0;
     g.wait_count = wait_count; g.wait_target = wait_target; g.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
-    hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(256), 0, st, P, g);
+    hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(VJF_GRAM_THREADS), 0, st, P, g);
     VJF_HIP(hipGetLastError());
     if (no_reduce) return 0;                                   // (the consumer sums the slabs itself)
     VjfReduceArgs r{};
@@ -1359,7 +1359,7 @@ int vjf_blr_rls(const float* x, const float* target, const float* v, float shrin
     VjfGramArgs g{};
     g.jobs = (const VjfJob*)(ws + c.jobs); g.E = E; g.ACT = E; g.DEL = E; g.slabs = (float*)(ws + c.slabs);
     g.B = B; g.nsplit = c.nsplit; g.rows_per_split = ((B + c.nsplit - 1) / c.nsplit + 7) / 8 * 8;
-    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c.njobs * c.nsplit), dim3(256), 0, s, P, g);
+    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c.njobs * c.nsplit), dim3(VJF_GRAM_THREADS), 0, s, P, g);
     VJF_HIP(hipGetLastError());
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(ws + c.partial); r.red = (float*)(ws + c.red);
@@ -1405,7 +1405,7 @@ int vjf_blr_kalman(const float* x, const float* target, const float* v, float di
     VjfGramArgs g{};
     g.jobs = (const VjfJob*)(ws + c.jobs); g.E = E; g.ACT = E; g.DEL = E; g.slabs = (float*)(ws + c.slabs);
     g.B = B; g.nsplit = c.nsplit; g.rows_per_split = ((B + c.nsplit - 1) / c.nsplit + 7) / 8 * 8;
-    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c.njobs * c.nsplit), dim3(256), 0, s, P, g);
+    hipLaunchKernelGGL(vjf_gram_kernel, dim3(c.njobs * c.nsplit), dim3(VJF_GRAM_THREADS), 0, s, P, g);
     VJF_HIP(hipGetLastError());
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(ws + c.partial); r.red = (float*)(ws + c.red);

@@ -575,8 +575,8 @@ __device__ __forceinline__ void inv_chain(const float* Lk, const float* piv, flo
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        const int rj = (j & 3) + 4 * (j >> 3), hj = (j >> 2) & 1;
-        const float x = racc[rj] * sv[j];                               // x[c] = Linv[j][c] on half hj (la is 0 on the other)
+        const int rj = (j & 3) + 4 * (j >> 3);
+        const float x = racc[rj] * sv[j];                               // x[c] = Linv[j][c] on half (j >> 2) & 1 (la is 0 on the other)
         xrow[j] = x;
         racc = __builtin_amdgcn_mfma_f32_32x32x2f32(la[j], x, racc, 0, 0, 0);
     }
@@ -602,8 +602,8 @@ __device__ __forceinline__ void trsm_chain(float* pb, const float* Lk, const flo
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        const int rj = (j & 3) + 4 * (j >> 3), hj = (j >> 2) & 1;
-        const float b = acc[rj] * sv[j];                                // b[c] = L_ik[c][j] on half hj (la is 0 on the other)
+        const int rj = (j & 3) + 4 * (j >> 3);
+        const float b = acc[rj] * sv[j];                                // b[c] = L_ik[c][j] on half (j >> 2) & 1 (la is 0 on the other)
         lrow[j] = b;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(la[j], b, acc, 0, 0, 0);   // A_ik^T[i][:] -= L_kk[i][j] L_ik[:][j], i > j
     }
@@ -702,9 +702,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
     float* s_blk = lds;                               // ntri blocks: lower block triangle of P -> L -> L^-1
     float* s_aux = s_blk + (size_t)ntri * 1024;       // nbl blocks: inverted diagonal blocks of L; later scratch
     float* s_g = s_aux + (size_t)nbl * 1024;          // npad x DZP  g, later W
-    // npad x DZP  y = L^-1 g: for DZP <= 16 in the upper part of s_aux once the inverted diagonal blocks have been copied out
-    // (2 * npad * DZP <= nbl * 1024); for DZP = 32 that does not hold and y follows g
-    float* s_y = DZP <= 16 ? s_aux + (size_t)npad * DZP : s_g + (size_t)npad * DZP;
+    // (y = L^-1 g overwrites g in place; for DZP = 32 a second npad x DZP region behind g is reserved)
     int* s_flag = (int*)(s_g + (size_t)npad * DZP * (DZP <= 16 ? 1 : 2));   // [0] ok
     double* s_d = (double*)(s_flag + 8);              // 16 doubles for the final reduction
     int* s_bi = s_flag + 64;                          // block-row / block-column of lower block b

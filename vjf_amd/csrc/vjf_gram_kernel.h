@@ -26,8 +26,11 @@ struct VjfGramArgs {
     float* status;
 };
 
-__global__ __launch_bounds__(256) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A) {
-    __shared__ float s_acc[3 * 1024];
+#define VJF_GRAM_WAVES 4            // wavefronts per workgroup (8 was tried: 1.4 us/step slower at config B)
+#define VJF_GRAM_THREADS (64 * VJF_GRAM_WAVES)
+__global__ __launch_bounds__(VJF_GRAM_THREADS) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A) {
+    constexpr int GW = VJF_GRAM_WAVES;
+    __shared__ float s_acc[(GW - 1) * 1024];
     // linear id = job * nsplit + split: workgroups are dealt round-robin over the 8 XCDs, so with nsplit a
     // multiple of 8 every job of one trial range lands on the same XCD and re-reads its rows from that L2
     if (A.wait_count) {
@@ -58,13 +61,13 @@ __global__ __launch_bounds__(256) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A)
     vjf_f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // wave w takes trials k_begin + 8*j + 2*w + {0,1}; 8 steps' operands (16 loads) are in flight before the first MFMA
+    // wave w takes trials k_begin + 2*GW*j + 2*w + {0,1}; 8 steps' operands (16 loads) are in flight before the first MFMA
     int k = k_begin + 2 * wave + kh;
-    for (; k + 56 < k_end + kh; k += 64) {
+    for (; k + 14 * GW < k_end + kh; k += 16 * GW) {
         float a[8], b[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int kq = k + 8 * q;
+            const int kq = k + 2 * GW * q;
             const bool kok = kq < k_end;
             a[q] = (kok && xok) ? xp[(size_t)kq * ldx] : 0.f;
             b[q] = (kok && yok) ? yp[(size_t)kq * ldy] : 0.f;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A)
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
     }
-    for (; k < k_end + kh; k += 8) {
+    for (; k < k_end + kh; k += 2 * GW) {
         const bool kok = k < k_end;
         const float a = (kok && xok) ? xp[(size_t)k * ldx] : 0.f;
         const float b = (kok && yok) ? yp[(size_t)k * ldy] : 0.f;
@@ -88,7 +91,9 @@ __global__ __launch_bounds__(256) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A)
         float* slab = A.slabs + ((size_t)jobid * A.nsplit + split) * 1024;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float v = ((acc[i] + s_acc[i * 64 + lane]) + s_acc[1024 + i * 64 + lane]) + s_acc[2048 + i * 64 + lane];
+            float v = acc[i];
+#pragma unroll
+            for (int w = 0; w < GW - 1; ++w) v += s_acc[w * 1024 + i * 64 + lane];   // wave order
             const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
             slab[row * 32 + r] = v;
         }
