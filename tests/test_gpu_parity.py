@@ -272,6 +272,37 @@ def test_filter_vs_oracle(vjf, case):
     assert model.status() == 0
 
 
+@pytest.mark.parametrize("case", CASES[:4], ids=lambda c: f"B{c['B']}_dz{c['dz']}_dy{c['dy']}_{c['lik']}")
+def test_filter_sequence_vs_oracle(vjf, case):
+    """The sequence entry point (persistent RLS kernels, three streams) on ragged batches, a control input, three layers, one
+    trial: every step's posterior and loss, and the final state, against the oracle stepped on the same inputs."""
+    torch.manual_seed(6)
+    c = dict(case)
+    c.pop("T")
+    T = 5
+    model = vjf.VJF.make_model(c["dy"], c["dz"], c["du"], c["n"], c["hidden"], likelihood=c["lik"], lr=1e-3)
+    s = load_oracle_state(model, np.float64)
+    g = torch.Generator().manual_seed(10)
+    B, dz = c["B"], c["dz"]
+    if c["lik"] == "poisson":
+        y = torch.poisson(torch.exp(0.5 * torch.randn(T, B, c["dy"], generator=g) - 0.5), generator=g)
+    else:
+        y = torch.randn(T, B, c["dy"], generator=g)
+    u = torch.randn(T, B, c["du"], generator=g) if c["du"] else None
+    eps = torch.randn(T, 2, B, dz, generator=g)
+    mu_s, lv_s, loss = model.filter_sequence(y, u, None, eps=eps)
+    mu, lv = None, None
+    for t in range(T):
+        o = orc.filter_step(s, y[t].numpy(), None if u is None else u[t].numpy(), mu, lv, eps[t, 0].numpy(), eps[t, 1].numpy())
+        mu, lv = o.mu_t, o.lv_t
+        close(mu_s[t], o.mu_t, rtol=5e-5, atol=5e-5)
+        close(lv_s[t], o.lv_t, rtol=5e-5, atol=5e-5)
+        close(loss[t], [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
+    close(model.transition.logvar, s.tr_logvar, rtol=0, atol=5e-5)
+    state_close(model, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3)
+    assert model.status() == 0
+
+
 def test_flags_sgd_update_off(vjf):
     """sgd=False leaves the optimised tensors untouched; update=False leaves RLS state / variances untouched."""
     torch.manual_seed(2)
