@@ -163,7 +163,6 @@ struct VjfSgdArgs {
     unsigned flags;
 };
 __global__ __launch_bounds__(1024) void vjf_sgd_kernel(VjfPlan P, VjfSgdArgs A) {
-    __shared__ double s_part[256];
     __shared__ float s_sc[RS_N];
     const int tid = threadIdx.x;
     float* S = A.state;
@@ -208,14 +207,8 @@ __global__ __launch_bounds__(1024) void vjf_sgd_kernel(VjfPlan P, VjfSgdArgs A) 
             for (int q = 0; q < 8; ++q) v += (double)t[q];
         }
         for (; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
-        s_part[tid] = v;
-    }
-    __syncthreads();
-    if (tid < 256 && (tid & 31) == 0) {
-        const int sc = tid >> 5;
-        double t = 0.0;
-        for (int i = 0; i < 32; ++i) t += s_part[sc * 32 + i];
-        s_sc[sc] = (float)t;
+        v = vjf_sum32(v);
+        if (l == 0) s_sc[sc] = (float)v;
     }
     __syncthreads();
     const bool do_sgd = A.flags & VJF_FLAG_SGD, do_upd = A.flags & VJF_FLAG_UPDATE, warm = A.flags & VJF_FLAG_WARM_UP;

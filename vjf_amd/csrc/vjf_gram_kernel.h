@@ -118,8 +118,7 @@ struct VjfReduceArgs {
 __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(VjfPlan P, VjfReduceArgs A) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x == A.njobs) {
-        __shared__ double s_part[256];
-        // RS_N scalars; 32 threads per scalar accumulate strided partials in double, fixed order
+        // RS_N scalars; 32 threads per scalar accumulate strided partials in double, then a fixed xor tree over the 32
         const int sc = (tid >> 5) & 7, l = tid & 31;
         double v = 0.0;
         if (tid < 256) {
@@ -132,13 +131,8 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
                 for (int q = 0; q < 8; ++q) v += (double)t[q];
             }
             for (; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
-            s_part[tid] = v;
-        }
-        __syncthreads();
-        if (tid < 256 && l == 0 && ((A.sc_mask >> sc) & 1u)) {
-            double t = 0.0;
-            for (int i = 0; i < 32; ++i) t += s_part[sc * 32 + i];
-            A.red[P.red_SC + sc] = (float)t;
+            v = vjf_sum32(v);
+            if (l == 0 && ((A.sc_mask >> sc) & 1u)) A.red[P.red_SC + sc] = (float)v;
         }
         if (A.done_count) vjf_wg_signal(A.done_count, tid);
         return;

@@ -197,6 +197,15 @@ __device__ __forceinline__ bool vjf_wg_wait(const unsigned* count, unsigned targ
 }
 #endif
 
+#ifdef __HIPCC__
+// sum over the 32 lanes of a half wavefront, fixed xor tree (the loss sums: every kernel that forms them uses this order)
+__device__ __forceinline__ double vjf_sum32(double v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#endif
+
 // OR status bits into the status scalar (a float holding a small integer).  Kernels of one step may run on two
 // streams (vjf_filter_seq), so the read-modify-write is a compare-and-swap loop.
 __device__ __forceinline__ void vjf_status_or(float* p, unsigned bits) {
