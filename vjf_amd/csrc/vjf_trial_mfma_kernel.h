@@ -83,10 +83,15 @@ struct VjfTrialMfmaArgs {
                            //   (release at agent scope): the statistics Gram on another stream starts behind vjf_gate_kernel on it
     const unsigned* rls_done;  // backward half: workgroups of the previous step's post kernel that have their W, w_chol, sigma in
     unsigned rls_target;       //   memory; non-null -> the workgroup waits (bounded) for the count before stage 2, its reloads done
+    unsigned* phi_done;    // part 3: += 1 per workgroup once the Phi columns of its E rows are in memory (the Gram of Phi^T Phi starts
+                           //   behind it, before the recognition network has run)
     int part;              // 0: whole step; 1: forward half (features, recognition, E / ACT rows, posterior);
                            // 2: backward half (predictive mean / variance, losses, backward, DEL rows) -- reloads the
                            //    forward half's rows, so that it can run after the RLS update of the previous step while
                            //    the forward half of this step ran beside it (vjf_filter_seq, two streams)
+                           // 3: whole step in the order  features -> [Phi rows out, phi_done] -> recognition -> [dx / ACT rows and
+                           //    posterior out, fwd_done] -> [wait: RLS update of the previous step] -> predictive mean / variance,
+                           //    decoder, losses, backward: one launch per step, the statistics leave as early as they exist
 };
 
 #define VJF_K1_STAMP(i)                                                                     \
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     const bool prior = (A.mu_s == nullptr);
     const bool warm = (A.flags & VJF_FLAG_WARM_UP) != 0;
     const bool tri = S[P.off[VJF_SLOT_SCALARS] + VJF_SC_TRI_CLEAN] != 0.f;   // w_chol known upper triangular
-    const bool fwd = AA.part != 2, bwd = AA.part != 1;
+    const bool fwd = AA.part != 2, bwd = AA.part != 1, fused3 = AA.part == 3;
     constexpr int LD = VJF_LDT;
     constexpr int NW = VJF_K1M_WAVES;
 
@@ -210,58 +215,21 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     __syncthreads();
 
-    if (AA.rls_done && bwd) {
-        // W, w_chol, sigma come from the post kernel of the previous step on another stream: the host only lets this kernel
-        // start once that kernel's workgroups are resident (vjf_prep_kernel's last workgroup checks), so the wait cannot starve it
-        if (tid == 0) {
-            bool there = false;
-            for (unsigned spins = 0; spins < (1u << 19); ++spins) {
-                if ((int)(__hip_atomic_load(AA.rls_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - AA.rls_target) >= 0) { there = true; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (!there) vjf_status_or(const_cast<float*>(A.state) + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    auto signal_rows = [&](unsigned* count) {                  // producer side of a hand-off to a kernel on another stream
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-    }
-    VJF_K1_STAMP(24);
-    // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
-    if (bwd) {
-        const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
-        const int ntile = (n + 15) >> 4;
-        float v2 = 0.f;
-        // tiles in descending cost, dealt to the 4 wavefronts in a snake so that the triangular work balances
-        for (int r = 0;; ++r) {
-            const int idx = (r & 1) ? r * NW + NW - 1 - wave : r * NW + wave;
-            if (idx >= ntile) { if (r * NW >= ntile) break; else continue; }
-            const int t = ntile - 1 - idx, j0 = t * 16;
-            const int K = tri ? min(n, j0 + 16) : n;
-            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            mma_tile(acc, Wc, n, n, j0, s_phi, K, lane);
-            v2 = fmaf(acc[0], acc[0], fmaf(acc[1], acc[1], fmaf(acc[2], acc[2], fmaf(acc[3], acc[3], v2))));
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        v2 += __shfl_xor(v2, 16, 64);
-        v2 += __shfl_xor(v2, 32, 64);
-        if (lane < 16) s_red[wave * 16 + lane] = v2;
-        // mean tiles, dealt from the last wavefront backwards (it has the lightest variance share)
-        const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
-        const int mt = (dz + 15) >> 4;
-        for (int t = NW - 1 - wave; t < mt; t += NW) {
-            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            mma_tile(acc, Wm, dz, dz, t * 16, s_phi, n, lane);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = t * 16 + 4 * (lane >> 4) + r, b = lane & 15;
-                if (j < dz) s_pm[j * LD + b] = s_xu[j * LD + b] + acc[r];
-            }
+    };
+    if (fused3) {
+        for (int b = wave; b < nb; b += NW) {
+            float* erow = A.E + (size_t)(b0 + b) * P.ldE;
+            for (int c = lane; c < n; c += 64) erow[c] = s_phi[c * LD + b];
         }
-    }
-    __syncthreads();
-    if (bwd && tid < 16) {
-        float v = 0.f;
-        for (int w = 0; w < NW; ++w) v += s_red[w * 16 + tid];
-        s_plv[tid] = logf(v);
+        if (AA.phi_done) signal_rows(AA.phi_done);
     }
 
     VJF_K1_STAMP(25);
@@ -343,7 +311,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
 
     VJF_K1_STAMP(27);
-    if (!bwd) {
+    if (!bwd || fused3) {
         // forward half: of the loss scalars only sum |dx|^2 (the RLS chain's residual identity needs it), summed
         // exactly as stage 5 does; then the E and ACT rows
         constexpr int LPT = VJF_K1M_THREADS / 16;
@@ -362,6 +330,80 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
         }
     }
+    if (fused3) {
+        // the rest of the forward half's rows (dx and zero padding of E, all of ACT; the posterior went out in stage 4), the
+        // signal for the kernels that take them, and only then what needs the previous step's RLS update
+        for (int b = wave; b < nb; b += NW) {
+            float* erow = A.E + (size_t)(b0 + b) * P.ldE;
+            for (int c = n + lane; c < P.ldE; c += 64) erow[c] = c < n + dz ? s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b] : 0.f;
+            float* arow = A.ACT + (size_t)(b0 + b) * P.ldA;
+            for (int c = lane; c <= din; c += 64) arow[c] = c < din ? s_in[c * LD + b] : 1.f;
+            int aoff = 0;
+            for (int l = 0; l < P.L; ++l) {
+                const int hl = P.h[l], c0 = P.colA_act[l + 1];
+                for (int k = lane; k <= hl; k += 64) arow[c0 + k] = k < hl ? s_act[(aoff + k) * LD + b] : 1.f;
+                aoff += hl;
+            }
+            for (int j = lane; P.colA_xt + j < P.ldA; j += 64) arow[P.colA_xt + j] = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f);
+        }
+        if (AA.fwd_done) signal_rows(AA.fwd_done);
+    }
+    // (every part: as late as it can be -- recognition or its reload, xt and the decoder above do not need the RLS update)
+    if (AA.rls_done && bwd) {
+        // W, w_chol, sigma come from the post kernel of the previous step on another stream: the host only lets this kernel
+        // start once that kernel's workgroups are resident (vjf_prep_kernel's last workgroup checks), so the wait cannot starve it
+        if (tid == 0) {
+            bool there = false;
+            for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+                if ((int)(__hip_atomic_load(AA.rls_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - AA.rls_target) >= 0) { there = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!there) vjf_status_or(const_cast<float*>(A.state) + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        }
+    VJF_K1_STAMP(24);
+    // ---- stage 2 (runs in front of stage 5): predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and
+    //      pt.mean = xs + Phi W (module.py:77)
+    if (bwd) {
+        const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
+        const int ntile = (n + 15) >> 4;
+        float v2 = 0.f;
+        // tiles in descending cost, dealt to the 4 wavefronts in a snake so that the triangular work balances
+        for (int r = 0;; ++r) {
+            const int idx = (r & 1) ? r * NW + NW - 1 - wave : r * NW + wave;
+            if (idx >= ntile) { if (r * NW >= ntile) break; else continue; }
+            const int t = ntile - 1 - idx, j0 = t * 16;
+            const int K = tri ? min(n, j0 + 16) : n;
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile(acc, Wc, n, n, j0, s_phi, K, lane);
+            v2 = fmaf(acc[0], acc[0], fmaf(acc[1], acc[1], fmaf(acc[2], acc[2], fmaf(acc[3], acc[3], v2))));
+        }
+        v2 += __shfl_xor(v2, 16, 64);
+        v2 += __shfl_xor(v2, 32, 64);
+        if (lane < 16) s_red[wave * 16 + lane] = v2;
+        // mean tiles, dealt from the last wavefront backwards (it has the lightest variance share)
+        const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
+        const int mt = (dz + 15) >> 4;
+        for (int t = NW - 1 - wave; t < mt; t += NW) {
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile(acc, Wm, dz, dz, t * 16, s_phi, n, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = t * 16 + 4 * (lane >> 4) + r, b = lane & 15;
+                if (j < dz) s_pm[j * LD + b] = s_xu[j * LD + b] + acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    if (bwd && tid < 16) {
+        float v = 0.f;
+        for (int w = 0; w < NW; ++w) v += s_red[w * 16 + tid];
+        s_plv[tid] = logf(v);
+    }
+    __syncthreads();
     // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
     if (bwd) {
         constexpr int LPT = VJF_K1M_THREADS / 16;          // lanes per trial
@@ -421,7 +463,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         }
     }
     __syncthreads();
-    if (bwd && tid < RS_N && (fwd || tid != RS_SDX2)) {           // (the forward half owns sum |dx|^2)
+    if (bwd && tid < RS_N && ((fwd && !fused3) || tid != RS_SDX2)) {   // (the forward half / part owns sum |dx|^2)
         float v = 0.f;
         if (tid <= RS_SDX2) for (int b = 0; b < 16; ++b) v += s_sc[b * RS_N + tid];
         A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
@@ -495,7 +537,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     // ---- stage 7: rows of E = [Phi | dx | 0], ACT = [in|1|h_1|1|..|h_L|1|xt|1|0], DEL = [.. | dmu | dlv | dpy].
     //      wavefront w writes the rows of trials w, w+4, ...; the lane walks the columns (coalesced, no divisions)
     for (int b = wave; b < nb; b += NW) {
-        if (fwd) {
+        if (fwd && !fused3) {
             float* erow = A.E + (size_t)(b0 + b) * P.ldE;
             for (int c = lane; c < P.ldE; c += 64) {
                 float v = 0.f;
