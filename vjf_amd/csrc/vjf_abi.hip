@@ -214,6 +214,9 @@ struct vjf_ctx {
                            // but then the post kernel cannot be placed before the trial kernel has drained: measured slower)
     bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
                            // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
+    int fdx_job0;          // first E^T E job whose tile row holds dx columns (they are the tail of the E jobs)
+    unsigned phi_count;    // host mirror of the trial kernel's "Phi rows written" count (part 3)
+    bool fused_seq;        // vjf_filter_seq with one trial-kernel launch per step (VJF_FUSED_SEQ)
     unsigned epoch_k1;     // diagnostic: epoch of the step whose backward half is launched next (ring entry of its stamps)
     bool queues_ok;        // the four streams of vjf_filter_seq run beside each other (probed when they are created)
     bool persistent;       // vjf_filter_seq: the RLS chain as persistent kernels (default; VJF_NO_PERSISTENT turns it off)
@@ -304,6 +307,9 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->mfma_trial = c->lds_k1m <= kMaxLds - 1024;
     c->n_ejobs = 0;
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
+    c->fdx_job0 = c->n_ejobs;
+    for (int i = 0; i < c->n_ejobs; ++i) if ((jobs[i].ti + 1) * VJF_TILE > P.n) { c->fdx_job0 = i; break; }
+    c->phi_count = 0; c->fused_seq = getenv("VJF_FUSED_SEQ") != nullptr;
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
     c->overlap_serial = false; c->gate_post = getenv("VJF_GATE_POST") != nullptr; c->sb_gates = getenv("VJF_SB_INKERNEL_WAIT") == nullptr; c->prepg_inkernel = getenv("VJF_PREPG_INKERNEL") != nullptr;
     c->k1_inkernel = getenv("VJF_K1_GATE") == nullptr;
@@ -492,7 +498,8 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
         m.rls_done = rls_done; m.rls_target = rls_target;
         m.done = (unsigned*)(c->ws + c->cv.flags) + 16;
         if (part != 1) c->k1_count += (unsigned)nblk;
-        if (part == 1 && count_fwd) { m.fwd_done = (unsigned*)(c->ws + c->cv.flags) + 48; c->fwd_count += (unsigned)nblk; }
+        if ((part == 1 || part == 3) && count_fwd) { m.fwd_done = (unsigned*)(c->ws + c->cv.flags) + 48; c->fwd_count += (unsigned)nblk; }
+        if (part == 3) { m.phi_done = (unsigned*)(c->ws + c->cv.flags) + 53; c->phi_count += (unsigned)nblk; }
         m.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
         if (m.stamps && c->stamps_keep_overlap) m.stamps += part == 1 ? 8 * 32 : (rls_done ? (c->epoch_k1 & 7u) * 32 : 0);   // ring entry (diagnostic)
         VJF_LAUNCH(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, stop, P, m);
@@ -545,7 +552,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
 // Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
 int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, hipEvent_t stop = nullptr,
                 int gen = 0, const unsigned* wait_count = nullptr, unsigned wait_target = 0, bool no_reduce = false,
-                unsigned* done_count = nullptr) {
+                unsigned* done_count = nullptr, unsigned kind0_mask = 0) {
     const VjfPlan& P = c->plan;
     const int nsplit = split_for(B);
     VjfGramArgs g{};
@@ -555,13 +562,14 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     g.B = B; g.nsplit = nsplit; g.job0 = job0;
     g.wait_count = wait_count; g.wait_target = wait_target; g.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
+    g.high_prio = (kind0_mask != 0 && getenv("VJF_GRAM_PRIO")) ? 1 : 0;
     hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(VJF_GRAM_THREADS), 0, st, P, g);
     VJF_HIP(hipGetLastError());
     if (no_reduce) return 0;                                   // (the consumer sums the slabs itself)
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial)); r.red = red;
     r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask;
-    r.done_count = done_count;
+    r.done_count = done_count; r.kind0_mask = kind0_mask;
     VJF_LAUNCH(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(VJF_REDUCE_THREADS), 0, st, stop, P, r);
     VJF_HIP(hipGetLastError());
     return 0;
@@ -902,7 +910,13 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     unsigned* fdone = fl + 48; unsigned* runw = fl + VJF_CHOL_MAXBLK + 2;
     float* stw = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     const int nbl = (P.n + 31) / 32;
-    const unsigned npost = (unsigned)(2 * nbl + 1), nblk = (unsigned)trial_blocks(c, B), nred = (unsigned)(ne + 1), nprep = (unsigned)((P.n + 15) / 16);
+    // fused: ONE trial-kernel launch per step (part 3): it signals "Phi rows written" before the recognition network runs and "all
+    // rows written" before it waits for the RLS update; Phi^T Phi is reduced behind the first signal (what the Cholesky loop
+    // waits for), Phi^T dx and sum |dx|^2 behind the second (what the operand kernel needs)
+    const bool fused = c->fused_seq && !c->comm_a;
+    unsigned* phic = fl + 53;
+    const unsigned npost = (unsigned)(2 * nbl + 1), nblk = (unsigned)trial_blocks(c, B), nred = (unsigned)(fused ? ne : ne + 1),
+                   nprep = (unsigned)((P.n + 15) / 16);
     {   // ---- the persistent kernels of this sequence
         VjfCholArgs a{};
         a.state = c->state; a.red = rede[0]; a.red2 = rede[1]; a.gbuf = (const float*)(c->ws + c->cv.work); a.B_total = Bt; a.flags = flags;
@@ -937,12 +951,23 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     const unsigned epoch0 = c->epoch + 1;
     c->epoch += (unsigned)T;
     c->start_count += npost;
-    if ((rc = launch_trial(c, args(0), 1, sa, nullptr, true))) return rc;   // prologue: forward half of step 0
+    if (!fused && (rc = launch_trial(c, args(0), 1, sa, nullptr, true))) return rc;   // prologue: forward half of step 0
     for (int t = 0; t < T; ++t) {
         const unsigned post_before = c->post_count;                      // workgroups of post(0 .. t-1)
+        if (fused) {
+            // sa: the whole trial kernel of step t (its backward part waits in-kernel for post(t-1))
+            c->epoch_k1 = epoch0 + (unsigned)t;
+            if ((rc = launch_trial(c, args(t), 3, sa, nullptr, true, t > 0 ? pdone : nullptr, post_before))) return rc;
+            // sb: Phi^T Phi behind "Phi rows written", then Phi^T dx and sum |dx|^2 behind "all rows written"
+            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)phic, c->phi_count, stw);
+            if ((rc = launch_gram(c, B, 0, ne, 0u, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, statc, 1u))) return rc;
+            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
+            if ((rc = launch_gram(c, B, c->fdx_job0, ne - c->fdx_job0, kScRls, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, nullptr, 2u))) return rc;
+        } else {
         // sb: statistics of step t as soon as its forward half is done ...
         hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
         if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, c->comm_b ? nullptr : statc))) return rc;
+        }
         if (c->comm_b) {                                                 // trials are sharded over ranks: sum [G | FDX | sums]
             VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum,
                                        c->comm_b, sb));
@@ -956,7 +981,7 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         c->prep_count += nprep;
         // sa: backward half(t); it waits in-kernel for post(t-1), whose workgroups are resident
         c->epoch_k1 = epoch0 + (unsigned)t;
-        if ((rc = launch_trial(c, args(t), 2, sa, nullptr, false, t > 0 ? pdone : nullptr, post_before))) return rc;
+        if (!fused && (rc = launch_trial(c, args(t), 2, sa, nullptr, false, t > 0 ? pdone : nullptr, post_before))) return rc;
         c->post_count += npost;
         if (t == 0) {
             hipLaunchKernelGGL(vjf_triclean_kernel, dim3(64), dim3(256), 0, sa, P, c->state);
@@ -983,7 +1008,7 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
                              t == 0 ? runw : nullptr, epoch0, started, c->start_count);
         }
         if (rc) return rc;
-        if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
+        if (!fused && t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
     }
     VJF_HIP(hipEventRecord(c->ev_c, sb));
     VJF_HIP(hipEventRecord(c->ev_s, sc));

@@ -21,6 +21,7 @@ struct VjfGramArgs {
     float* slabs;            // (njobs, nsplit, 1024)
     int B, nsplit, rows_per_split;
     int job0;                // first job of this launch (the grid covers a contiguous job range)
+    int high_prio;           // raise the wavefronts' issue priority (the statistics Gram that runs beside the trial kernel)
     const unsigned* wait_count;   // non-null: the rows come from a kernel on another stream; every workgroup first waits
     unsigned wait_target;         //   (bounded) until *wait_count has reached wait_target, then acquires at agent scope
     float* status;
@@ -31,6 +32,7 @@ struct VjfGramArgs {
 __global__ __launch_bounds__(VJF_GRAM_THREADS) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A) {
     constexpr int GW = VJF_GRAM_WAVES;
     __shared__ float s_acc[(GW - 1) * 1024];
+    if (A.high_prio) __builtin_amdgcn_s_setprio(3);     // beside the trial kernel's older wavefronts: do not starve
     // linear id = job * nsplit + split: workgroups are dealt round-robin over the 8 XCDs, so with nsplit a
     // multiple of 8 every job of one trial range lands on the same XCD and re-reads its rows from that L2
     if (A.wait_count) {
@@ -108,6 +110,9 @@ struct VjfReduceArgs {
     int njobs, nsplit, nblocks_k1;
     int job0;                 // first job of this launch; njobs = jobs in this launch
     unsigned sc_mask;         // which of K1's loss sums the extra workgroup reduces (bit per RS_* index)
+    unsigned kind0_mask;      // E^T E tiles: bit 0 -> write the Phi^T Phi entries, bit 1 -> the Phi^T dx entries (0 = both).  The one-launch-
+                              //   per-step sequence reduces Phi^T Phi early (all tiles, from rows whose dx columns are not there yet)
+                              //   and Phi^T dx late (the tile rows that hold dx, again)
     unsigned* done_count;     // non-null: += 1 per workgroup once its sums are in memory (consumers that are already running wait
                               //   for njobs + 1 of them: the persistent RLS kernels of vjf_filter_seq)
 };
@@ -161,12 +166,13 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
         if (i >= job.xn || j >= job.yn) continue;
         if (job.kind == 0) {
             const int gr = job.ti * VJF_TILE + i, gc = job.tj * VJF_TILE + j;   // gr: X column, gc: Y column of E
+            const unsigned km = A.kind0_mask ? A.kind0_mask : 3u;
             if (gr < P.n) {
-                if (gc < P.n && gc <= gr) {
+                if ((km & 1u) && gc < P.n && gc <= gr) {
                     A.red[P.red_G + (size_t)gr * P.n + gc] = v;
                     A.red[P.red_G + (size_t)gc * P.n + gr] = v;
                 }
-            } else if (gr < P.n + P.dz && gc < P.n) {
+            } else if ((km & 2u) && gr < P.n + P.dz && gc < P.n) {
                 A.red[P.red_FDX + (size_t)gc * P.dz + (gr - P.n)] = v;
             }
         } else {
