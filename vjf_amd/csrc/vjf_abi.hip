@@ -214,6 +214,8 @@ struct vjf_ctx {
                            // but then the post kernel cannot be placed before the trial kernel has drained: measured slower)
     bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
                            // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
+    float* k1_next_E; const float* k1_next_eps; const float* k1_next_u; int k1_own_phi;   // part 3: see VjfTrialMfmaArgs::next_E
+    bool ahead_ok;         // the plan allows the statistics-one-step-ahead variant (centroids staged in LDS, xs' fits its scratch rows)
     int fdx_job0;          // first E^T E job whose tile row holds dx columns (they are the tail of the E jobs)
     unsigned phi_count;    // host mirror of the trial kernel's "Phi rows written" count (part 3)
     bool fused_seq;        // vjf_filter_seq with one trial-kernel launch per step (VJF_FUSED_SEQ)
@@ -310,6 +312,11 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->fdx_job0 = c->n_ejobs;
     for (int i = 0; i < c->n_ejobs; ++i) if ((jobs[i].ti + 1) * VJF_TILE > P.n) { c->fdx_job0 = i; break; }
     c->phi_count = 0; c->fused_seq = getenv("VJF_FUSED_SEQ") != nullptr;
+    c->k1_next_E = nullptr; c->k1_next_eps = nullptr; c->k1_next_u = nullptr; c->k1_own_phi = 1;
+    {
+        const bool compact = P.dy >= P.hmax;
+        c->ahead_ok = (P.n * P.dxu + P.n) <= 2 * (compact ? P.dy : P.hmax) * VJF_LDT && P.dxu <= 3 * P.dz && getenv("VJF_NO_AHEAD") == nullptr;
+    }
     c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
     c->overlap_serial = false; c->gate_post = getenv("VJF_GATE_POST") != nullptr; c->sb_gates = getenv("VJF_SB_INKERNEL_WAIT") == nullptr; c->prepg_inkernel = getenv("VJF_PREPG_INKERNEL") != nullptr;
     c->k1_inkernel = getenv("VJF_K1_GATE") == nullptr;
@@ -499,7 +506,11 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
         m.done = (unsigned*)(c->ws + c->cv.flags) + 16;
         if (part != 1) c->k1_count += (unsigned)nblk;
         if ((part == 1 || part == 3) && count_fwd) { m.fwd_done = (unsigned*)(c->ws + c->cv.flags) + 48; c->fwd_count += (unsigned)nblk; }
-        if (part == 3) { m.phi_done = (unsigned*)(c->ws + c->cv.flags) + 53; c->phi_count += (unsigned)nblk; }
+        if (part == 3) {
+            m.phi_done = (unsigned*)(c->ws + c->cv.flags) + 53;
+            m.own_phi = c->k1_own_phi; m.next_E = c->k1_next_E; m.next_eps_s = c->k1_next_eps; m.next_u = c->k1_next_u;
+            c->phi_count += (unsigned)nblk * (unsigned)((m.own_phi ? 1 : 0) + (m.next_E ? 1 : 0));
+        }
         m.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
         if (m.stamps && c->stamps_keep_overlap) m.stamps += part == 1 ? 8 * 32 : (rls_done ? (c->epoch_k1 & 7u) * 32 : 0);   // ring entry (diagnostic)
         VJF_LAUNCH(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, stop, P, m);
@@ -955,12 +966,25 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     for (int t = 0; t < T; ++t) {
         const unsigned post_before = c->post_count;                      // workgroups of post(0 .. t-1)
         if (fused) {
-            // sa: the whole trial kernel of step t (its backward part waits in-kernel for post(t-1))
+            // sa: the whole trial kernel of step t (its backward part waits in-kernel for post(t-1)).  ahead: it also writes the
+            // Phi columns of step t+1, which depend only on this step's posterior
+            const bool ahead = c->ahead_ok;
+            const unsigned phi_before = c->phi_count;
             c->epoch_k1 = epoch0 + (unsigned)t;
-            if ((rc = launch_trial(c, args(t), 3, sa, nullptr, true, t > 0 ? pdone : nullptr, post_before))) return rc;
-            // sb: Phi^T Phi behind "Phi rows written", then Phi^T dx and sum |dx|^2 behind "all rows written"
-            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)phic, c->phi_count, stw);
-            if ((rc = launch_gram(c, B, 0, ne, 0u, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, statc, 1u))) return rc;
+            c->k1_own_phi = (!ahead || t == 0) ? 1 : 0;
+            if (ahead && t + 1 < T) {
+                c->k1_next_E = (float*)(c->ws + (((t + 1) & 1) ? c->cv.E2 : c->cv.E));
+                c->k1_next_eps = eps + (size_t)(t + 1) * 2 * sz; c->k1_next_u = u ? u + (size_t)(t + 1) * su : nullptr;
+            } else { c->k1_next_E = nullptr; c->k1_next_eps = nullptr; c->k1_next_u = nullptr; }
+            rc = launch_trial(c, args(t), 3, sa, nullptr, true, t > 0 ? pdone : nullptr, post_before);
+            c->k1_next_E = nullptr; c->k1_own_phi = 1;
+            if (rc) return rc;
+            // sb: Phi^T Phi of this step behind "Phi rows written" (not ahead, or step 0) ...
+            if (!ahead || t == 0) {
+                hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)phic, phi_before + nblk, stw);
+                if ((rc = launch_gram(c, B, 0, ne, 0u, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, statc, 1u))) return rc;
+            }
+            // ... Phi^T dx and sum |dx|^2 behind "all rows written" ...
             hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
             if ((rc = launch_gram(c, B, c->fdx_job0, ne - c->fdx_job0, kScRls, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, nullptr, 2u))) return rc;
         } else {
@@ -973,12 +997,18 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
                                        c->comm_b, sb));
             hipLaunchKernelGGL(vjf_count_kernel, dim3(1), dim3(64), 0, sb, statc, nred);
         }
-        c->stat_count += nred;
+        if (!(fused && c->ahead_ok) || t == 0) c->stat_count += nred;   // (ahead: step t's Phi^T Phi was reduced during step t-1)
         // ... then, behind W and sigma of step t-1 and once the Cholesky loop holds P_old in registers, the state's P and g
         hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)pdone, post_before, (const unsigned*)runw, epoch0 + (unsigned)t, stw);
         VJF_HIP(hipGetLastError());
         if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, prepc))) return rc;
         c->prep_count += nprep;
+        if (fused && c->ahead_ok && t + 1 < T) {
+            // ... and Phi^T Phi of step t+1, a step early: its reduce buffer was step t-1's, free once post(t-1) is done
+            hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)phic, c->phi_count, (const unsigned*)pdone, post_before, stw);
+            if ((rc = launch_gram(c, B, 0, ne, 0u, rede[(t + 1) & 1], sb, nullptr, (t + 1) & 1, nullptr, 0, false, statc, 1u))) return rc;
+            c->stat_count += nred;
+        }
         // sa: backward half(t); it waits in-kernel for post(t-1), whose workgroups are resident
         c->epoch_k1 = epoch0 + (unsigned)t;
         if (!fused && (rc = launch_trial(c, args(t), 2, sa, nullptr, false, t > 0 ? pdone : nullptr, post_before))) return rc;

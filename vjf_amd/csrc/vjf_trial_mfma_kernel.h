@@ -83,6 +83,10 @@ struct VjfTrialMfmaArgs {
                            //   (release at agent scope): the statistics Gram on another stream starts behind vjf_gate_kernel on it
     const unsigned* rls_done;  // backward half: workgroups of the previous step's post kernel that have their W, w_chol, sigma in
     unsigned rls_target;       //   memory; non-null -> the workgroup waits (bounded) for the count before stage 2, its reloads done
+    // part 3, statistics one step ahead: Phi of the NEXT step depends only on this step's posterior, xs' = mu_t + eps_s' e^{lv_t/2}.
+    // With next_E set the kernel writes those Phi columns (the rows of the next step's parity) right after the posterior and
+    // counts them in phi_done; own_phi = 0 then says that this step's Phi columns were written by the previous launch.
+    float* next_E; const float* next_eps_s; const float* next_u; int own_phi;
     unsigned* phi_done;    // part 3: += 1 per workgroup once the Phi columns of its E rows are in memory (the Gram of Phi^T Phi starts
                            //   behind it, before the recognition network has run)
     int part;              // 0: whole step; 1: forward half (features, recognition, E / ACT rows, posterior);
@@ -183,6 +187,9 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     __syncthreads();
 
+    float* s_cen = s_d0;                           // n * dxu + n floats needed; available: 2 * hmax * 17, or s_py + s_dpy
+    float* s_iw = s_cen + n * dxu;
+    const bool stage_c = (n * dxu + n) <= 2 * (compact ? dy : P.hmax) * LD;
     VJF_K1_STAMP(23);
     // ---- stage 1: RBF features (functional.py:11-22); lanes walk the trial index
     if (!fwd) {                                   // backward half: the forward half left Phi in the E rows
@@ -192,9 +199,6 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         // centroids and -1/(2 w^2) staged in LDS (the delta buffers are free until the backward pass)
         const float* cen = S + P.off[VJF_SLOT_CENTROID];
         const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
-        float* s_cen = s_d0;                       // n * dxu + n floats needed; available: 2 * hmax * 17, or s_py + s_dpy
-        float* s_iw = s_cen + n * dxu;
-        const bool stage_c = (n * dxu + n) <= 2 * (compact ? dy : P.hmax) * LD;
         if (stage_c) {
             for (int e = tid; e < n * dxu; e += VJF_K1M_THREADS) s_cen[e] = cen[e];
             for (int e = tid; e < n; e += VJF_K1M_THREADS) { const float w = expf(lw[e]); s_iw[e] = -0.5f / (w * w); }
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    if (fused3) {
+    if (fused3 && AA.own_phi) {
         for (int b = wave; b < nb; b += NW) {
             float* erow = A.E + (size_t)(b0 + b) * P.ldE;
             for (int c = lane; c < n; c += 64) erow[c] = s_phi[c * LD + b];
@@ -294,6 +298,29 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         A.lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
     }
     __syncthreads();
+    if (fused3 && AA.next_E) {
+        // Phi of the next step, exactly as stage 0 / 1 of the next launch will form it (same operations in the same order: the
+        // same bits).  xs' goes to the backward seeds' rows (free until stage 5); the staged centroids are still in place.
+        float* s_xn = s_dmu;                                           // dxu <= 3 dz rows (host checks)
+        for (int e = tid; e < 16 * dxu; e += VJF_K1M_THREADS) {
+            const int c = e >> 4, b = e & 15;
+            const size_t g = (size_t)(b0 + (b < nb ? b : 0));
+            float v;
+            if (c < dz) v = fmaf(AA.next_eps_s[g * dz + c], expf(0.5f * s_lv[c * LD + b]), s_mu[c * LD + b]);
+            else v = AA.next_u[g * du + (c - dz)];
+            s_xn[c * LD + b] = v;
+        }
+        __syncthreads();
+        for (int b = wave; b < nb; b += NW) {
+            float* erow = AA.next_E + (size_t)(b0 + b) * P.ldE;
+            for (int k = lane; k < n; k += 64) {
+                float d2 = 0.f;
+                for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
+                erow[k] = expf(d2 * s_iw[k]);
+            }
+        }
+        if (AA.phi_done) signal_rows(AA.phi_done);
+    }
     if (bwd) {
         const float* CT = AA.aux + P.aux_decT;                         // (dz, dy)
         const float* d = S + P.off[VJF_SLOT_DEC_B];
