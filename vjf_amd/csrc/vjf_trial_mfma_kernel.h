@@ -298,6 +298,24 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         A.lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
     }
     __syncthreads();
+    if (fused3) {
+        // sum |dx|^2 of this workgroup (as the forward half forms it), needed behind the signal below
+        constexpr int LPT = VJF_K1M_THREADS / 16;
+        const int b = tid / LPT, sl = tid % LPT;
+        float sdx2 = 0.f;
+        for (int j = sl; j < dz; j += LPT) {
+            const float dx = s_xt[j * LD + b] - s_xu[j * LD + b];
+            sdx2 = fmaf(dx, dx, sdx2);
+        }
+        sdx2 = group_sum<LPT>(sdx2);
+        if (sl == 0) s_sc[b * RS_N + RS_SDX2] = b < nb ? sdx2 : 0.f;
+        __syncthreads();
+        if (tid == RS_SDX2) {
+            float v = 0.f;
+            for (int bb = 0; bb < 16; ++bb) v += s_sc[bb * RS_N + tid];
+            A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
+        }
+    }
     if (fused3 && AA.next_E) {
         // Phi of the next step, exactly as stage 0 / 1 of the next launch will form it (same operations in the same order: the
         // same bits).  xs' goes to the backward seeds' rows (free until stage 5); the staged centroids are still in place.
@@ -319,7 +337,32 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
                 erow[k] = expf(d2 * s_iw[k]);
             }
         }
-        if (AA.phi_done) signal_rows(AA.phi_done);
+    }
+    if (fused3) {
+        // the rest of the forward half's rows (dx and zero padding of E, all of ACT; the posterior went out in stage 4), the
+        // signal for the kernels that take them, and only then what needs the previous step's RLS update
+        for (int b = wave; b < nb; b += NW) {
+            float* erow = A.E + (size_t)(b0 + b) * P.ldE;
+            for (int c = n + lane; c < P.ldE; c += 64) erow[c] = c < n + dz ? s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b] : 0.f;
+            float* arow = A.ACT + (size_t)(b0 + b) * P.ldA;
+            for (int c = lane; c <= din; c += 64) arow[c] = c < din ? s_in[c * LD + b] : 1.f;
+            int aoff = 0;
+            for (int l = 0; l < P.L; ++l) {
+                const int hl = P.h[l], c0 = P.colA_act[l + 1];
+                for (int k = lane; k <= hl; k += 64) arow[c0 + k] = k < hl ? s_act[(aoff + k) * LD + b] : 1.f;
+                aoff += hl;
+            }
+            for (int j = lane; P.colA_xt + j < P.ldA; j += 64) arow[P.colA_xt + j] = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f);
+        }
+        // ONE release for everything this launch hands to other streams: the rows of this step and Phi of the next
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (AA.fwd_done) __hip_atomic_fetch_add(AA.fwd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (AA.phi_done && AA.next_E) __hip_atomic_fetch_add(AA.phi_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (bwd) {
         const float* CT = AA.aux + P.aux_decT;                         // (dz, dy)
@@ -338,7 +381,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
 
     VJF_K1_STAMP(27);
-    if (!bwd || fused3) {
+    if (!bwd) {
         // forward half: of the loss scalars only sum |dx|^2 (the RLS chain's residual identity needs it), summed
         // exactly as stage 5 does; then the E and ACT rows
         constexpr int LPT = VJF_K1M_THREADS / 16;
@@ -356,24 +399,6 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             for (int bb = 0; bb < 16; ++bb) v += s_sc[bb * RS_N + tid];
             A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
         }
-    }
-    if (fused3) {
-        // the rest of the forward half's rows (dx and zero padding of E, all of ACT; the posterior went out in stage 4), the
-        // signal for the kernels that take them, and only then what needs the previous step's RLS update
-        for (int b = wave; b < nb; b += NW) {
-            float* erow = A.E + (size_t)(b0 + b) * P.ldE;
-            for (int c = n + lane; c < P.ldE; c += 64) erow[c] = c < n + dz ? s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b] : 0.f;
-            float* arow = A.ACT + (size_t)(b0 + b) * P.ldA;
-            for (int c = lane; c <= din; c += 64) arow[c] = c < din ? s_in[c * LD + b] : 1.f;
-            int aoff = 0;
-            for (int l = 0; l < P.L; ++l) {
-                const int hl = P.h[l], c0 = P.colA_act[l + 1];
-                for (int k = lane; k <= hl; k += 64) arow[c0 + k] = k < hl ? s_act[(aoff + k) * LD + b] : 1.f;
-                aoff += hl;
-            }
-            for (int j = lane; P.colA_xt + j < P.ldA; j += 64) arow[P.colA_xt + j] = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f);
-        }
-        if (AA.fwd_done) signal_rows(AA.fwd_done);
     }
     // (every part: as late as it can be -- recognition or its reload, xt and the decoder above do not need the RLS update)
     if (AA.rls_done && bwd) {
