@@ -161,6 +161,28 @@ def test_filter_sequence_persistent_equals_per_step_launches(vjf, monkeypatch):
     assert torch.equal(outs[0][2], outs[1][2])
 
 
+def test_filter_sequence_one_launch_equals_two_halves(vjf, monkeypatch):
+    """The default sequence schedule (one trial-kernel launch per step, Phi^T Phi a step ahead) against the schedule with a
+    forward and a backward half per step: bit for bit, also with a control input and the Poisson likelihood."""
+    for name in ("g5_medium_gaussian_f32", "g5_gaussian_du2_wu0_f32", "g5_medium_poisson_f32"):
+        z, info, _ = gio.traj_case(name)
+        y, eps = torch.tensor(z["y"]), torch.tensor(z["eps"])
+        u = torch.tensor(z["u"]) if info["du"] else None
+        outs = []
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("VJF_NO_FUSED_SEQ", env)
+            m = _model_for(vjf, info)
+            load_fixture_state(m, z, "s0")
+            o = m.filter_sequence(y, u, None, eps=eps)
+            assert m.status() == 0
+            outs.append((o, m._blob.clone()))
+        monkeypatch.delenv("VJF_NO_FUSED_SEQ", raising=False)
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert torch.equal(a, b)
+        assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_filter_sequence_in_chunks(vjf, monkeypatch):
     """Long sequences are enqueued in chunks (one set of persistent kernels per chunk): same bits as one piece."""
     z, info, _ = gio.traj_case("g5_medium_gaussian_f32")

@@ -218,7 +218,7 @@ struct vjf_ctx {
     bool ahead_ok;         // the plan allows the statistics-one-step-ahead variant (centroids staged in LDS, xs' fits its scratch rows)
     int fdx_job0;          // first E^T E job whose tile row holds dx columns (they are the tail of the E jobs)
     unsigned phi_count;    // host mirror of the trial kernel's "Phi rows written" count (part 3)
-    bool fused_seq;        // vjf_filter_seq with one trial-kernel launch per step (VJF_FUSED_SEQ)
+    bool fused_seq;        // vjf_filter_seq with one trial-kernel launch per step (default; VJF_NO_FUSED_SEQ: a forward and a backward half)
     unsigned epoch_k1;     // diagnostic: epoch of the step whose backward half is launched next (ring entry of its stamps)
     bool queues_ok;        // the four streams of vjf_filter_seq run beside each other (probed when they are created)
     bool persistent;       // vjf_filter_seq: the RLS chain as persistent kernels (default; VJF_NO_PERSISTENT turns it off)
@@ -311,7 +311,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
     c->fdx_job0 = c->n_ejobs;
     for (int i = 0; i < c->n_ejobs; ++i) if ((jobs[i].ti + 1) * VJF_TILE > P.n) { c->fdx_job0 = i; break; }
-    c->phi_count = 0; c->fused_seq = getenv("VJF_FUSED_SEQ") != nullptr;
+    c->phi_count = 0; c->fused_seq = getenv("VJF_NO_FUSED_SEQ") == nullptr;
     c->k1_next_E = nullptr; c->k1_next_eps = nullptr; c->k1_next_u = nullptr; c->k1_own_phi = 1;
     {
         const bool compact = P.dy >= P.hmax;
@@ -924,7 +924,7 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     // fused: ONE trial-kernel launch per step (part 3): it signals "Phi rows written" before the recognition network runs and "all
     // rows written" before it waits for the RLS update; Phi^T Phi is reduced behind the first signal (what the Cholesky loop
     // waits for), Phi^T dx and sum |dx|^2 behind the second (what the operand kernel needs)
-    const bool fused = c->fused_seq && !c->comm_a;
+    const bool fused = c->fused_seq && !c->comm_a && (c->ahead_ok || getenv("VJF_FUSED_SEQ"));   // (without the step-ahead Gram it loses)
     unsigned* phic = fl + 53;
     const unsigned npost = (unsigned)(2 * nbl + 1), nblk = (unsigned)trial_blocks(c, B), nred = (unsigned)(fused ? ne : ne + 1),
                    nprep = (unsigned)((P.n + 15) / 16);
