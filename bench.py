@@ -249,8 +249,9 @@ def main():
                          "traffic_note": "HBM bytes per step: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, "
                                          "summed over the kernels of a step (profiles/pmc_traffic_current.json); algorithmic bytes "
                                          "per step = bytes_per_trial_step x trials",
-                         "kernel": "one filter step = vjf_trial_mfma_kernel (forward + backward half), vjf_gram_kernel x2, "
-                                   "vjf_gram_reduce_kernel, vjf_sgd_kernel, vjf_prepg_kernel, two gate kernels, and one step's share "
+                         "kernel": "one filter step = vjf_trial_mfma_kernel (one launch: forward part, row signals, in-kernel wait for the "
+                                   "RLS update, backward part), vjf_gram_kernel x3 (Phi^T Phi a step ahead, Phi^T dx, gradients), "
+                                   "vjf_gram_reduce_kernel x2, vjf_sgd_kernel, vjf_prepg_kernel, gate kernels, and one step's share "
                                    "of the persistent vjf_rls_pair_kernel (Cholesky, y/W and inverse workgroups) that "
                                    "serve the whole sequence; three streams (HIP events around the timed region / steps)",
                          "flops_per_trial_step": flops, "serial_flops_per_step": serial_flops,
