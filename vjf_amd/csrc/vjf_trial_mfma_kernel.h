@@ -313,7 +313,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         if (tid == RS_SDX2) {
             float v = 0.f;
             for (int bb = 0; bb < 16; ++bb) v += s_sc[bb * RS_N + tid];
-            A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
+            __hip_atomic_store(A.partial + (size_t)blockIdx.x * RS_N + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (fused3 && AA.next_E) {
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             for (int k = lane; k < n; k += 64) {
                 float d2 = 0.f;
                 for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
-                erow[k] = expf(d2 * s_iw[k]);
+                __hip_atomic_store(erow + k, expf(d2 * s_iw[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through, see below)
             }
         }
     }
@@ -343,7 +343,8 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         // signal for the kernels that take them, and only then what needs the previous step's RLS update
         for (int b = wave; b < nb; b += NW) {
             float* erow = A.E + (size_t)(b0 + b) * P.ldE;
-            for (int c = n + lane; c < P.ldE; c += 64) erow[c] = c < n + dz ? s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b] : 0.f;
+            for (int c = n + lane; c < P.ldE; c += 64)
+                __hip_atomic_store(erow + c, c < n + dz ? s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float* arow = A.ACT + (size_t)(b0 + b) * P.ldA;
             for (int c = lane; c <= din; c += 64) arow[c] = c < din ? s_in[c * LD + b] : 1.f;
             int aoff = 0;
@@ -354,12 +355,12 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             }
             for (int j = lane; P.colA_xt + j < P.ldA; j += 64) arow[P.colA_xt + j] = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f);
         }
-        // ONE release for everything this launch hands to other streams: the rows of this step and Phi of the next
+        // What this launch hands to kernels on other streams (the dx columns of E, Phi of the next step, sum |dx|^2) went out as
+        // write-through stores: in memory once vmcnt has drained -- no L2 write-back by 256 workgroups (the ACT rows and the
+        // posterior are for kernels behind this one in its own stream)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (AA.fwd_done) __hip_atomic_fetch_add(AA.fwd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (AA.phi_done && AA.next_E) __hip_atomic_fetch_add(AA.phi_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
