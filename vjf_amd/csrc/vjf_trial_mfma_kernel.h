@@ -128,6 +128,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     const bool warm = (A.flags & VJF_FLAG_WARM_UP) != 0;
     const bool tri = S[P.off[VJF_SLOT_SCALARS] + VJF_SC_TRI_CLEAN] != 0.f;   // w_chol known upper triangular
     const bool fwd = AA.part != 2, bwd = AA.part != 1, fused3 = AA.part == 3;
+    const bool handoff = AA.fwd_done != nullptr && !bwd;        // part 1 inside vjf_filter_seq
     constexpr int LD = VJF_LDT;
     constexpr int NW = VJF_K1M_WAVES;
 
@@ -316,28 +317,6 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             __hip_atomic_store(A.partial + (size_t)blockIdx.x * RS_N + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (fused3 && AA.next_E) {
-        // Phi of the next step, exactly as stage 0 / 1 of the next launch will form it (same operations in the same order: the
-        // same bits).  xs' goes to the backward seeds' rows (free until stage 5); the staged centroids are still in place.
-        float* s_xn = s_dmu;                                           // dxu <= 3 dz rows (host checks)
-        for (int e = tid; e < 16 * dxu; e += VJF_K1M_THREADS) {
-            const int c = e >> 4, b = e & 15;
-            const size_t g = (size_t)(b0 + (b < nb ? b : 0));
-            float v;
-            if (c < dz) v = fmaf(AA.next_eps_s[g * dz + c], expf(0.5f * s_lv[c * LD + b]), s_mu[c * LD + b]);
-            else v = AA.next_u[g * du + (c - dz)];
-            s_xn[c * LD + b] = v;
-        }
-        __syncthreads();
-        for (int b = wave; b < nb; b += NW) {
-            float* erow = AA.next_E + (size_t)(b0 + b) * P.ldE;
-            for (int k = lane; k < n; k += 64) {
-                float d2 = 0.f;
-                for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
-                __hip_atomic_store(erow + k, expf(d2 * s_iw[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through, see below)
-            }
-        }
-    }
     if (fused3) {
         // the rest of the forward half's rows (dx and zero padding of E, all of ACT; the posterior went out in stage 4), the
         // signal for the kernels that take them, and only then what needs the previous step's RLS update
@@ -362,7 +341,6 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         __syncthreads();
         if (tid == 0) {
             if (AA.fwd_done) __hip_atomic_fetch_add(AA.fwd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (AA.phi_done && AA.next_E) __hip_atomic_fetch_add(AA.phi_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (bwd) {
@@ -398,7 +376,8 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         if (tid == RS_SDX2) {
             float v = 0.f;
             for (int bb = 0; bb < 16; ++bb) v += s_sc[bb * RS_N + tid];
-            A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
+            if (handoff) __hip_atomic_store(A.partial + (size_t)blockIdx.x * RS_N + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
         }
     }
     // (every part: as late as it can be -- recognition or its reload, xt and the decoder above do not need the RLS update)
@@ -417,6 +396,43 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         __syncthreads();
         }
+    if (fused3 && AA.next_E) {
+        // Phi of the next step, exactly as stage 0 / 1 of the next launch will form it (same operations in the same order: the
+        // same bits), written BEHIND the wait above: the rows it overwrites are those of step t-1, whose Phi^T dx Gram is only
+        // known to be finished once the RLS update of step t-1 is (operand kernel -> y / W loop -> sigma).  xs' goes to the
+        // backward seeds' rows (free until stage 5); the centroids are still staged unless the decoder has overwritten them
+        // (compact layout: then they come from L2).
+        float* s_xn = s_dmu;                                           // dxu <= 3 dz rows (host checks)
+        for (int e = tid; e < 16 * dxu; e += VJF_K1M_THREADS) {
+            const int c = e >> 4, b = e & 15;
+            const size_t g = (size_t)(b0 + (b < nb ? b : 0));
+            float v;
+            if (c < dz) v = fmaf(AA.next_eps_s[g * dz + c], expf(0.5f * s_lv[c * LD + b]), s_mu[c * LD + b]);
+            else v = AA.next_u[g * du + (c - dz)];
+            s_xn[c * LD + b] = v;
+        }
+        __syncthreads();
+        const float* cen_g = S + P.off[VJF_SLOT_CENTROID];
+        const float* lw_g = S + P.off[VJF_SLOT_LOGWIDTH];
+        for (int b = wave; b < nb; b += NW) {
+            float* erow = AA.next_E + (size_t)(b0 + b) * P.ldE;
+            for (int k = lane; k < n; k += 64) {
+                float d2 = 0.f, iw;
+                if (!compact) {
+                    for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
+                    iw = s_iw[k];
+                } else {
+                    for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - cen_g[k * dxu + c]; d2 = fmaf(d, d, d2); }
+                    const float w = expf(lw_g[k]);
+                    iw = -0.5f / (w * w);
+                }
+                __hip_atomic_store(erow + k, expf(d2 * iw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through)
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && AA.phi_done) __hip_atomic_fetch_add(AA.phi_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     VJF_K1_STAMP(24);
     // ---- stage 2 (runs in front of stage 5): predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and
     //      pt.mean = xs + Phi W (module.py:77)
@@ -596,7 +612,9 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
                 float v = 0.f;
                 if (c < n) v = s_phi[c * LD + b];
                 else if (c < n + dz) v = s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b];
-                erow[c] = v;
+                // (forward half of the sequence: the statistics Gram on another stream takes these rows -- write-through)
+                if (handoff) __hip_atomic_store(erow + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else erow[c] = v;
             }
             float* arow = A.ACT + (size_t)(b0 + b) * P.ldA;
             for (int c = lane; c <= din; c += 64) arow[c] = c < din ? s_in[c * LD + b] : 1.f;
@@ -628,16 +646,12 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     if (AA.done && bwd && tid == 0) __hip_atomic_fetch_add(AA.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (AA.fwd_done && !bwd) {
-        // producer side of a hand-off between launches on different streams (MI355X guide, visibility, valid forms): every
-        // storing wavefront drains its stores, the workgroup barrier, one lane releases at agent scope (L2 write-back),
-        // drains again, then the relaxed agent-scope signal
+        // producer side of a hand-off between launches on different streams: what the other stream takes (E rows, sum |dx|^2)
+        // went out as write-through stores, in memory once every storing wavefront's vmcnt has drained; the workgroup barrier,
+        // then the relaxed agent-scope count -- no L2 write-back by 256 workgroups
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(AA.fwd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) __hip_atomic_fetch_add(AA.fwd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
