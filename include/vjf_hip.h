@@ -41,6 +41,17 @@ extern "C" {
 #define VJF_STATUS_NONFINITE_DYN 2u     /* l_dynamics non-finite (model.py:141-142)               */
 #define VJF_STATUS_NONFINITE_ENT 4u     /* entropy non-finite (model.py:144-145)                  */
 #define VJF_STATUS_RLS_FAILED 8u        /* Cholesky pivot <= 0 in rls: RLS state left unchanged   */
+/* detail bits beside VJF_STATUS_RLS_FAILED: which bounded wait of vjf_filter_seq's multi-stream schedule ran out (a kernel
+   waited for a kernel of another stream that did not deliver in time; results of the call are then not to be used) */
+#define VJF_STATUS_WAIT_RESIDENT 0x100u  /* SGD kernel: RLS kernels not resident                  */
+#define VJF_STATUS_WAIT_OPERAND 0x200u   /* operand kernel: previous step's RLS update            */
+#define VJF_STATUS_WAIT_STATS 0x400u     /* Cholesky loop: statistics reduced                     */
+#define VJF_STATUS_WAIT_SIGMA 0x800u     /* Cholesky loop: previous step's RLS update             */
+#define VJF_STATUS_WAIT_GATE 0x1000u     /* a gate kernel / in-kernel gate of the Gram kernel     */
+#define VJF_STATUS_WAIT_GATE2 0x2000u    /* a two-count gate kernel                               */
+#define VJF_STATUS_WAIT_G 0x4000u        /* y / W loop: operands (g)                              */
+#define VJF_STATUS_WAIT_COLUMN 0x8000u   /* post kernel: a column of L, or the trial kernel's readers */
+#define VJF_STATUS_WAIT_K1 0x10000u      /* trial kernel: previous step's RLS update              */
 
 /* Slots of the state blob, in the reference's state_dict order followed by the plain-attribute
  * RLS tensors and the scalars the reference keeps as Python numbers. */
@@ -160,7 +171,13 @@ int vjf_filter_global(vjf_ctx* ctx, int32_t B_total, float* loss4, uint32_t flag
 
 /* T successive steps, each fed the previous posterior: the inner loop of VJF.fit
  * (model.py:252-261).  y (T,B,ydim); u (T,B,udim) or NULL; eps (T,2,B,xdim);
- * mu0/lv0 (B,xdim) or NULL => prior; outputs mu, lv (T,B,xdim), loss (T,4). */
+ * mu0/lv0 (B,xdim) or NULL => prior; outputs mu, lv (T,B,xdim), loss (T,4).
+ * With update and without warm-up the steps run as a multi-stream schedule (bit-identical to the
+ * one-stream order).  On a single rank its RLS chain runs in kernels that stay resident for the
+ * sequence; the call then checkpoints the state blob, synchronises the caller's stream ONCE at
+ * the end to read the status word, and if one of the schedule's bounded waits ran out
+ * (VJF_STATUS_WAIT_*) restores the blob and runs the sequence again with a launch per step
+ * (VJF_NO_SEQ_GUARD=1: no checkpoint, no synchronisation, no re-run). */
 int vjf_filter_seq(vjf_ctx* ctx, int32_t T, int32_t B, const float* y, const float* u, const float* eps,
                    const float* mu0, const float* lv0, float* mu, float* lv, float* loss, uint32_t flags);
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <string>
 #include <vector>
@@ -149,7 +150,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 }
 
 struct Carve {
-    size_t pscr; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t backup; size_t pscr; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -173,6 +174,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
     c.flags = take(256);                                   // column flags of the Cholesky -> post hand-off (a block of their own)
     c.lscr = take((size_t)P.n * P.n * 4);                  // L, column by column, from the Cholesky kernel to the post kernel
+    c.backup = take((size_t)P.n_state * 4);                 // the state blob as it was when a persistent sequence started
     c.pscr = take((size_t)(VJF_CHOL_MAXBLK * (VJF_CHOL_MAXBLK + 1) / 2) * 1024 * 4);   // lower blocks of P, from one Cholesky kernel to the next
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
@@ -795,8 +797,32 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     // (single rank only: a collective library may synchronise the device when it sets something up lazily, which kernels that
     //  stay resident for the whole sequence would turn into a time-out; VJF_PERSISTENT_DIST=1 tries it anyway)
     if (c->persistent && !c->overlap_serial) { int rc0 = ensure_stream2(c); if (rc0) return rc0; }
-    if (c->persistent && c->queues_ok && !c->overlap_serial && c->mfma_trial && c->post_kernels && c->plan.dz <= 16 && (!c->comm_a || getenv("VJF_PERSISTENT_DIST")))
-        return filter_seq_persist(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
+    if (c->persistent && c->queues_ok && !c->overlap_serial && c->mfma_trial && c->post_kernels && c->plan.dz <= 16 && (!c->comm_a || getenv("VJF_PERSISTENT_DIST"))) {
+        // The persistent kernels wait (bounded) for kernels the host enqueues while they run.  The runtime multiplexes streams
+        // onto a few hardware queues; once in a while a launch of ours is held behind the persistent kernel's queue until that
+        // kernel's waits run out (seen under heavy stream churn: ~1 % of sequences, an 80 ms stall).  Such a sequence is not to
+        // be used: the state blob is checkpointed first, the status word read back at the end (one host synchronisation per
+        // sequence), and on a wait time-out the blob is restored, the hand-off counters are reset and the sequence runs again
+        // with a launch per step -- which does not depend on any kernel staying resident.  Single rank only (with communicators
+        // a re-run would have to be agreed between the ranks: there the per-step launches are the default anyway).
+        const bool guard = !c->comm_a && getenv("VJF_NO_SEQ_GUARD") == nullptr;
+        float* backup = (float*)(c->ws + c->cv.backup);
+        if (guard) VJF_HIP(hipMemcpyAsync(backup, c->state, (size_t)c->plan.n_state * 4, hipMemcpyDeviceToDevice, c->stream));
+        int rc1 = filter_seq_persist(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
+        if (rc1 || !guard) return rc1;
+        float stf = 0.f;
+        VJF_HIP(hipMemcpyAsync(&stf, c->state + c->plan.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, 4, hipMemcpyDeviceToHost, c->stream));
+        VJF_HIP(hipStreamSynchronize(c->stream));
+        if (((unsigned)stf & 0x1ff00u) == 0) return 0;
+        if (getenv("VJF_VERBOSE")) fprintf(stderr, "vjf: a wait of the persistent sequence timed out (status 0x%x): re-running it with per-step launches\n", (unsigned)stf);
+        VJF_HIP(hipStreamSynchronize(c->stream2)); VJF_HIP(hipStreamSynchronize(c->stream3)); VJF_HIP(hipStreamSynchronize(c->stream4));
+        VJF_HIP(hipMemcpyAsync(c->state, backup, (size_t)c->plan.n_state * 4, hipMemcpyDeviceToDevice, c->stream));
+        VJF_HIP(hipMemsetAsync(c->ws + c->cv.flags, 0, 256, c->stream));
+        VJF_HIP(hipStreamSynchronize(c->stream));
+        c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0; c->stat_count = 0; c->prep_count = 0; c->start_count = 0;
+        c->phi_count = 0;
+        c->persistent = false;                                           // (this context stays on the per-step launches)
+    }
     int rc = ensure_stream2(c);
     if (rc) return rc;
     const VjfPlan& P = c->plan;
@@ -963,7 +989,27 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     c->epoch += (unsigned)T;
     c->start_count += npost;
     if (!fused && (rc = launch_trial(c, args(0), 1, sa, nullptr, true))) return rc;   // prologue: forward half of step 0
+    const bool dbg_gap = getenv("VJF_DEBUG_GAPS") != nullptr;
+    timespec ts_prev{};
+    if (dbg_gap) clock_gettime(CLOCK_MONOTONIC, &ts_prev);
+    timespec tk{};
+    if (dbg_gap) clock_gettime(CLOCK_MONOTONIC, &tk);
+    auto tick = [&](const char* what, int t) {
+        if (!dbg_gap) return;
+        timespec now{};
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        const double ms = (now.tv_sec - tk.tv_sec) * 1e3 + (now.tv_nsec - tk.tv_nsec) * 1e-6;
+        if (ms > 20.0) fprintf(stderr, "vjf:   %.1f ms before '%s' returned (step %d)\n", ms, what, t);
+        tk = now;
+    };
     for (int t = 0; t < T; ++t) {
+        if (dbg_gap) {
+            timespec now{};
+            clock_gettime(CLOCK_MONOTONIC, &now);
+            const double ms = (now.tv_sec - ts_prev.tv_sec) * 1e3 + (now.tv_nsec - ts_prev.tv_nsec) * 1e-6;
+            if (ms > 20.0) fprintf(stderr, "vjf: host took %.1f ms to reach step %d of %d\n", ms, t, T);
+            ts_prev = now;
+        }
         const unsigned post_before = c->post_count;                      // workgroups of post(0 .. t-1)
         if (fused) {
             // sa: the whole trial kernel of step t (its backward part waits in-kernel for post(t-1)).  ahead: it also writes the
@@ -976,7 +1022,9 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
                 c->k1_next_E = (float*)(c->ws + (((t + 1) & 1) ? c->cv.E2 : c->cv.E));
                 c->k1_next_eps = eps + (size_t)(t + 1) * 2 * sz; c->k1_next_u = u ? u + (size_t)(t + 1) * su : nullptr;
             } else { c->k1_next_E = nullptr; c->k1_next_eps = nullptr; c->k1_next_u = nullptr; }
+            tick("loop top", t);
             rc = launch_trial(c, args(t), 3, sa, nullptr, true, t > 0 ? pdone : nullptr, post_before);
+            tick("trial kernel launch", t);
             c->k1_next_E = nullptr; c->k1_own_phi = 1;
             if (rc) return rc;
             // sb: Phi^T Phi of this step behind "Phi rows written" (not ahead, or step 0) ...
@@ -1013,10 +1061,12 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         c->epoch_k1 = epoch0 + (unsigned)t;
         if (!fused && (rc = launch_trial(c, args(t), 2, sa, nullptr, false, t > 0 ? pdone : nullptr, post_before))) return rc;
         c->post_count += npost;
+        tick("statistics stream launches", t);
         if (t == 0) {
             hipLaunchKernelGGL(vjf_triclean_kernel, dim3(64), dim3(256), 0, sa, P, c->state);
             hipLaunchKernelGGL(vjf_triclean_done_kernel, dim3(1), dim3(1), 0, sa, P, c->state);
             VJF_HIP(hipGetLastError());
+            tick("triclean launches", t);
         }
         // single rank: the SGD kernel sums the gradient slabs itself (one launch instead of reduce + SGD; VJF_NO_FUSED_SGD: two)
         const bool fuse_sgd = !c->comm_a && getenv("VJF_NO_FUSED_SGD") == nullptr;
@@ -1037,6 +1087,7 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, nullptr, nullptr, 0,
                              t == 0 ? runw : nullptr, epoch0, started, c->start_count);
         }
+        tick("gradient Gram + SGD launches", t);
         if (rc) return rc;
         if (!fused && t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
     }

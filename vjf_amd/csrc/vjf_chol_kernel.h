@@ -138,9 +138,10 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
                 const unsigned r = __hip_atomic_load(A.run_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned q = __hip_atomic_load(A.start_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int)(r - A.run_epoch) >= 0 && (int)(q - A.start_target) >= 0) { there = true; break; }
+                if ((spins & 255u) == 255u && vjf_abort_seen(SC + VJF_SC_STATUS)) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (!there) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
+            if (!there) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
         }
     }
 }
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void vjf_prepg_kernel(VjfPlan P, VjfPrepArgs A
                 if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.wait_target) >= 0) { there = true; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
-            if (!there) vjf_status_or(S + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
+            if (!there) vjf_status_or(S + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_OPERAND);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -720,7 +721,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
     }
     if (tid == 0) s_flag[0] = 1;
     __syncthreads();
-    if (A.stat_count && !vjf_wg_wait(A.stat_count, it_stat_target, tid)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED); *s_dead = 1; }
+    if (A.stat_count && !vjf_wg_wait(A.stat_count, it_stat_target, tid, SC + VJF_SC_STATUS)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_STATS); *s_dead = 1; }
 
     if (!warm) {
         // ---- load the lower block triangle of P_new (vjf_prep_kernel already added Phi^T Phi / v).  Wavefront 0 takes the
@@ -740,7 +741,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // operands in registers: the state's P may now be overwritten
             __syncthreads();
             if (tid == 0) __hip_atomic_store(A.flags_out + VJF_CHOL_MAXBLK + 2, it_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!vjf_wg_wait(A.wait_count, it_wait_target, tid)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED); *s_dead = 1; }
+            if (!vjf_wg_wait(A.wait_count, it_wait_target, tid, SC + VJF_SC_STATUS)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
             sig = __hip_atomic_load(S + P.off[VJF_SLOT_TR_LOGVAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto g4 = [&](int gi, int gj) {                                 // 4 entries of G, zero outside the matrix

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(VJF_GRAM_THREADS) void vjf_gram_kernel(VjfPlan P, V
                 if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.wait_target) >= 0) { there = true; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
-            if (!there) vjf_status_or(A.status, VJF_STATUS_RLS_FAILED);
+            if (!there) vjf_status_or(A.status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }

@@ -180,13 +180,21 @@ __device__ __forceinline__ void vjf_wg_signal(unsigned* count, int tid) {
         __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// A wait that ran out somewhere in the sequence (status detail bits 0x1ff00, include/vjf_hip.h) ends every other wait at once:
+// the sequence is lost anyway (the host re-runs it), and nothing should sit through its own bound step after step.
+__device__ __forceinline__ bool vjf_abort_seen(const float* status) {
+    if (!status) return false;
+    const float f = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ((unsigned)f & 0x1ff00u) != 0u;
+}
 // returns false (lane 0 only; the others get true) when the count did not arrive within the bound
-__device__ __forceinline__ bool vjf_wg_wait(const unsigned* count, unsigned target, int tid) {
+__device__ __forceinline__ bool vjf_wg_wait(const unsigned* count, unsigned target, int tid, const float* status = nullptr) {
     bool there = true;
     if (tid == 0) {
         there = false;
         for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
             if ((int)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { there = true; break; }
+            if ((spins & 255u) == 255u && vjf_abort_seen(status)) break;
             __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

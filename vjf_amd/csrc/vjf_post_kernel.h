@@ -94,12 +94,13 @@ __device__ __forceinline__ void post_mma32(vjf_f32x4& acc, const float* Bs, int 
 // Wait (one lane polls, relaxed, bounded) until the Cholesky kernel has published flag word `k` for this epoch, then make
 // its bytes visible to the whole workgroup: one agent-scope acquire, its vmcnt drained, the workgroup barrier, and only then
 // the plain loads (cdna guide, Guideline 16).  Returns 0 = there, 1 = the factorisation failed, 2 = timed out.
-__device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned epoch, int k, int* s_ctl, int tid) {
+__device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned epoch, int k, int* s_ctl, int tid, const float* status) {
     if (tid == 0) {
         int st = 2;
         for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
             const unsigned v = __hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((v >> 1) == epoch) { st = (int)(v & 1u); break; }
+            if ((spins & 255u) == 255u && vjf_abort_seen(status)) break;
             __builtin_amdgcn_s_sleep(4);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -200,11 +201,11 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
     auto wait_g = [&]() {
         if (g_there) return;
         g_there = true;
-        if (!vjf_wg_wait(A.prep_count, it_prep_target, tid)) { vjf_status_or(A.status, VJF_STATUS_RLS_FAILED); *s_dead = 1; }
+        if (!vjf_wg_wait(A.prep_count, it_prep_target, tid, A.status)) { vjf_status_or(A.status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_G); *s_dead = 1; }
     };
     // ---- forward  Y_k = Dinv_k R_k ;  R_i -= L_ik Y_k  (i > k),   k = j0 .. nbl-1, column k of L staged when it appears
     for (int k = j0; k < nbl; ++k) {
-        bad = post_wait_column(A.flags, it_epoch, k, s_ctl, tid);
+        bad = post_wait_column(A.flags, it_epoch, k, s_ctl, tid, A.status);
         if (bad) break;
         if (solve && k == 0) {
             wait_g();
@@ -264,13 +265,14 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
         }
         __syncthreads();
     }
-    if (!bad) bad = post_wait_column(A.flags, it_epoch, VJF_CHOL_MAXBLK, s_ctl, tid);   // the factor as a whole
+    if (!bad) bad = post_wait_column(A.flags, it_epoch, VJF_CHOL_MAXBLK, s_ctl, tid, A.status);   // the factor as a whole
     if (A.k1_done) {                                           // readers of W, w_chol, sigma on another stream: all done?
         if (tid == 0) {
             int st = 2;
             for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
                 const unsigned v = __hip_atomic_load(A.k1_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int)(v - it_k1_target) >= 0) { st = 0; break; }
+                if ((spins & 255u) == 255u && vjf_abort_seen(A.status)) break;
                 __builtin_amdgcn_s_sleep(4);
             }
             s_ctl[0] = st;
@@ -280,7 +282,7 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
         __syncthreads();
     }
     VJF_POST_STAMP(18);
-    if (bad == 2 && tid == 0) { vjf_status_or(A.status, VJF_STATUS_RLS_FAILED); *s_dead = 1; }
+    if (bad == 2 && tid == 0) { vjf_status_or(A.status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_COLUMN); *s_dead = 1; }
     const bool failed = bad != 0;                              // factorisation failed: RLS state stays as it was
     if (failed && !(solve && A.fold_sigma)) { leave(); return; }
 
@@ -487,9 +489,10 @@ __global__ __launch_bounds__(64) void vjf_gate_kernel(const unsigned* count, uns
     for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
         const unsigned v = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(v - target) >= 0) return;
+        if ((spins & 255u) == 255u && vjf_abort_seen(status)) return;
         __builtin_amdgcn_s_sleep(2);
     }
-    vjf_status_or(status, VJF_STATUS_RLS_FAILED);
+    vjf_status_or(status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
 }
 
 // The same with two counts (both must have reached their targets).
@@ -500,9 +503,10 @@ __global__ __launch_bounds__(64) void vjf_gate2_kernel(const unsigned* count, un
         const unsigned v = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned w = __hip_atomic_load(count2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(v - target) >= 0 && (int)(w - target2) >= 0) return;
+        if ((spins & 255u) == 255u && vjf_abort_seen(status)) return;
         __builtin_amdgcn_s_sleep(2);
     }
-    vjf_status_or(status, VJF_STATUS_RLS_FAILED);
+    vjf_status_or(status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
 }
 
 struct VjfResidArgs {

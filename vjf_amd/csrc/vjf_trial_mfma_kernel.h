@@ -388,9 +388,10 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             bool there = false;
             for (unsigned spins = 0; spins < (1u << 19); ++spins) {
                 if ((int)(__hip_atomic_load(AA.rls_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - AA.rls_target) >= 0) { there = true; break; }
+                if ((spins & 255u) == 255u && vjf_abort_seen(A.state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS)) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (!there) vjf_status_or(const_cast<float*>(A.state) + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
+            if (!there) vjf_status_or(const_cast<float*>(A.state) + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
