@@ -343,7 +343,8 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             if (AA.fwd_done) __hip_atomic_fetch_add(AA.fwd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (bwd) {
+    const bool late_dec = fused3 && compact && AA.next_E != nullptr;   // (see the next-step Phi block: it needs the staged centroids)
+    if (bwd && !late_dec) {
         const float* CT = AA.aux + P.aux_decT;                         // (dz, dy)
         const float* d = S + P.off[VJF_SLOT_DEC_B];
         const int mt = (dy + 15) >> 4;
@@ -401,8 +402,8 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         // Phi of the next step, exactly as stage 0 / 1 of the next launch will form it (same operations in the same order: the
         // same bits), written BEHIND the wait above: the rows it overwrites are those of step t-1, whose Phi^T dx Gram is only
         // known to be finished once the RLS update of step t-1 is (operand kernel -> y / W loop -> sigma).  xs' goes to the
-        // backward seeds' rows (free until stage 5); the centroids are still staged unless the decoder has overwritten them
-        // (compact layout: then they come from L2).
+        // backward seeds' rows (free until stage 5); the centroids are still staged (compact layout: the decoder, whose output
+        // takes their place, runs behind this block).
         float* s_xn = s_dmu;                                           // dxu <= 3 dz rows (host checks)
         for (int e = tid; e < 16 * dxu; e += VJF_K1M_THREADS) {
             const int c = e >> 4, b = e & 15;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             float* erow = AA.next_E + (size_t)(b0 + b) * P.ldE;
             for (int k = lane; k < n; k += 64) {
                 float d2 = 0.f, iw;
-                if (!compact) {
+                if (stage_c) {
                     for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
                     iw = s_iw[k];
                 } else {
@@ -434,6 +435,21 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         __syncthreads();
         if (tid == 0 && AA.phi_done) __hip_atomic_fetch_add(AA.phi_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (bwd && late_dec) {                                         // compact layout: the decoder mean overwrites the staged centroids
+        const float* CT = AA.aux + P.aux_decT;                         // (dz, dy)
+        const float* d = S + P.off[VJF_SLOT_DEC_B];
+        const int mt = (dy + 15) >> 4;
+        for (int t = wave; t < mt; t += NW) {
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile(acc, CT, dy, dy, t * 16, s_xt, dz, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = t * 16 + 4 * (lane >> 4) + r;
+                if (f < dy) s_py[f * LD + (lane & 15)] = acc[r] + d[f];
+            }
+        }
+    }
+    if (late_dec) __syncthreads();
     VJF_K1_STAMP(24);
     // ---- stage 2 (runs in front of stage 5): predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and
     //      pt.mean = xs + Phi W (module.py:77)
