@@ -217,6 +217,8 @@ struct vjf_ctx {
     bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
                            // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
     float* k1_next_E; const float* k1_next_eps; const float* k1_next_u; int k1_own_phi;   // part 3: see VjfTrialMfmaArgs::next_E
+    bool phi_in_k1;        // Phi of the next step by the trial kernel itself (wide observations: measured 85 vs 90 us/step at config C)
+                           // or by vjf_phi_next_kernel on the statistics stream (67.1 vs 67.9 at config B); VJF_PHI_IN_K1=0/1 overrides
     bool ahead_ok;         // the plan allows the statistics-one-step-ahead variant (centroids staged in LDS, xs' fits its scratch rows)
     int fdx_job0;          // first E^T E job whose tile row holds dx columns (they are the tail of the E jobs)
     unsigned phi_count;    // host mirror of the trial kernel's "Phi rows written" count (part 3)
@@ -315,6 +317,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     for (int i = 0; i < c->n_ejobs; ++i) if ((jobs[i].ti + 1) * VJF_TILE > P.n) { c->fdx_job0 = i; break; }
     c->phi_count = 0; c->fused_seq = getenv("VJF_NO_FUSED_SEQ") == nullptr;
     c->k1_next_E = nullptr; c->k1_next_eps = nullptr; c->k1_next_u = nullptr; c->k1_own_phi = 1;
+    c->phi_in_k1 = getenv("VJF_PHI_IN_K1") ? atoi(getenv("VJF_PHI_IN_K1")) != 0 : P.dy >= P.hmax;
     {
         const bool compact = P.dy >= P.hmax;
         c->ahead_ok = (P.n * P.dxu + P.n) <= 2 * (compact ? P.dy : P.hmax) * VJF_LDT && P.dxu <= 3 * P.dz && getenv("VJF_NO_AHEAD") == nullptr;
@@ -338,6 +341,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     allow_lds(vjf_serial_kernel, c->lds_k2);
     allow_lds(vjf_rls_post_kernel, c->lds_post);
     allow_lds(vjf_prepg_kernel, vjf_prepg_lds_bytes(P));
+    allow_lds(vjf_phi_next_kernel, ((size_t)P.n * P.dxu + P.n + (size_t)P.dxu * VJF_LDT) * 4);
     if (c->mfma_trial) allow_lds(vjf_trial_mfma_kernel, c->lds_k1m);
     allow_lds(vjf_chol_lds_kernel<4>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<8>, c->lds_chol);
     allow_lds(vjf_chol_lds_kernel<12>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<16>, c->lds_chol);
@@ -1018,7 +1022,9 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             const unsigned phi_before = c->phi_count;
             c->epoch_k1 = epoch0 + (unsigned)t;
             c->k1_own_phi = (!ahead || t == 0) ? 1 : 0;
-            if (ahead && t + 1 < T) {
+            // (VJF_PHI_IN_K1: the trial kernel writes Phi of step t+1 itself, behind its RLS wait, instead of vjf_phi_next_kernel)
+            const bool phi_in_k1 = c->phi_in_k1;
+            if (ahead && phi_in_k1 && t + 1 < T) {
                 c->k1_next_E = (float*)(c->ws + (((t + 1) & 1) ? c->cv.E2 : c->cv.E));
                 c->k1_next_eps = eps + (size_t)(t + 1) * 2 * sz; c->k1_next_u = u ? u + (size_t)(t + 1) * su : nullptr;
             } else { c->k1_next_E = nullptr; c->k1_next_eps = nullptr; c->k1_next_u = nullptr; }
@@ -1052,8 +1058,19 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, prepc))) return rc;
         c->prep_count += nprep;
         if (fused && c->ahead_ok && t + 1 < T) {
-            // ... and Phi^T Phi of step t+1, a step early: its reduce buffer was step t-1's, free once post(t-1) is done
-            hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)phic, c->phi_count, (const unsigned*)pdone, post_before, stw);
+            // ... and Phi^T Phi of step t+1, a step early: its reduce buffer was step t-1's, free once post(t-1) is done.  Phi(t+1)
+            // itself comes from this step's posterior (vjf_phi_next_kernel, behind "rows written" and post(t-1): both are implied
+            // by the operand kernel in front of it in this stream; the rows it overwrites were last read by step t-1's Phi^T dx Gram)
+            if (c->phi_in_k1) {
+                hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)phic, c->phi_count, (const unsigned*)pdone, post_before, stw);
+            } else {
+                VjfPhiNextArgs pn{};
+                pn.state = c->state; pn.mu_t = mu + (size_t)t * sz; pn.lv_t = lv + (size_t)t * sz;
+                pn.eps_s = eps + (size_t)(t + 1) * 2 * sz; pn.u = u ? u + (size_t)(t + 1) * su : nullptr;
+                pn.E = (float*)(c->ws + (((t + 1) & 1) ? c->cv.E2 : c->cv.E)); pn.B = B;
+                const size_t lds = ((size_t)P.n * P.dxu + P.n + (size_t)P.dxu * VJF_LDT) * 4;
+                hipLaunchKernelGGL(vjf_phi_next_kernel, dim3((B + 15) / 16), dim3(256), lds, sb, P, pn);
+            }
             if ((rc = launch_gram(c, B, 0, ne, 0u, rede[(t + 1) & 1], sb, nullptr, (t + 1) & 1, nullptr, 0, false, statc, 1u))) return rc;
             c->stat_count += nred;
         }

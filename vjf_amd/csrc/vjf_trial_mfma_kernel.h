@@ -295,8 +295,13 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     if (fwd) for (int e = tid; e < nb * dz; e += VJF_K1M_THREADS) {                 // coalesced posterior stores
         const int b = e / dz, j = e - b * dz;
-        A.mu_t[(size_t)(b0 + b) * dz + j] = s_mu[j * LD + b];
-        A.lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
+        if (fused3) {                                                  // (taken by a kernel on another stream behind "rows written")
+            __hip_atomic_store(A.mu_t + (size_t)(b0 + b) * dz + j, s_mu[j * LD + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.lv_t + (size_t)(b0 + b) * dz + j, s_lv[j * LD + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            A.mu_t[(size_t)(b0 + b) * dz + j] = s_mu[j * LD + b];
+            A.lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
+        }
     }
     __syncthreads();
     if (fused3) {
@@ -669,6 +674,45 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(AA.fwd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Phi of the next step from this step's posterior, for the statistics stream (vjf_filter_seq, one-launch schedule): the Phi^T Phi
+// Gram of step t+1 then runs a step early.  xs' = mu_t + eps_s' e^{lv_t/2}, Phi = exp(-|xu' - c_k|^2 / (2 w_k^2)) with exactly the
+// operations, in the order, of stages 0 / 1 of the trial kernel (which forms the same Phi for itself in the next launch): the
+// same bits.  16 trials per workgroup; writes the Phi columns of the next parity's E rows.
+struct VjfPhiNextArgs {
+    const float* state; const float* mu_t; const float* lv_t; const float* eps_s; const float* u; float* E; int B;
+};
+__global__ __launch_bounds__(256) void vjf_phi_next_kernel(VjfPlan P, VjfPhiNextArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = P.n, dz = P.dz, du = P.du, dxu = P.dxu, b0 = blockIdx.x * 16, nb = min(16, A.B - b0);
+    constexpr int LD = VJF_LDT;
+    float* s_cen = smem;                           // n * dxu
+    float* s_iw = s_cen + n * dxu;                 // n
+    float* s_xn = s_iw + n;                        // dxu x 17
+    const float* S = A.state;
+    const float* cen = S + P.off[VJF_SLOT_CENTROID];
+    const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
+    for (int e = tid; e < n * dxu; e += 256) s_cen[e] = cen[e];
+    for (int e = tid; e < n; e += 256) { const float w = expf(lw[e]); s_iw[e] = -0.5f / (w * w); }
+    for (int e = tid; e < 16 * dxu; e += 256) {
+        const int c = e >> 4, b = e & 15;
+        const size_t g = (size_t)(b0 + (b < nb ? b : 0));
+        float v;
+        if (c < dz) v = fmaf(A.eps_s[g * dz + c], expf(0.5f * A.lv_t[g * dz + c]), A.mu_t[g * dz + c]);
+        else v = A.u[g * du + (c - dz)];
+        s_xn[c * LD + b] = v;
+    }
+    __syncthreads();
+    for (int b = wave; b < nb; b += 4) {
+        float* erow = A.E + (size_t)(b0 + b) * P.ldE;
+        for (int k = lane; k < n; k += 64) {
+            float d2 = 0.f;
+            for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
+            erow[k] = expf(d2 * s_iw[k]);
+        }
     }
 }
 
