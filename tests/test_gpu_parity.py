@@ -405,8 +405,8 @@ def test_sharded_path_one_rank_nccl(vjf, monkeypatch, persistent):
     load_fixture_state(m1, z, "s0")
     load_fixture_state(m2, z, "s0")
     y, eps = torch.tensor(z["y"][:4]), torch.tensor(z["eps"][:4])
-    if persistent:                                           # the persistent RLS kernels beside the communicators (opt-in there)
-        monkeypatch.setenv("VJF_PERSISTENT_DIST", "1")
+    if not persistent:                                       # per-step launches instead of the persistent RLS kernels
+        monkeypatch.setenv("VJF_NO_PERSISTENT_DIST", "1")
     m1.set_overlap(False)
     o1 = m1.filter_sequence(y, None, None, eps=eps)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

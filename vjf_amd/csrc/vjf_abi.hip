@@ -399,7 +399,7 @@ int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world)
     int e = nccl().comm_init_rank(&cb, world, ids[1], rank);
     if (e != 0) { (void)nccl().comm_destroy(ca); return fail(-110, "ncclCommInitRank failed: %s", nccl().err ? nccl().err(e) : "rccl error"); }
     ctx->comm_a = ca; ctx->comm_b = cb; ctx->world = world;
-    if (getenv("VJF_PERSISTENT_DIST")) {
+    if (getenv("VJF_NO_PERSISTENT_DIST") == nullptr) {
         // The persistent RLS kernels must never meet a collective library that still has something to set up (a lazy connect may
         // synchronise the device, which kernels that stay resident for a whole sequence turn into a time-out): run the two
         // all-reduces of a step once now, on the streams and with the sizes the sequence uses (the buffers are scratch).
@@ -417,6 +417,14 @@ int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world)
         VJF_NCCL(nccl().all_reduce(rede + P.red_G, rede + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum, ctx->comm_b, ctx->stream2));
         VJF_HIP(hipStreamSynchronize(ctx->stream));
         VJF_HIP(hipStreamSynchronize(ctx->stream2));
+        // every rank must take the same route through vjf_filter_seq (the persistent one ends with an all-reduce of a flag): the
+        // ranks agree on the outcome of the stream probe -- if it failed anywhere, nobody uses the persistent kernels
+        float bad = ctx->queues_ok ? 0.f : 1.f;
+        VJF_HIP(hipMemcpyAsync(redg, &bad, 4, hipMemcpyHostToDevice, ctx->stream));
+        VJF_NCCL(nccl().all_reduce(redg, redg, 1, kNcclFloat, kNcclSum, ctx->comm_a, ctx->stream));
+        VJF_HIP(hipMemcpyAsync(&bad, redg, 4, hipMemcpyDeviceToHost, ctx->stream));
+        VJF_HIP(hipStreamSynchronize(ctx->stream));
+        if (bad != 0.f) ctx->queues_ok = false;
     }
     return 0;
 }
@@ -799,17 +807,17 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
 int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
                        const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
     // (single rank only: a collective library may synchronise the device when it sets something up lazily, which kernels that
-    //  stay resident for the whole sequence would turn into a time-out; VJF_PERSISTENT_DIST=1 tries it anyway)
+    //  stay resident for the whole sequence would turn into a time-out: vjf_comm_init runs the collectives once beforehand)
     if (c->persistent && !c->overlap_serial) { int rc0 = ensure_stream2(c); if (rc0) return rc0; }
-    if (c->persistent && c->queues_ok && !c->overlap_serial && c->mfma_trial && c->post_kernels && c->plan.dz <= 16 && (!c->comm_a || getenv("VJF_PERSISTENT_DIST"))) {
+    if (c->persistent && c->queues_ok && !c->overlap_serial && c->mfma_trial && c->post_kernels && c->plan.dz <= 16 && (!c->comm_a || getenv("VJF_NO_PERSISTENT_DIST") == nullptr)) {
         // The persistent kernels wait (bounded) for kernels the host enqueues while they run.  The runtime multiplexes streams
         // onto a few hardware queues; once in a while a launch of ours is held behind the persistent kernel's queue until that
         // kernel's waits run out (seen under heavy stream churn: ~1 % of sequences, an 80 ms stall).  Such a sequence is not to
         // be used: the state blob is checkpointed first, the status word read back at the end (one host synchronisation per
         // sequence), and on a wait time-out the blob is restored, the hand-off counters are reset and the sequence runs again
-        // with a launch per step -- which does not depend on any kernel staying resident.  Single rank only (with communicators
-        // a re-run would have to be agreed between the ranks: there the per-step launches are the default anyway).
-        const bool guard = !c->comm_a && getenv("VJF_NO_SEQ_GUARD") == nullptr;
+        // with a launch per step -- which does not depend on any kernel staying resident.  With communicators the ranks agree
+        // on it (one more all-reduce, of a flag, per sequence).
+        const bool guard = getenv("VJF_NO_SEQ_GUARD") == nullptr;
         float* backup = (float*)(c->ws + c->cv.backup);
         if (guard) VJF_HIP(hipMemcpyAsync(backup, c->state, (size_t)c->plan.n_state * 4, hipMemcpyDeviceToDevice, c->stream));
         int rc1 = filter_seq_persist(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
@@ -817,7 +825,17 @@ int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         float stf = 0.f;
         VJF_HIP(hipMemcpyAsync(&stf, c->state + c->plan.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, 4, hipMemcpyDeviceToHost, c->stream));
         VJF_HIP(hipStreamSynchronize(c->stream));
-        if (((unsigned)stf & 0x1ff00u) == 0) return 0;
+        float lost = ((unsigned)stf & 0x1ff00u) ? 1.f : 0.f;
+        if (c->comm_a) {
+            // sharded trials: every rank must take the same route -- the sum of the "lost" flags over the ranks (the gradient
+            // reduce buffer is free between sequences)
+            float* scratch = (float*)(c->ws + c->cv.red);
+            VJF_HIP(hipMemcpyAsync(scratch, &lost, 4, hipMemcpyHostToDevice, c->stream));
+            VJF_NCCL(nccl().all_reduce(scratch, scratch, 1, kNcclFloat, kNcclSum, c->comm_a, c->stream));
+            VJF_HIP(hipMemcpyAsync(&lost, scratch, 4, hipMemcpyDeviceToHost, c->stream));
+            VJF_HIP(hipStreamSynchronize(c->stream));
+        }
+        if (lost == 0.f) return 0;
         if (getenv("VJF_VERBOSE")) fprintf(stderr, "vjf: a wait of the persistent sequence timed out (status 0x%x): re-running it with per-step launches\n", (unsigned)stf);
         VJF_HIP(hipStreamSynchronize(c->stream2)); VJF_HIP(hipStreamSynchronize(c->stream3)); VJF_HIP(hipStreamSynchronize(c->stream4));
         VJF_HIP(hipMemcpyAsync(c->state, backup, (size_t)c->plan.n_state * 4, hipMemcpyDeviceToDevice, c->stream));
