@@ -326,7 +326,9 @@ __global__ __launch_bounds__(256) void vjf_prepg_kernel(VjfPlan P, VjfPrepArgs A
             if (in) {
                 float4 o;
                 o.x = fmaf(g[q].x, inv_v, p[q].x); o.y = fmaf(g[q].y, inv_v, p[q].y); o.z = fmaf(g[q].z, inv_v, p[q].z); o.w = fmaf(g[q].w, inv_v, p[q].w);
-                *reinterpret_cast<float4*>(Pm + (size_t)(i0 + row) * n + c4) = o;
+                float* dstp = Pm + (size_t)(i0 + row) * n + c4;
+                if (A.done_count) { vjf_store_wt(dstp, o.x); vjf_store_wt(dstp + 1, o.y); vjf_store_wt(dstp + 2, o.z); vjf_store_wt(dstp + 3, o.w); }
+                else *reinterpret_cast<float4*>(dstp) = o;
             }
         }
     }
@@ -351,10 +353,11 @@ __global__ __launch_bounds__(256) void vjf_prepg_kernel(VjfPlan P, VjfPrepArgs A
         const int r = e >> 4, c = e & 15;
         if (c < dz && i0 + r < n) {
             const float v = ((s_r[r * 17 + c] + s_r[(16 + r) * 17 + c]) + s_r[(32 + r) * 17 + c]) + s_r[(48 + r) * 17 + c];
-            A.gbuf[(size_t)(i0 + r) * dz + c] = v + FDX[(size_t)(i0 + r) * dz + c] * inv_v;
+            const float gv = v + FDX[(size_t)(i0 + r) * dz + c] * inv_v;
+            if (A.done_count) vjf_store_wt(A.gbuf + (size_t)(i0 + r) * dz + c, gv); else A.gbuf[(size_t)(i0 + r) * dz + c] = gv;
         }
     }
-    if (A.done_count) vjf_wg_signal(A.done_count, tid);
+    if (A.done_count) vjf_wg_signal_wt(A.done_count, tid);
 }
 
 // ---------------------------------------------------------------------------------------------

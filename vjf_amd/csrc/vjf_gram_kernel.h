@@ -122,6 +122,7 @@ struct VjfReduceArgs {
 #define VJF_REDUCE_THREADS 1024
 __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(VjfPlan P, VjfReduceArgs A) {
     const int tid = threadIdx.x;
+    const bool wt = A.done_count != nullptr;      // a kernel that is already running takes the sums: write-through stores
     if ((int)blockIdx.x == A.njobs) {
         // RS_N scalars; 32 threads per scalar accumulate strided partials in double, then a fixed xor tree over the 32
         const int sc = (tid >> 5) & 7, l = tid & 31;
@@ -137,9 +138,9 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
             }
             for (; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
             v = vjf_sum32(v);
-            if (l == 0 && ((A.sc_mask >> sc) & 1u)) A.red[P.red_SC + sc] = (float)v;
+            if (l == 0 && ((A.sc_mask >> sc) & 1u)) { if (wt) vjf_store_wt(A.red + P.red_SC + sc, (float)v); else A.red[P.red_SC + sc] = (float)v; }
         }
-        if (A.done_count) vjf_wg_signal(A.done_count, tid);
+        if (A.done_count) vjf_wg_signal_wt(A.done_count, tid);
         return;
     }
     const VjfJob job = A.jobs[A.job0 + blockIdx.x];
@@ -169,16 +170,16 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
             const unsigned km = A.kind0_mask ? A.kind0_mask : 3u;
             if (gr < P.n) {
                 if ((km & 1u) && gc < P.n && gc <= gr) {
-                    A.red[P.red_G + (size_t)gr * P.n + gc] = v;
-                    A.red[P.red_G + (size_t)gc * P.n + gr] = v;
+                    if (wt) { vjf_store_wt(A.red + P.red_G + (size_t)gr * P.n + gc, v); vjf_store_wt(A.red + P.red_G + (size_t)gc * P.n + gr, v); }
+                    else { A.red[P.red_G + (size_t)gr * P.n + gc] = v; A.red[P.red_G + (size_t)gc * P.n + gr] = v; }
                 }
             } else if ((km & 2u) && gr < P.n + P.dz && gc < P.n) {
-                A.red[P.red_FDX + (size_t)gc * P.dz + (gr - P.n)] = v;
+                if (wt) vjf_store_wt(A.red + P.red_FDX + (size_t)gc * P.dz + (gr - P.n), v); else A.red[P.red_FDX + (size_t)gc * P.dz + (gr - P.n)] = v;
             }
         } else {
             if (j < job.ncol_w) A.red[job.dst + (size_t)i * job.ld + j] = v;
             else if (j == job.ncol_w && job.dst_b >= 0) A.red[job.dst_b + i] = v;
         }
     }
-    if (A.done_count) vjf_wg_signal(A.done_count, tid);
+    if (A.done_count) vjf_wg_signal_wt(A.done_count, tid);
 }

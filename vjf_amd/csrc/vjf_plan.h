@@ -187,6 +187,14 @@ __device__ __forceinline__ bool vjf_abort_seen(const float* status) {
     const float f = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return ((unsigned)f & 0x1ff00u) != 0u;
 }
+// The same for a workgroup whose outputs went out as write-through stores (in memory once vmcnt has drained): no L2 write-back
+// (an agent-scope release by every workgroup of a kernel that runs beside the trial kernel costs that kernel microseconds).
+__device__ __forceinline__ void vjf_wg_signal_wt(unsigned* count, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void vjf_store_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // returns false (lane 0 only; the others get true) when the count did not arrive within the bound
 __device__ __forceinline__ bool vjf_wg_wait(const unsigned* count, unsigned target, int tid, const float* status = nullptr) {
     bool there = true;
