@@ -203,6 +203,29 @@ def test_filter_sequence_in_chunks(vjf, monkeypatch):
         assert torch.equal(outs[0][1], outs[k][1])
 
 
+def test_sequences_under_stream_churn(vjf, monkeypatch):
+    """Many contexts created and destroyed in one process, each running chunked sequences (several launches of the persistent
+    RLS kernels back to back): the runtime re-multiplexes streams onto hardware queues, and now and then a launch is held behind
+    a persistent kernel until its bounded waits run out.  The guard in vjf_filter_seq (checkpoint, status read-back, re-run with
+    per-step launches) must make that invisible: every run bit-identical to the first, status clean."""
+    z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
+    y, eps = torch.tensor(z["y"]), torch.tensor(z["eps"])
+    ref = None
+    for rep in range(24):
+        monkeypatch.setenv("VJF_SEQ_CHUNK", ("0", "3", "2")[rep % 3])
+        m = _model_for(vjf, info)
+        load_fixture_state(m, z, "s0")
+        o = m.filter_sequence(y, None, None, eps=eps)
+        assert m.status() == 0, rep
+        if ref is None:
+            ref = (o, m._blob.clone())
+        else:
+            for a, b in zip(ref[0], o):
+                assert torch.equal(a, b), rep
+            assert torch.equal(ref[1], m._blob), rep
+    monkeypatch.delenv("VJF_SEQ_CHUNK", raising=False)
+
+
 def test_filter_sequence_two_stream_equals_one_stream(vjf):
     """vjf_filter_seq's two-stream schedule (RLS chain beside the trial / SGD chain) is a re-ordering of independent
     kernels only: every output and the whole state blob match the one-stream order bit for bit."""
