@@ -972,7 +972,9 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     // fused: ONE trial-kernel launch per step (part 3): it signals "Phi rows written" before the recognition network runs and "all
     // rows written" before it waits for the RLS update; Phi^T Phi is reduced behind the first signal (what the Cholesky loop
     // waits for), Phi^T dx and sum |dx|^2 behind the second (what the operand kernel needs)
-    const bool fused = c->fused_seq && !c->comm_a && (c->ahead_ok || getenv("VJF_FUSED_SEQ"));   // (without the step-ahead Gram it loses)
+    // (without the step-ahead Gram it loses; with communicators it needs it: the early and the late statistics are summed
+    //  over the ranks separately)
+    const bool fused = c->fused_seq && (c->ahead_ok || (getenv("VJF_FUSED_SEQ") && !c->comm_a)) && (!c->comm_a || getenv("VJF_NO_FUSED_DIST") == nullptr);
     unsigned* phic = fl + 53;
     const unsigned npost = (unsigned)(2 * nbl + 1), nblk = (unsigned)trial_blocks(c, B), nred = (unsigned)(fused ? ne : ne + 1),
                    nprep = (unsigned)((P.n + 15) / 16);
@@ -1054,17 +1056,23 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             // sb: Phi^T Phi of this step behind "Phi rows written" (not ahead, or step 0) ...
             if (!ahead || t == 0) {
                 hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)phic, phi_before + nblk, stw);
-                if ((rc = launch_gram(c, B, 0, ne, 0u, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, statc, 1u))) return rc;
+                if ((rc = launch_gram(c, B, 0, ne, 0u, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, c->comm_b ? nullptr : statc, 1u))) return rc;
+                if (c->comm_b) {                                         // sum Phi^T Phi over the ranks, then the count
+                    VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)P.n * P.n, kNcclFloat, kNcclSum, c->comm_b, sb));
+                    hipLaunchKernelGGL(vjf_count_kernel, dim3(1), dim3(64), 0, sb, statc, nred);
+                }
             }
             // ... Phi^T dx and sum |dx|^2 behind "all rows written" ...
             hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
             if ((rc = launch_gram(c, B, c->fdx_job0, ne - c->fdx_job0, kScRls, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, nullptr, 2u))) return rc;
+            if (c->comm_b)                                               // sum [Phi^T dx | sums] over the ranks (the operand kernel follows in this stream)
+                VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_FDX, rede[t & 1] + P.red_FDX, (size_t)(P.red_len - P.red_FDX), kNcclFloat, kNcclSum, c->comm_b, sb));
         } else {
         // sb: statistics of step t as soon as its forward half is done ...
         hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
         if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, c->comm_b ? nullptr : statc))) return rc;
         }
-        if (c->comm_b) {                                                 // trials are sharded over ranks: sum [G | FDX | sums]
+        if (c->comm_b && !fused) {                                       // trials are sharded over ranks: sum [G | FDX | sums]
             VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum,
                                        c->comm_b, sb));
             hipLaunchKernelGGL(vjf_count_kernel, dim3(1), dim3(64), 0, sb, statc, nred);
@@ -1089,7 +1097,11 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
                 const size_t lds = ((size_t)P.n * P.dxu + P.n + (size_t)P.dxu * VJF_LDT) * 4;
                 hipLaunchKernelGGL(vjf_phi_next_kernel, dim3((B + 15) / 16), dim3(256), lds, sb, P, pn);
             }
-            if ((rc = launch_gram(c, B, 0, ne, 0u, rede[(t + 1) & 1], sb, nullptr, (t + 1) & 1, nullptr, 0, false, statc, 1u))) return rc;
+            if ((rc = launch_gram(c, B, 0, ne, 0u, rede[(t + 1) & 1], sb, nullptr, (t + 1) & 1, nullptr, 0, false, c->comm_b ? nullptr : statc, 1u))) return rc;
+            if (c->comm_b) {
+                VJF_NCCL(nccl().all_reduce(rede[(t + 1) & 1] + P.red_G, rede[(t + 1) & 1] + P.red_G, (size_t)P.n * P.n, kNcclFloat, kNcclSum, c->comm_b, sb));
+                hipLaunchKernelGGL(vjf_count_kernel, dim3(1), dim3(64), 0, sb, statc, nred);
+            }
             c->stat_count += nred;
         }
         // sa: backward half(t); it waits in-kernel for post(t-1), whose workgroups are resident
