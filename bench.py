@@ -226,7 +226,9 @@ def main():
         kstats = None
         try:                                                    # per-kernel averages of the committed rocprofv3 --stats run of this build
             import csv
-            ks = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_kernel_stats.csv")))
+            import re
+            ks = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_kernel_stats.csv")),
+                        key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])     # r01_v10 after r01_v9
             rows = list(csv.DictReader(open(ks[-1])))
             # (one operand kernel / Cholesky / serial kernel per step; the persistent RLS kernels are one launch per sequence)
             steps_in_profile = max(int(r["Calls"]) for r in rows if "prepg" in r["Name"] or "chol" in r["Name"] or "serial" in r["Name"])
