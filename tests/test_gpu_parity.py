@@ -203,6 +203,28 @@ def test_filter_sequence_in_chunks(vjf, monkeypatch):
         assert torch.equal(outs[0][1], outs[k][1])
 
 
+def test_sequence_guard_recovers_from_injected_timeout(vjf, monkeypatch):
+    """VJF_DEBUG_INJECT=k makes the persistent Cholesky loop report a wait time-out at step k: vjf_filter_seq must restore the
+    checkpointed state, re-run the sequence with per-step launches and deliver exactly what an undisturbed run delivers."""
+    z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
+    y, eps = torch.tensor(z["y"]), torch.tensor(z["eps"])
+    outs = []
+    for inj in (None, "0", "3"):
+        if inj is not None:
+            monkeypatch.setenv("VJF_DEBUG_INJECT", inj)
+        m = _model_for(vjf, info)
+        load_fixture_state(m, z, "s0")
+        o = m.filter_sequence(y, None, None, eps=eps)
+        assert m.status() == 0
+        o2 = m.filter_sequence(y, None, None, eps=eps)       # the context is on the per-step launches now: still the same results
+        outs.append((o + o2, m._blob.clone()))
+    monkeypatch.delenv("VJF_DEBUG_INJECT", raising=False)
+    for k in (1, 2):
+        for a, b in zip(outs[0][0], outs[k][0]):
+            assert torch.equal(a, b)
+        assert torch.equal(outs[0][1], outs[k][1])
+
+
 def test_sequences_under_stream_churn(vjf, monkeypatch):
     """Many contexts created and destroyed in one process, each running chunked sequences (several launches of the persistent
     RLS kernels back to back): the runtime re-multiplexes streams onto hardware queues, and now and then a launch is held behind

@@ -989,6 +989,7 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         a.wait_count = pdone; a.wait_target = c->post_count; a.wait_stride = npost;
         a.stat_count = statc; a.stat_target = c->stat_count + nred; a.stat_stride = nred;
         a.nsteps = T; a.step0 = 0;
+        if (const char* inj = getenv("VJF_DEBUG_INJECT")) { const int k = atoi(inj); if (k >= 0 && k < T) a.inject_epoch = c->epoch + 1 + (unsigned)k; }
         VjfPostArgs pa{};
         pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.lscr = a.lscr; pa.flags = fl; pa.epoch = a.epoch; pa.status = stw;
         pa.k1_done = k1done; pa.k1_target = c->k1_count + nblk; pa.k1_stride = nblk;

@@ -636,6 +636,7 @@ struct VjfCholArgs {
     // sigma arrives).  Step `it`: epoch + it, statistics in red (even step0 + it) or red2 (odd), ready when *stat_count has
     // reached stat_target + it * stat_stride; sigma when *wait_count has reached wait_target + it * wait_stride.
     int nsteps, step0;
+    unsigned inject_epoch; // test hook (VJF_DEBUG_INJECT=k): at this epoch the statistics wait is reported as timed out
     const float* red2;
     const unsigned* stat_count; unsigned stat_target, stat_stride, wait_stride;
     int no_triclean;       // post mode: the caller clears the zero halves of w_chol / w_pchol itself (vjf_triclean_kernel)
@@ -724,7 +725,10 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
     }
     if (tid == 0) s_flag[0] = 1;
     __syncthreads();
-    if (A.stat_count && !vjf_wg_wait(A.stat_count, it_stat_target, tid, SC + VJF_SC_STATUS)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_STATS); *s_dead = 1; }
+    if (A.stat_count && (!vjf_wg_wait(A.stat_count, it_stat_target, tid, SC + VJF_SC_STATUS) || (A.inject_epoch && tid == 0 && it_epoch == A.inject_epoch))) {
+        vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_STATS);
+        *s_dead = 1;
+    }
 
     if (!warm) {
         // ---- load the lower block triangle of P_new (vjf_prep_kernel already added Phi^T Phi / v).  Wavefront 0 takes the
