@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
         }
         if (A.run_word) {
             bool there = false;
-            for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+            for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
                 const unsigned r = __hip_atomic_load(A.run_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned q = __hip_atomic_load(A.start_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int)(r - A.run_epoch) >= 0 && (int)(q - A.start_target) >= 0) { there = true; break; }
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void vjf_prepg_kernel(VjfPlan P, VjfPrepArgs A
     if (A.wait_count) {
         if (tid == 0) {
             bool there = false;
-            for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+            for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
                 if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.wait_target) >= 0) { there = true; break; }
                 __builtin_amdgcn_s_sleep(4);
             }

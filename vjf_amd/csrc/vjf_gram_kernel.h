@@ -38,7 +38,7 @@ __global__ __launch_bounds__(VJF_GRAM_THREADS) void vjf_gram_kernel(VjfPlan P, V
     if (A.wait_count) {
         if (threadIdx.x == 0) {
             bool there = false;
-            for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+            for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
                 if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.wait_target) >= 0) { there = true; break; }
                 __builtin_amdgcn_s_sleep(4);
             }

@@ -17,7 +17,7 @@
 #include "vjf_trial_mfma_kernel.h"   // vjf_f32x4
 
 // bound of every in-kernel wait (each poll is an L2 round trip + s_sleep: ~0.5 s in all); time-out -> status bit, never a hang
-#define VJF_SPIN_LIMIT (1u << 19)
+#define VJF_SPIN_LIMIT VJF_WAIT_SPINS
 #define VJF_POST_THREADS 512
 #define VJF_POST_KPAR 4                // wavefronts = 2 row tiles x 4 interleaved block sums
 #define VJF_POST_LDB 33               // padded leading dimension of a 32x32 block in LDS

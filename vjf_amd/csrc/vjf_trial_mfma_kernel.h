@@ -392,7 +392,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         // start once that kernel's workgroups are resident (vjf_prep_kernel's last workgroup checks), so the wait cannot starve it
         if (tid == 0) {
             bool there = false;
-            for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+            for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
                 if ((int)(__hip_atomic_load(AA.rls_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - AA.rls_target) >= 0) { there = true; break; }
                 if ((spins & 255u) == 255u && vjf_abort_seen(A.state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS)) break;
                 __builtin_amdgcn_s_sleep(2);
