@@ -224,7 +224,7 @@ struct vjf_ctx {
     unsigned phi_count;    // host mirror of the trial kernel's "Phi rows written" count (part 3)
     bool fused_seq;        // vjf_filter_seq with one trial-kernel launch per step (default; VJF_NO_FUSED_SEQ: a forward and a backward half)
     unsigned epoch_k1;     // diagnostic: epoch of the step whose backward half is launched next (ring entry of its stamps)
-    bool queues_ok;        // the four streams of vjf_filter_seq run beside each other (probed when they are created)
+    bool queues_ok;        // the caller's stream, stream2 and stream3 run beside each other (probed when the streams are created)
     bool persistent;       // vjf_filter_seq: the RLS chain as persistent kernels (default; VJF_NO_PERSISTENT turns it off)
     unsigned start_count;  // host mirror of the post kernel's "workgroups started" count
     unsigned stat_count, prep_count;   // host mirrors of the "statistics reduced" / "operand rows done" workgroup counts
