@@ -167,8 +167,10 @@ def main():
         torch.cuda.synchronize()
 
     # warm-up (untimed): also sizes the context and, for N > 1, the RCCL communicator
-    mu, lv, _ = model.filter_sequence(y[:W], eps=eps[:W])
-    q = vjf_amd.Gaussian(mu[-1], lv[-1])
+    q = None
+    if W > 0:
+        mu, lv, _ = model.filter_sequence(y[:W], eps=eps[:W])
+        q = vjf_amd.Gaussian(mu[-1], lv[-1])
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
