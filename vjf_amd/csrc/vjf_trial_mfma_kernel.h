@@ -89,6 +89,7 @@ struct VjfTrialMfmaArgs {
     float* next_E; const float* next_eps_s; const float* next_u; int own_phi;
     unsigned* phi_done;    // part 3: += 1 per workgroup once the Phi columns of its E rows are in memory (the Gram of Phi^T Phi starts
                            //   behind it, before the recognition network has run)
+    int late_prio;         // > 0: the last late_prio workgroups of the grid raise their wavefronts' priority (see the kernel)
     int part;              // 0: whole step; 1: forward half (features, recognition, E / ACT rows, posterior);
                            // 2: backward half (predictive mean / variance, losses, backward, DEL rows) -- reloads the
                            //    forward half's rows, so that it can run after the RLS update of the previous step while
@@ -118,6 +119,10 @@ static inline size_t vjf_trial_mfma_lds_floats(const VjfPlan& P) {
 
 __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrialMfmaArgs AA) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // The last workgroups of the grid are the ones that find no CU of their own (16 CUs are taken by the RLS kernels): they run
+    // beside an older workgroup whose wavefronts win the issue arbitration, and finish 10 us after everybody else.  A raised
+    // priority lets the two share the CU evenly: the pair ends earlier than its slower half did.
+    if (AA.late_prio > 0 && (int)blockIdx.x >= (int)gridDim.x - AA.late_prio) __builtin_amdgcn_s_setprio(2);
     const VjfTrialArgs& A = AA.t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * 16;
