@@ -122,7 +122,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     // The last workgroups of the grid are the ones that find no CU of their own (16 CUs are taken by the RLS kernels): they run
     // beside an older workgroup whose wavefronts win the issue arbitration, and finish 10 us after everybody else.  A raised
     // priority lets the two share the CU evenly: the pair ends earlier than its slower half did.
-    if (AA.late_prio > 0 && (int)blockIdx.x >= (int)gridDim.x - AA.late_prio) __builtin_amdgcn_s_setprio(2);
+    if (AA.late_prio > 0 && (int)blockIdx.x >= (int)gridDim.x - AA.late_prio) __builtin_amdgcn_s_setprio(3);
     const VjfTrialArgs& A = AA.t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * 16;
