@@ -1,0 +1,193 @@
+"""BASELINE.json configs at (or near) their full sizes on the GPU, through the entry points the bench times.
+
+  * configs[1] (B): `filter_sequence` at B = 4096 for T = 50 steps -- the schedule and the size `bench.py` runs -- bitwise
+    against stepwise `filter`, and every step against the fp64 oracle (vjf/model.py:179-221);
+  * configs[4] (E): n_rbf = 1000 (32 block columns of the multi-launch RLS), d_z = 64, d_y = 512, hidden [512, 512];
+  * configs[3] (D): B = 32768 on one GPU, and the 8-shard sum property through vjf_filter_local / vjf_filter_global;
+  * configs[2] (C): Poisson, d_y = 200 at B = 4096 through `filter_sequence`.
+Tolerances as in tests/test_gpu_parity.py (fp32 device path against the fp64 oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vjf_oracle as orc
+from tests.helpers import load_oracle_state, state_close
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, **kw):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), **kw)
+
+
+@pytest.fixture(scope="module")
+def vjf():
+    import vjf_amd
+    assert torch.cuda.is_available()
+    return vjf_amd
+
+
+def _data(c, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    if c["lik"] == "poisson":
+        y = torch.poisson(torch.exp(0.5 * torch.randn(T, c["B"], c["dy"], generator=g) - 0.5), generator=g)
+    else:
+        y = torch.randn(T, c["B"], c["dy"], generator=g)
+    eps = torch.randn(T, 2, c["B"], c["dz"], generator=g)
+    return y, eps
+
+
+def _model(vjf, c, lr=1e-3):
+    m = vjf.VJF.make_model(c["dy"], c["dz"], 0, c["n"], c["hidden"], likelihood=c["lik"], lr=lr)
+    if c["dz"] >= 32:      # the default RBF init underflows every feature at d_z = 64: SURVEY 8d's init
+        r = float(np.sqrt(c["dz"]))
+        m.transition.velocity.feature.centroid.uniform_(-r, r)
+        m.transition.velocity.feature.logwidth.fill_(float(np.log(r)))
+    return m
+
+
+CFG_B = dict(B=4096, dz=10, dy=50, n=200, hidden=[128], lik="gaussian")
+CFG_C = dict(B=4096, dz=10, dy=200, n=200, hidden=[128], lik="poisson")
+CFG_D1 = dict(B=32768, dz=10, dy=50, n=200, hidden=[128], lik="gaussian")
+CFG_E = dict(B=64, dz=64, dy=512, n=1000, hidden=[512, 512], lik="gaussian")
+
+
+@pytest.mark.parametrize("cfg", [CFG_B, CFG_C], ids=["configB", "configC"])
+def test_sequence_at_bench_size_bitwise_and_oracle(vjf, cfg):
+    """The benchmarked entry point at the benchmarked size (256 trial tiles, every hand-off of the schedule under its real
+    workgroup count): (1) `filter_sequence` == stepwise `filter`, bit for bit, outputs and state blob; (2) two chunks == one
+    piece; (3) every step's posterior and loss terms, and the final state, against the fp64 oracle."""
+    T = 50 if cfg is CFG_B else 12
+    torch.manual_seed(11)
+    m_seq = _model(vjf, cfg)
+    torch.manual_seed(11)
+    m_stp = _model(vjf, cfg)
+    torch.manual_seed(11)
+    m_chk = _model(vjf, cfg)
+    s = load_oracle_state(m_seq, np.float64)
+    y, eps = _data(cfg, T, 21)
+    yd, ed = y.cuda(), eps.cuda()
+    mu, lv, loss = m_seq.filter_sequence(yd, eps=ed)
+    assert m_seq.status() == 0
+    k = T // 2 + 1
+    mu1, lv1, l1 = m_chk.filter_sequence(yd[:k], eps=ed[:k])
+    mu2, lv2, l2 = m_chk.filter_sequence(yd[k:], qs=vjf.Gaussian(mu1[-1], lv1[-1]), eps=ed[k:])
+    assert torch.equal(torch.cat([mu1, mu2]), mu) and torch.equal(torch.cat([lv1, lv2]), lv) and torch.equal(torch.cat([l1, l2]), loss)
+    assert torch.equal(m_chk._blob, m_seq._blob)
+    q = None
+    nstep = min(T, 12)                                          # (stepwise calls: a prefix is enough for the bitwise claim)
+    for t in range(nstep):
+        q, l, *c = m_stp.filter(yd[t], None, q, verbose=True, eps=(ed[t, 0], ed[t, 1]))
+        assert torch.equal(q.mean, mu[t]) and torch.equal(q.logvar, lv[t]), t
+        assert torch.equal(torch.stack([l, *c]), loss[t]), t
+    om, ol = None, None
+    for t in range(T):
+        o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
+        om, ol = o.mu_t, o.lv_t
+        close(mu[t], o.mu_t, rtol=5e-5, atol=5e-5)
+        close(lv[t], o.lv_t, rtol=5e-5, atol=5e-5)
+        close(loss[t], [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
+    close(m_seq.transition.logvar, s.tr_logvar, rtol=0, atol=5e-5)
+    state_close(m_seq, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3)
+
+
+def test_config_E_full_width(vjf):
+    """configs[4]: RBF(1000) = 32 block columns of the chip-wide RLS, d_z = 64, d_y = 512, hidden [512, 512]; 2 steps and a
+    2-step sequence against the oracle, then a precision matrix that fails in block column 20 (state left as it was)."""
+    c = CFG_E
+    torch.manual_seed(12)
+    m = _model(vjf, c)
+    s = load_oracle_state(m, np.float64)
+    T = 4
+    y, eps = _data(c, T, 22)
+    q, om, ol = None, None, None
+    for t in range(2):
+        q, loss, *comp = m.filter(y[t], None, q, verbose=True, eps=(eps[t, 0], eps[t, 1]))
+        o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
+        om, ol = o.mu_t, o.lv_t
+        close(q.mean, o.mu_t, rtol=5e-5, atol=5e-5)
+        close(q.logvar, o.lv_t, rtol=5e-5, atol=5e-5)
+        close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
+    mu, lv, ls = m.filter_sequence(y[2:], qs=q, eps=eps[2:])
+    for t in range(2, T):
+        o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
+        om, ol = o.mu_t, o.lv_t
+        close(mu[t - 2], o.mu_t, rtol=1e-4, atol=1e-4)
+        close(ls[t - 2], [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-4, atol=1e-4)
+    state_close(m, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3, rls_atol=5e-5)
+    assert m.status() == 0
+    # RLS failure at 32 block columns
+    lr = m.transition.velocity
+    n = c["n"]
+    with torch.no_grad():
+        P = lr.w_precision.clone()
+        P[640:, 640:] -= 1e7 * torch.eye(n - 640, device=P.device)
+        lr.w_precision.copy_(P)
+    keep = {k: getattr(lr, k).clone() for k in ("w_mean", "w_chol", "w_pchol")}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.filter(y[0], eps=(eps[0, 0], eps[0, 1]))
+    assert m.status() & 8
+    for k2 in keep:
+        assert torch.equal(getattr(lr, k2), keep[k2]), k2
+
+
+def test_config_D_one_gpu_and_shard_sum(vjf):
+    """configs[3]: 32768 trials.  (1) all of them on one GPU, two steps against the oracle (single step and sequence entry
+    points); (2) the 8-shard protocol of the multi-GPU path on one device: eight `vjf_filter_local` calls of 4096 trials, their
+    reduce buffers summed (the all-reduce), one `vjf_filter_global` with B_total = 32768 -- same posterior bits, same loss and
+    state up to summation order."""
+    from vjf_amd import _native as N
+    c = CFG_D1
+    B, dz = c["B"], c["dz"]
+    torch.manual_seed(13)
+    m = _model(vjf, c, lr=1e-4)
+    torch.manual_seed(13)
+    m_sh = _model(vjf, c, lr=1e-4)
+    torch.manual_seed(13)
+    m_seq = _model(vjf, c, lr=1e-4)
+    s = load_oracle_state(m, np.float64)
+    y, eps = _data(c, 2, 23)
+    yd, ed = y.cuda(), eps.cuda()
+    q, om, ol = None, None, None
+    outs = []
+    for t in range(2):
+        q, loss, *comp = m.filter(yd[t], None, q, verbose=True, eps=(ed[t, 0], ed[t, 1]))
+        o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
+        om, ol = o.mu_t, o.lv_t
+        close(q.mean, o.mu_t, rtol=5e-5, atol=5e-5)
+        close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
+        outs.append((q.mean.clone(), loss.clone()))
+    state_close(m, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3)
+    mu, lv, ls = m_seq.filter_sequence(yd, eps=ed)
+    assert torch.equal(mu[1], outs[1][0]) and torch.equal(ls[1, 0], outs[1][1])
+    assert torch.equal(m_seq._blob, m._blob) and m_seq.status() == 0
+    # (2) eight shards
+    m_sh._ensure_ctx(B // 8)
+    L, ctx = m_sh._backend(), m_sh._ctx
+    flags = N.FLAG_SGD | N.FLAG_UPDATE
+    h = B // 8
+    mu_s = torch.empty(B, dz, device="cuda"); lv_s = torch.empty(B, dz, device="cuda"); loss4 = torch.empty(4, device="cuda")
+    acc = None
+    for k in range(8):
+        a, b = k * h, (k + 1) * h
+        N.check(L.vjf_filter_local(ctx, h, N.ptr(yd[0, a:b]), None, None, None, N.ptr(ed[0, 0, a:b]), N.ptr(ed[0, 1, a:b]),
+                                   N.ptr(mu_s[a:b]), N.ptr(lv_s[a:b]), flags))
+        acc = m_sh._reduce.clone() if acc is None else acc + m_sh._reduce
+    m_sh._reduce.copy_(acc)
+    N.check(L.vjf_filter_global(ctx, B, N.ptr(loss4), flags))
+    s_sh = load_oracle_state(_fresh(vjf, c), np.float64)
+    o = orc.filter_step(s_sh, y[0].numpy(), None, None, None, eps[0, 0].numpy(), eps[0, 1].numpy())
+    close(mu_s, o.mu_t, rtol=5e-5, atol=5e-5)
+    close(loss4, [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
+    state_close(m_sh, s_sh, rtol=5e-4, atol=5e-5, rls_rtol=5e-3)
+    close(mu_s, outs[0][0], rtol=1e-5, atol=1e-5)            # per-trial work does not depend on the shard
+    close(loss4[0], outs[0][1], rtol=1e-5)
+
+
+def _fresh(vjf, c):
+    torch.manual_seed(13)
+    return _model(vjf, c, lr=1e-4)
