@@ -16,6 +16,7 @@
 #include "../../include/vjf_hip.h"
 #include "vjf_chol_kernel.h"
 #include "vjf_gram_kernel.h"
+#include "vjf_mega_kernel.h"
 #include "vjf_ops_kernels.h"
 #include "vjf_plan.h"
 #include "vjf_post_kernel.h"
@@ -149,8 +150,42 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
     grad(P.colD_dpy, P.dy, P.colA_xt, P.dz, VJF_SLOT_DEC_W, VJF_SLOT_DEC_B);
 }
 
+// ---- the one-launch route (vjf_mega_kernel.h): which plans it serves and how the grid's workgroups are dealt to its roles
+constexpr size_t kMegaLds = kMaxLds - 512;             // dynamic LDS of every workgroup of the launch (one workgroup per CU)
+constexpr int kMegaMaxTrialWg = 256, kMegaMaxGramWg = 64;
+struct MegaShape { int n_rls, n_trial, n_gram, n_prep, n_sgd, ntiles, gram_rows; };
+
+bool mega_plan_ok(const VjfPlan& P) {
+    const int nbl = (P.n + 31) / 32;
+    if (!vjf_chol_lds_ok(P) || P.dz > 16 || nbl > VJF_CHOL_MAXBLK) return false;          // LDS Cholesky loop + y / W and inverse loops
+    if ((size_t)(nbl * (nbl + 1) / 2 + nbl) * 1024 * 4 + (size_t)nbl * 32 * 16 * 4 + 768 > kMegaLds) return false;   // vjf_chol_loop<16>
+    if (vjf_post_lds_bytes(P) > kMegaLds) return false;
+    if ((size_t)vjf_mega_trial_lds(P).total * 4 > kMegaLds) return false;                 // 32 trials' working set
+    if (vjf_mega_gram_lds_floats(P) * 4 > kMegaLds || vjf_mega_prep_lds_floats(P) * 4 > kMegaLds) return false;
+    if (P.dxu > 3 * P.dz) return false;                                                  // xs' of the next step parks in 3 dz rows
+    if (nbl * (nbl + 1) / 2 > VJF_MG_WAVES * VJF_MG_MAXQ) return false;
+    return true;
+}
+
+bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
+    const int nbl = (P.n + 31) / 32;
+    m->n_rls = 2 + 2 * nbl;
+    m->n_prep = (P.n + 15) / 16;
+    m->n_sgd = (P.train_len + VJF_MG_THREADS - 1) / VJF_MG_THREADS;
+    if (m->n_sgd > 32) m->n_sgd = 32;
+    m->ntiles = (B + VJF_MG_TR - 1) / VJF_MG_TR;
+    m->n_gram = (B + VJF_MG_GROWS - 1) / VJF_MG_GROWS;
+    if (m->n_gram > kMegaMaxGramWg) m->n_gram = kMegaMaxGramWg;
+    const int avail = ncu - m->n_rls - m->n_gram - m->n_prep - m->n_sgd;
+    if (avail < 1) return false;
+    m->n_trial = m->ntiles < avail ? m->ntiles : avail;
+    if (m->n_trial > kMegaMaxTrialWg) m->n_trial = kMegaMaxTrialWg;
+    m->gram_rows = ((B + m->n_gram - 1) / m->n_gram + 1) & ~1;
+    return true;
+}
+
 struct Carve {
-    size_t backup; size_t pscr; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -174,8 +209,15 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.post = take((size_t)((P.n + 31) / 32) * 1024 * 4 + VJF_RESID_BLOCKS * 8 + 64);   // Dinv blocks | resid partials | ok flag
     c.flags = take(256);                                   // column flags of the Cholesky -> post hand-off (a block of their own)
     c.lscr = take((size_t)P.n * P.n * 4);                  // L, column by column, from the Cholesky kernel to the post kernel
-    c.backup = take((size_t)P.n_state * 4);                 // the state blob as it was when a persistent sequence started
     c.pscr = take((size_t)(VJF_CHOL_MAXBLK * (VJF_CHOL_MAXBLK + 1) / 2) * 1024 * 4);   // lower blocks of P, from one Cholesky kernel to the next
+    if (mega_plan_ok(P)) {                                 // slabs of the one-launch route, sized for the largest role counts
+        const int nbl = (P.n + 31) / 32;
+        c.mg_early = take((size_t)2 * kMegaMaxTrialWg * ((size_t)P.n * 16 + 8) * 4);   // (two sets: even / odd steps)
+        c.mg_late = take((size_t)kMegaMaxTrialWg * ((size_t)P.train_len + 8) * 4);
+        c.mg_gslab = take((size_t)kMegaMaxGramWg * (nbl * (nbl + 1) / 2) * 1024 * 4);
+        c.mg_cnt = take((size_t)MG_C_WORDS * 4);
+        c.mg_stamps = take(32 * 16 * 8);
+    }
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
     c.total = o;
@@ -202,45 +244,29 @@ struct vjf_ctx {
     Carve cv;
     int njobs;
     size_t lds_k2;
-    bool post_kernels;     // RLS tail (inverse, solve, residual) on many CUs after the Cholesky kernel
+    bool post_kernels;     // RLS tail (inverse, solve, residual) on many CUs beside / after the Cholesky kernel
     size_t lds_post;
-    bool mfma_trial;       // 16 trials' working set fits LDS: matrix-core trial kernel
+    bool mfma_trial;       // 16 trials' working set fits LDS: matrix-core trial kernel of the per-step routes
     size_t lds_k1m;
-    bool stamps;           // diagnostic: record s_memtime phase stamps in the serial kernel
-    bool stamps_keep_overlap;   // ... without forcing vjf_filter_seq into the one-stream order (enable = 2)
-    bool fast_chol;        // n_rbf <= 224: prep kernel + LDS-resident MFMA Cholesky; else the generic serial kernel
+    bool stamps;           // diagnostic: s_memrealtime phase stamps
+    bool stamps_keep_overlap;
+    bool fast_chol;        // n_rbf <= 224: prep kernel + LDS-resident MFMA Cholesky; else the generic serial kernel / multi-launch RLS
     size_t lds_chol;
     int n_ejobs;           // jobs [0, n_ejobs) are the E^T E tiles, the rest gradient tiles
-    bool overlap;          // vjf_filter_seq: RLS chain on a second stream beside the trial / SGD chain
-    bool gate_post;        // experiment: hold the post kernel back until the Cholesky kernel runs (frees 15 CUs for the trial kernel,
-                           // but then the post kernel cannot be placed before the trial kernel has drained: measured slower)
-    bool sb_gates;         // gate kernels on the RLS stream (default) instead of in-kernel waits in its first kernels: workgroups that
-                           // spin inside the Gram / operand kernels cost 7 us per step (A/B on one box: 87.2 vs 80.6 us/step)
-    float* k1_next_E; const float* k1_next_eps; const float* k1_next_u; int k1_own_phi;   // part 3: see VjfTrialMfmaArgs::next_E
-    bool phi_in_k1;        // Phi of the next step by the trial kernel itself (wide observations: measured 85 vs 90 us/step at config C)
-                           // or by vjf_phi_next_kernel on the statistics stream (67.1 vs 67.9 at config B); VJF_PHI_IN_K1=0/1 overrides
-    bool ahead_ok;         // the plan allows the statistics-one-step-ahead variant (centroids staged in LDS, xs' fits its scratch rows)
-    int fdx_job0;          // first E^T E job whose tile row holds dx columns (they are the tail of the E jobs)
-    unsigned phi_count;    // host mirror of the trial kernel's "Phi rows written" count (part 3)
-    bool fused_seq;        // vjf_filter_seq with one trial-kernel launch per step (default; VJF_NO_FUSED_SEQ: a forward and a backward half)
-    unsigned epoch_k1;     // diagnostic: epoch of the step whose backward half is launched next (ring entry of its stamps)
-    bool queues_ok;        // the caller's stream, stream2 and stream3 run beside each other (probed when the streams are created)
-    bool persistent;       // vjf_filter_seq: the RLS chain as persistent kernels (default; VJF_NO_PERSISTENT turns it off)
-    unsigned start_count;  // host mirror of the post kernel's "workgroups started" count
-    unsigned stat_count, prep_count;   // host mirrors of the "statistics reduced" / "operand rows done" workgroup counts
-    bool self_prep;        // vjf_filter_seq: the Cholesky kernel forms P + G/v itself (default; VJF_NO_SELF_PREP turns it off)
-    bool k1_inkernel;      // the trial kernel's backward half waits for post(t-1) itself, behind its reloads (default), instead of
-                           // starting behind a gate kernel (VJF_K1_GATE)
-    bool prepg_inkernel;   // the RLS operand kernel waits for post(t-1) itself instead of behind a gate kernel
-    bool overlap_serial;   // ... same kernels and hand-offs, but enqueued on ONE stream (profilers that serialise kernels)
-    hipStream_t stream2, stream3, stream4;
-    hipEvent_t ev_a, ev_s, ev_c, ev_d;
+    bool overlap;          // 1: single rank -> the one-launch route, ranks -> the three-stream per-step route; 0: one-stream order
+    bool mega_ok;          // the plan fits the one-launch route (vjf_mega_kernel.h)
+    int ncu;               // compute units of the device: the one-launch grid has one workgroup per CU
+    hipStream_t stream2, stream3;
+    hipEvent_t ev_s, ev_c;
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
     unsigned k1_count;     // workgroups of the matrix-core trial kernel (whole step or backward half) launched so far
     unsigned post_count;   // workgroups of the post kernel launched so far
     unsigned fwd_count;    // workgroups of forward halves launched with a completion count
-    void* comm_a; void* comm_b;   // RCCL communicators of the two chains of vjf_filter_seq (null: single rank)
+    unsigned start_count;  // host mirror of the post kernel's "workgroups started" count
+    void* comm_a; void* comm_b;   // RCCL communicators of the two chains of the three-stream route (null: single rank)
     int world;
+    int fake_world;        // test hook (VJF_DEBUG_FAKE_WORLD=k at vjf_comm_init, one-rank communicators): behave as rank 0 of k ranks that
+                           // all hold the same trials -- every all-reduced buffer is multiplied by k and B_total = k B
 };
 
 extern "C" {
@@ -293,7 +319,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
         return fail(-9, "vjf_ctx_create: workspace too small (%lld < %zu bytes)", (long long)workspace_bytes, cv.total);
     const size_t lds_k2 = vjf_serial_lds_floats(P) * 4;
     const bool fast_chol = vjf_chol_lds_ok(P);
-    if (!fast_chol && lds_k2 > kMaxLds - 1024)
+    if (!fast_chol && lds_k2 > kMaxLds - 1024 && P.n <= 32 * VJF_CHOL_MAXBLK)
         return fail(-11, "vjf_ctx_create: n_rbf=%d too large for the single-workgroup RLS kernel", P.n);
     VJF_HIP(hipSetDevice(cfg->device));
     vjf_ctx* c = new (std::nothrow) vjf_ctx();
@@ -306,31 +332,26 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->post_kernels = fast_chol && P.dz <= 16 && c->lds_post <= kMaxLds - 1024;
     // the single-workgroup chain kernels ask for the whole LDS of their compute unit: nothing else (every other kernel of
     // a step uses some LDS) is then placed beside them to share their SIMDs' issue slots and matrix cores
-    // (minus the few static bytes of their wrappers)
     if (fast_chol) c->lds_chol = kMaxLds - 256;
     if (c->post_kernels) c->lds_post = kMaxLds - 256;
     c->lds_k1m = vjf_trial_mfma_lds_floats(P) * 4;
     c->mfma_trial = c->lds_k1m <= kMaxLds - 1024;
     c->n_ejobs = 0;
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
-    c->fdx_job0 = c->n_ejobs;
-    for (int i = 0; i < c->n_ejobs; ++i) if ((jobs[i].ti + 1) * VJF_TILE > P.n) { c->fdx_job0 = i; break; }
-    c->phi_count = 0; c->fused_seq = getenv("VJF_NO_FUSED_SEQ") == nullptr;
-    c->k1_next_E = nullptr; c->k1_next_eps = nullptr; c->k1_next_u = nullptr; c->k1_own_phi = 1;
-    c->phi_in_k1 = getenv("VJF_PHI_IN_K1") ? atoi(getenv("VJF_PHI_IN_K1")) != 0 : P.dy >= P.hmax;
+    c->overlap = true;
+    c->mega_ok = mega_plan_ok(P);
     {
-        const bool compact = P.dy >= P.hmax;
-        c->ahead_ok = (P.n * P.dxu + P.n) <= 2 * (compact ? P.dy : P.hmax) * VJF_LDT && P.dxu <= 3 * P.dz && getenv("VJF_NO_AHEAD") == nullptr;
+        int v = 0;
+        VJF_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device));
+        c->ncu = v;
+        int coop = 0;
+        VJF_HIP(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, cfg->device));
+        if (!coop) c->mega_ok = false;
     }
-    c->overlap = c->fast_chol && c->post_kernels && c->mfma_trial;
-    c->overlap_serial = false; c->gate_post = getenv("VJF_GATE_POST") != nullptr; c->sb_gates = getenv("VJF_SB_INKERNEL_WAIT") == nullptr; c->prepg_inkernel = getenv("VJF_PREPG_INKERNEL") != nullptr;
-    c->k1_inkernel = getenv("VJF_K1_GATE") == nullptr;
-    c->self_prep = getenv("VJF_SELF_PREP") != nullptr;
-    c->persistent = getenv("VJF_NO_PERSISTENT") == nullptr;
-    c->stat_count = 0; c->prep_count = 0; c->start_count = 0;
-    c->stream2 = c->stream3 = c->stream4 = nullptr; c->ev_a = c->ev_s = c->ev_c = c->ev_d = nullptr;
+    c->start_count = 0;
+    c->stream2 = c->stream3 = nullptr; c->ev_s = c->ev_c = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
-    c->comm_a = c->comm_b = nullptr; c->world = 1;
+    c->comm_a = c->comm_b = nullptr; c->world = 1; c->fake_world = 1;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red2, 0, (size_t)P.red_len * 4, c->stream);
@@ -341,28 +362,28 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     allow_lds(vjf_serial_kernel, c->lds_k2);
     allow_lds(vjf_rls_post_kernel, c->lds_post);
     allow_lds(vjf_prepg_kernel, vjf_prepg_lds_bytes(P));
-    allow_lds(vjf_phi_next_kernel, ((size_t)P.n * P.dxu + P.n + (size_t)P.dxu * VJF_LDT) * 4);
     if (c->mfma_trial) allow_lds(vjf_trial_mfma_kernel, c->lds_k1m);
     allow_lds(vjf_chol_lds_kernel<4>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<8>, c->lds_chol);
     allow_lds(vjf_chol_lds_kernel<12>, c->lds_chol); allow_lds(vjf_chol_lds_kernel<16>, c->lds_chol);
     allow_lds(vjf_chol_lds_kernel<32>, c->lds_chol);
     allow_lds(vjf_rls_pair_kernel<4>, c->lds_chol); allow_lds(vjf_rls_pair_kernel<8>, c->lds_chol);
     allow_lds(vjf_rls_pair_kernel<12>, c->lds_chol); allow_lds(vjf_rls_pair_kernel<16>, c->lds_chol);
+    if (c->mega_ok) allow_lds(vjf_mega_kernel, kMegaLds);
     *out = c;
     return 0;
 }
 
 int vjf_ctx_destroy(vjf_ctx* ctx) {
     if (ctx && ctx->comm_a) {
-        if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamSynchronize(ctx->stream4); }
+        if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3); }
         (void)hipStreamSynchronize(ctx->stream);
         (void)nccl().comm_destroy(ctx->comm_a); (void)nccl().comm_destroy(ctx->comm_b);
         ctx->comm_a = ctx->comm_b = nullptr;
     }
     if (ctx && ctx->stream2) {
-        (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamSynchronize(ctx->stream4);
-        (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_s); (void)hipEventDestroy(ctx->ev_c); (void)hipEventDestroy(ctx->ev_d);
-        (void)hipStreamDestroy(ctx->stream2); (void)hipStreamDestroy(ctx->stream3); (void)hipStreamDestroy(ctx->stream4);
+        (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3);
+        (void)hipEventDestroy(ctx->ev_s); (void)hipEventDestroy(ctx->ev_c);
+        (void)hipStreamDestroy(ctx->stream2); (void)hipStreamDestroy(ctx->stream3);
     }
     delete ctx;
     return 0;
@@ -370,9 +391,8 @@ int vjf_ctx_destroy(vjf_ctx* ctx) {
 
 int vjf_set_overlap(vjf_ctx* ctx, int enable) {
     if (!ctx) return fail(-1, "vjf_set_overlap: null context");
-    ctx->overlap = enable != 0 && ctx->fast_chol && ctx->post_kernels && ctx->mfma_trial;
-    ctx->overlap_serial = ctx->overlap && enable == 2;
-    return ctx->overlap ? (ctx->overlap_serial ? 2 : 1) : 0;
+    ctx->overlap = enable != 0;
+    return ctx->overlap ? 1 : 0;
 }
 
 int vjf_comm_unique_id(void* ids256) {
@@ -383,14 +403,13 @@ int vjf_comm_unique_id(void* ids256) {
     return 0;
 }
 
-}  // extern "C"
-namespace { int ensure_stream2(vjf_ctx* c); }
-extern "C" {
 int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world) {
     if (!ctx || !ids256) return fail(-1, "vjf_comm_init: null argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(-20, "vjf_comm_init: rank %d of %d", rank, world);
     if (!nccl().ok) return fail(-111, "vjf_comm_init: RCCL is not available in this process");
     if (ctx->comm_a) return fail(-112, "vjf_comm_init: the context already has communicators");
+    if (!(ctx->fast_chol && ctx->post_kernels && ctx->mfma_trial))
+        return fail(-113, "vjf_comm_init: this plan has no multi-stream route; keep the all-reduce on the caller's side (vjf_filter_local / vjf_filter_global)");
     VJF_HIP(hipSetDevice(ctx->cfg.device));
     VjfNcclId ids[2];
     memcpy(ids, ids256, sizeof ids);
@@ -399,33 +418,8 @@ int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world)
     int e = nccl().comm_init_rank(&cb, world, ids[1], rank);
     if (e != 0) { (void)nccl().comm_destroy(ca); return fail(-110, "ncclCommInitRank failed: %s", nccl().err ? nccl().err(e) : "rccl error"); }
     ctx->comm_a = ca; ctx->comm_b = cb; ctx->world = world;
-    if (getenv("VJF_NO_PERSISTENT_DIST") == nullptr) {
-        // The persistent RLS kernels must never meet a collective library that still has something to set up (a lazy connect may
-        // synchronise the device, which kernels that stay resident for a whole sequence turn into a time-out): run the two
-        // all-reduces of a step once now, on the streams and with the sizes the sequence uses (the buffers are scratch).
-        const VjfPlan& P = ctx->plan;
-        int rc = ensure_stream2(ctx);
-        if (rc) return rc;
-        float* redg = (float*)(ctx->ws + ctx->cv.red);
-        float* rede = (float*)(ctx->ws + ctx->cv.red2);
-        VJF_NCCL(nccl().group_start());
-        int e1 = nccl().all_reduce(redg, redg, (size_t)P.train_len, kNcclFloat, kNcclSum, ctx->comm_a, ctx->stream);
-        int e2 = nccl().all_reduce(redg + P.red_SC, redg + P.red_SC, (size_t)RS_N, kNcclFloat, kNcclSum, ctx->comm_a, ctx->stream);
-        VJF_NCCL(nccl().group_end());
-        VJF_NCCL(e1);
-        VJF_NCCL(e2);
-        VJF_NCCL(nccl().all_reduce(rede + P.red_G, rede + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum, ctx->comm_b, ctx->stream2));
-        VJF_HIP(hipStreamSynchronize(ctx->stream));
-        VJF_HIP(hipStreamSynchronize(ctx->stream2));
-        // every rank must take the same route through vjf_filter_seq (the persistent one ends with an all-reduce of a flag): the
-        // ranks agree on the outcome of the stream probe -- if it failed anywhere, nobody uses the persistent kernels
-        float bad = ctx->queues_ok ? 0.f : 1.f;
-        VJF_HIP(hipMemcpyAsync(redg, &bad, 4, hipMemcpyHostToDevice, ctx->stream));
-        VJF_NCCL(nccl().all_reduce(redg, redg, 1, kNcclFloat, kNcclSum, ctx->comm_a, ctx->stream));
-        VJF_HIP(hipMemcpyAsync(&bad, redg, 4, hipMemcpyDeviceToHost, ctx->stream));
-        VJF_HIP(hipStreamSynchronize(ctx->stream));
-        if (bad != 0.f) ctx->queues_ok = false;
-    }
+    ctx->fake_world = 1;
+    if (const char* fw = getenv("VJF_DEBUG_FAKE_WORLD")) { const int k = atoi(fw); if (world == 1 && k > 1 && k <= 64) ctx->fake_world = k; }
     return 0;
 }
 
@@ -449,6 +443,13 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status) {
 int vjf_debug_stamps(vjf_ctx* ctx, int enable, uint64_t* out32) {
     if (!ctx) return fail(-1, "vjf_debug_stamps: null context");
     int ring = 0;
+    if (enable >= 128) {                                     // 128 + k: the one-launch route's trial-role stamps of step k % 32 (16 words)
+        if (out32 && ctx->mega_ok) {
+            VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.mg_stamps + (size_t)((enable - 128) & 31) * 128, 128, hipMemcpyDeviceToHost, ctx->stream));
+            VJF_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return 0;
+    }
     if (enable >= 64) {                                      // 64 + k: 256-byte chunk k of the trial kernel's per-workgroup partials (even steps)
         if (out32) {
             VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.partial + (size_t)(enable - 64) * 256, 256, hipMemcpyDeviceToHost, ctx->stream));
@@ -456,7 +457,7 @@ int vjf_debug_stamps(vjf_ctx* ctx, int enable, uint64_t* out32) {
         }
         return 0;
     }
-    if (enable >= 16) ring = (enable - 16) % 10;             // 16 + k: ring entry k (steps with epoch % 8 == k; 8: forward halves), mode unchanged
+    if (enable >= 16) ring = (enable - 16) % 10;             // 16 + k: ring entry k (steps with epoch % 8 == k), mode unchanged
     else {
         ctx->stamps = enable != 0;
         ctx->stamps_keep_overlap = enable == 2;
@@ -477,7 +478,7 @@ int vjf_reduce_buffer(vjf_ctx* ctx, float** ptr, int64_t* n_floats) {
 
 namespace {
 int refresh_aux(vjf_ctx* c) {
-    if (!c->mfma_trial) return 0;
+    if (!c->mfma_trial && !c->mega_ok) return 0;
     hipLaunchKernelGGL(vjf_aux_kernel, dim3(32), dim3(256), 0, c->stream, c->plan, (const float*)c->state, (float*)(c->ws + c->cv.aux));
     VJF_HIP(hipGetLastError());
     return 0;
@@ -508,8 +509,8 @@ VjfTrialArgs trial_args(vjf_ctx* c, int32_t B, const float* y, const float* u, c
 
 int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16 : (B + 3) / 4; }   // (wide path: 4 trials per loss workgroup)
 
-// K1.  part: 0 whole step, 1 forward half, 2 backward half (matrix-core kernel only)
-int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hipEvent_t stop = nullptr, bool count_fwd = false,
+// K1 of the per-step routes.  part: 0 whole step, 1 forward half, 2 backward half (matrix-core kernel only)
+int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bool count_fwd = false,
                  const unsigned* rls_done = nullptr, unsigned rls_target = 0) {
     const VjfPlan& P = c->plan;
     const int nblk = trial_blocks(c, a.B);
@@ -517,19 +518,11 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
         VjfTrialMfmaArgs m{};
         m.t = a; m.aux = (const float*)(c->ws + c->cv.aux); m.part = part;
         m.rls_done = rls_done; m.rls_target = rls_target;
-        // (measured at config B: 68.4 us/step without, 67.3 with the last 32 raised; the tail moves to their older neighbours)
-        m.late_prio = getenv("VJF_LATE_PRIO") ? atoi(getenv("VJF_LATE_PRIO")) : (part == 3 ? 32 : 0);
         m.done = (unsigned*)(c->ws + c->cv.flags) + 16;
         if (part != 1) c->k1_count += (unsigned)nblk;
-        if ((part == 1 || part == 3) && count_fwd) { m.fwd_done = (unsigned*)(c->ws + c->cv.flags) + 48; c->fwd_count += (unsigned)nblk; }
-        if (part == 3) {
-            m.phi_done = (unsigned*)(c->ws + c->cv.flags) + 53;
-            m.own_phi = c->k1_own_phi; m.next_E = c->k1_next_E; m.next_eps_s = c->k1_next_eps; m.next_u = c->k1_next_u;
-            c->phi_count += (unsigned)nblk * (unsigned)((m.own_phi ? 1 : 0) + (m.next_E ? 1 : 0));
-        }
+        if (part == 1 && count_fwd) { m.fwd_done = (unsigned*)(c->ws + c->cv.flags) + 48; c->fwd_count += (unsigned)nblk; }
         m.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
-        if (m.stamps && c->stamps_keep_overlap) m.stamps += part == 1 ? 8 * 32 : (rls_done ? (c->epoch_k1 & 7u) * 32 : 0);   // ring entry (diagnostic)
-        VJF_LAUNCH(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, stop, P, m);
+        hipLaunchKernelGGL(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, P, m);
     } else {
         // working set beyond LDS: one GEMM over all trials per layer (vjf_trial_wide.h)
         VjfWideArgs w{};
@@ -577,9 +570,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, hi
 }
 
 // Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
-int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, hipEvent_t stop = nullptr,
-                int gen = 0, const unsigned* wait_count = nullptr, unsigned wait_target = 0, bool no_reduce = false,
-                unsigned* done_count = nullptr, unsigned kind0_mask = 0) {
+int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, int gen = 0) {
     const VjfPlan& P = c->plan;
     const int nsplit = split_for(B);
     VjfGramArgs g{};
@@ -587,26 +578,21 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     g.E = (const float*)(c->ws + (gen ? c->cv.E2 : c->cv.E)); g.ACT = (const float*)(c->ws + c->cv.ACT); g.DEL = (const float*)(c->ws + c->cv.DEL);
     g.slabs = (float*)(c->ws + c->cv.slabs);
     g.B = B; g.nsplit = nsplit; g.job0 = job0;
-    g.wait_count = wait_count; g.wait_target = wait_target; g.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
+    g.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
-    g.high_prio = (kind0_mask != 0 && getenv("VJF_GRAM_PRIO")) ? 1 : 0;
     hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(VJF_GRAM_THREADS), 0, st, P, g);
     VJF_HIP(hipGetLastError());
-    if (no_reduce) return 0;                                   // (the consumer sums the slabs itself)
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial)); r.red = red;
     r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask;
-    r.done_count = done_count; r.kind0_mask = kind0_mask;
-    VJF_LAUNCH(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(VJF_REDUCE_THREADS), 0, st, stop, P, r);
+    hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(VJF_REDUCE_THREADS), 0, st, P, r);
     VJF_HIP(hipGetLastError());
     return 0;
 }
 
 // which: 0 whole prep grid, 1 RLS operand rows only, 2 SGD + scalars only
 int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const float* red, int which, hipStream_t st,
-                hipEvent_t stop = nullptr, const unsigned* wait_count = nullptr, unsigned wait_target = 0,
-                const unsigned* run_word = nullptr, unsigned run_epoch = 0, const unsigned* start_count = nullptr, unsigned start_target = 0,
-                unsigned* done_count = nullptr) {
+                const unsigned* run_word = nullptr, unsigned run_epoch = 0, const unsigned* start_count = nullptr, unsigned start_target = 0) {
     const VjfPlan& P = c->plan;
     VjfPrepArgs p{};
     p.state = c->state; p.red = red; p.gbuf = (float*)(c->ws + c->cv.work);
@@ -614,53 +600,31 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
     p.loss4 = loss4; p.B_total = B_total; p.flags = flags;
     p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
     p.n_sgdblk = (P.train_len + 1023) / 1024;
-    p.wait_count = wait_count; p.wait_target = wait_target;
     p.run_word = run_word; p.run_epoch = run_epoch; p.start_count = start_count; p.start_target = start_target;
-    p.done_count = done_count;
     if (which != 2 && P.dz > 16) {                             // (the matrix-core operand kernel holds one 16-column tile of W)
         p.bid0 = 0;
         const int grid = which == 1 ? p.n_rowblk : p.n_rowblk + p.n_sgdblk + 1;
-        VJF_LAUNCH(vjf_prep_kernel, dim3(grid), dim3(256), 0, st, stop, P, p);
+        hipLaunchKernelGGL(vjf_prep_kernel, dim3(grid), dim3(256), 0, st, P, p);
         VJF_HIP(hipGetLastError());
         return 0;
     }
     if (which != 2) {                                          // RLS operands: g and P += G/v, 16 rows per workgroup
         const size_t lds = vjf_prepg_lds_bytes(P);
-        VJF_LAUNCH(vjf_prepg_kernel, dim3((P.n + 15) / 16), dim3(256), lds, st, which == 1 ? stop : (hipEvent_t) nullptr, P, p);
+        hipLaunchKernelGGL(vjf_prepg_kernel, dim3((P.n + 15) / 16), dim3(256), lds, st, P, p);
         VJF_HIP(hipGetLastError());
         if (which == 1) return 0;
     }
     p.bid0 = p.n_rowblk;                                       // clip + SGD and the scalars
-    VJF_LAUNCH(vjf_prep_kernel, dim3(p.n_sgdblk + 1), dim3(256), 0, st, stop, P, p);
+    hipLaunchKernelGGL(vjf_prep_kernel, dim3(p.n_sgdblk + 1), dim3(256), 0, st, P, p);
     VJF_HIP(hipGetLastError());
     return 0;
 }
 
-// slab reduce + clip + SGD + scalars in one launch (see vjf_sgd_kernel); the gradient Gram must have run with no_reduce
-int launch_sgd(vjf_ctx* c, int B, int32_t B_total, float* loss4, uint32_t flags, int job0, int njobs, hipStream_t st, int gen) {
-    const VjfPlan& P = c->plan;
-    VjfSgdArgs a{};
-    a.jobs = (const VjfJob*)(c->ws + c->cv.jobs); a.slabs = (const float*)(c->ws + c->cv.slabs);
-    a.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial));
-    a.state = c->state; a.aux = (float*)(c->ws + c->cv.aux); a.loss4 = loss4;
-    a.job0 = job0; a.njobs = njobs; a.nsplit = split_for(B); a.nblocks_k1 = trial_blocks(c, B); a.B_total = B_total; a.flags = flags;
-    hipLaunchKernelGGL(vjf_sgd_kernel, dim3(njobs + 1), dim3(1024), 0, st, P, a);
-    VJF_HIP(hipGetLastError());
-    return 0;
-}
-
-// Cholesky + RLS tail + state-noise update.  `before_chol` / `before_post`: events the stream waits for first (or null).
-// `self_prep`: the Cholesky kernel forms P_new itself from the copy the previous Cholesky kernel left and waits in-kernel for
-// sigma (`wait_count` >= `wait_target`: post kernel of the previous step done); the operand kernel (state's P, g) then runs on
-// `st_post`, behind a gate on the same count and in front of the y / W workgroup that consumes g.
-int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, hipStream_t st_post,
-               hipEvent_t stop = nullptr, bool no_triclean = false, hipStream_t st_inv = nullptr, bool self_prep = false,
-               const unsigned* wait_count = nullptr, unsigned wait_target = 0) {
-    // `st_post` may differ from `st`: the post kernel's workgroups then start beside the Cholesky kernel and take each
-    // column of L as the flag for it appears (the Cholesky kernel is always enqueued first, so even on one hardware queue
-    // nothing waits for a kernel behind it).  What the post kernel needs from elsewhere it waits for itself: g through the
-    // column flags (the prep kernel precedes the Cholesky kernel in `st`), the readers of W, w_chol, sigma through the trial
-    // kernel's workgroup count.
+// Cholesky + RLS tail + state-noise update of one step.  `st_post` may differ from `st` (three-stream route): the whole update --
+// Cholesky workgroup, y / W workgroup, inverse workgroups -- then goes out as ONE launch on `st`, whose workgroups hand the columns
+// of L to each other through flags (all of them belong to one grid; the operand kernel precedes it in `st`, so g is in place).
+int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, bool one_launch, hipEvent_t stop = nullptr,
+               bool no_triclean = false) {
     const VjfPlan& P = c->plan;
     if (!(flags & VJF_FLAG_UPDATE)) return 0;
     VjfCholArgs a{};
@@ -673,13 +637,9 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
     unsigned* colflags = (unsigned*)(c->ws + c->cv.flags);
     a.post = c->post_kernels ? 1 : 0; a.dinv_out = dinv; a.ok_out = okflag; a.lscr = (float*)(c->ws + c->cv.lscr);
     a.flags_out = colflags; a.epoch = ++c->epoch; a.no_triclean = no_triclean ? 1 : 0;
-    a.pscr = (float*)(c->ws + c->cv.pscr); a.self_prep = self_prep ? 1 : 0; a.wait_count = wait_count; a.wait_target = wait_target;
-    // Sequence with a collective library in the process (sharded trials): the whole RLS update -- Cholesky workgroup, y / W
-    // workgroup, inverse workgroups -- goes out as ONE launch on `st` (the operand kernel precedes it there, so g is in place).
-    // With the library's streams beside ours, a third or fourth stream of ours ends up sharing a hardware queue with the
-    // caller's stream, and its spinning kernel then sits in front of the trial / SGD chain (measured: 119 us/step).
-    const bool pair = c->post_kernels && !(flags & VJF_FLAG_WARM_UP) && st_inv && st_inv != st_post && st_post != st && P.dz <= 16 && !self_prep &&
-                      (c->comm_a ? getenv("VJF_NO_PAIR") == nullptr : getenv("VJF_PAIR") != nullptr);
+    a.pscr = (float*)(c->ws + c->cv.pscr);
+    const bool rls = !(flags & VJF_FLAG_WARM_UP);
+    const bool pair = one_launch && c->post_kernels && rls && P.dz <= 16;
     if (!pair) {
         switch (vjf_chol_dzp(P.dz)) {
             case 4: hipLaunchKernelGGL(vjf_chol_lds_kernel<4>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
@@ -688,63 +648,37 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
             case 16: hipLaunchKernelGGL(vjf_chol_lds_kernel<16>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
             default: hipLaunchKernelGGL(vjf_chol_lds_kernel<32>, dim3(1), dim3(VJF_CHOL_THREADS), c->lds_chol, st, P, a); break;
         }
+        VJF_HIP(hipGetLastError());
     }
-    VJF_HIP(hipGetLastError());
-    if (c->post_kernels) {
-        const bool rls = !(flags & VJF_FLAG_WARM_UP);
-        if (rls && st_post != st && c->gate_post) {            // (see the Cholesky kernel's "running" word)
-            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, st_post, (const unsigned*)(colflags + VJF_CHOL_MAXBLK + 2), a.epoch,
-                               c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS);
-            VJF_HIP(hipGetLastError());
-        }
-        if (rls && self_prep) {
-            // (the operand kernel reads this step's statistics too: they are complete once the Cholesky kernel, which follows
-            //  their reduction in its stream, says it is running)
-            hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, st_post, wait_count, wait_target,
-                               (const unsigned*)(colflags + VJF_CHOL_MAXBLK + 2), a.epoch, c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS);
-            VJF_HIP(hipGetLastError());
-            int rc = launch_prep(c, B_total, nullptr, flags, red, 1, st_post);
-            if (rc) return rc;
-        }
-        if (rls) {
-            // inverse column halves + the y / W workgroup, which also carries the state-noise update
-            VjfPostArgs pa{};
-            pa.undo_P = self_prep ? 1 : 0;
-            pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.lscr = a.lscr;
-            pa.flags = colflags; pa.epoch = a.epoch; pa.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
-            pa.k1_done = c->mfma_trial ? colflags + 16 : nullptr; pa.k1_target = c->k1_count;
-            pa.done = colflags + 32; pa.started = colflags + 24; c->post_count += (unsigned)(2 * nbl + 1);
-            c->start_count += (unsigned)(2 * nbl + 1);
-            pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
-            if (pair) {
-                // (every workgroup of the launch asks for the Cholesky workgroup's LDS; the inverse workgroups keep trial-kernel
-                //  workgroups off their CUs anyway, through their registers)
-                pa.role = 2;
-                const dim3 grid(2 + 2 * nbl);
-                switch (vjf_chol_dzp(P.dz)) {
-                    case 4: VJF_LAUNCH(vjf_rls_pair_kernel<4>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
-                    case 8: VJF_LAUNCH(vjf_rls_pair_kernel<8>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
-                    case 12: VJF_LAUNCH(vjf_rls_pair_kernel<12>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
-                    default: VJF_LAUNCH(vjf_rls_pair_kernel<16>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
-                }
-            } else if (st_inv && st_inv != st_post) {
-                // two launches: the inverse workgroups keep one column of L in LDS and share their CUs with the trial kernel;
-                // the y / W workgroup (all of L in LDS) runs beside them on its own stream
-                pa.role = 1;
-                hipLaunchKernelGGL(vjf_rls_post_kernel, dim3(2 * nbl), dim3(VJF_POST_THREADS), vjf_post_inv_lds_bytes(P), st_inv, P, pa);
-                pa.role = 2;
-                VJF_LAUNCH(vjf_rls_post_kernel, dim3(1), dim3(VJF_POST_THREADS), c->lds_post, st_post, stop, P, pa);
-            } else {
-                VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st_post, stop, P, pa);
+    if (!c->post_kernels) return 0;
+    if (rls) {
+        // inverse column halves + the y / W workgroup, which also carries the state-noise update
+        VjfPostArgs pa{};
+        pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.lscr = a.lscr;
+        pa.flags = colflags; pa.epoch = a.epoch; pa.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
+        pa.k1_done = c->mfma_trial ? colflags + 16 : nullptr; pa.k1_target = c->k1_count;
+        pa.done = colflags + 32; pa.started = colflags + 24; c->post_count += (unsigned)(2 * nbl + 1);
+        c->start_count += (unsigned)(2 * nbl + 1);
+        pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.stamps = a.stamps;
+        if (pair) {
+            pa.role = 2;
+            const dim3 grid(2 + 2 * nbl);
+            switch (vjf_chol_dzp(P.dz)) {
+                case 4: VJF_LAUNCH(vjf_rls_pair_kernel<4>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
+                case 8: VJF_LAUNCH(vjf_rls_pair_kernel<8>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
+                case 12: VJF_LAUNCH(vjf_rls_pair_kernel<12>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
+                default: VJF_LAUNCH(vjf_rls_pair_kernel<16>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
             }
-            VJF_HIP(hipGetLastError());
         } else {
-            VjfResidArgs ra{};
-            ra.state = c->state; ra.red = red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
-            hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st_post, P, ra);
-            VJF_LAUNCH(vjf_sigma_kernel, dim3(1), dim3(64), 0, st_post, stop, P, ra, (const int*)nullptr);
-            VJF_HIP(hipGetLastError());
+            VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st, stop, P, pa);
         }
+        VJF_HIP(hipGetLastError());
+    } else {
+        VjfResidArgs ra{};
+        ra.state = c->state; ra.red = red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
+        hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra);
+        VJF_LAUNCH(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, stop, P, ra, (const int*)nullptr);
+        VJF_HIP(hipGetLastError());
     }
     return 0;
 }
@@ -762,204 +696,98 @@ int launch_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const fl
 
 int ensure_stream2(vjf_ctx* c) {
     if (c->stream2) return 0;
+    VJF_HIP(hipSetDevice(c->cfg.device));
     VJF_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     VJF_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
-    VJF_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
-    VJF_HIP(hipEventCreate(&c->ev_d));
     VJF_HIP(hipEventCreate(&c->ev_c));
-    VJF_HIP(hipEventCreate(&c->ev_a));          // (default flags: the events are attached to kernel launches)
-    VJF_HIP(hipEventCreate(&c->ev_s));
-    // Do the streams run beside each other?  Consumers first (the worst case): a waiter on sc and on sb, the latter followed in its
-    // stream by the setter of the former's flag; the caller's stream sets the first flag.  On hardware queues of their own
-    // all of it completes in microseconds; if two of the streams share a queue a waiter sits in front of the setter it waits
-    // for and times out (~1 ms): the persistent kernels are then not used (the per-step launches only get slower).
-    {
-        unsigned* f = (unsigned*)(c->ws + c->cv.flags) + 56;                   // [56..58] flags, [59] time-outs
-        const unsigned tag = 0x5eed0000u + (unsigned)c->epoch;
-        VJF_HIP(hipMemsetAsync(f, 0, 16, c->stream));
-        VJF_HIP(hipStreamSynchronize(c->stream));
-        // (the persistent kernels and their feeders use the caller's stream, stream2 and stream3)
-        hipLaunchKernelGGL(vjf_probe_wait_kernel, dim3(1), dim3(64), 0, c->stream3, (const unsigned*)(f + 1), tag, f + 3);
-        hipLaunchKernelGGL(vjf_probe_wait_kernel, dim3(1), dim3(64), 0, c->stream2, (const unsigned*)f, tag, f + 3);
-        hipLaunchKernelGGL(vjf_probe_set_kernel, dim3(1), dim3(64), 0, c->stream2, f + 1, tag);
-        hipLaunchKernelGGL(vjf_probe_set_kernel, dim3(1), dim3(64), 0, c->stream, f, tag);
-        VJF_HIP(hipGetLastError());
-        unsigned timed_out = 0;
-        VJF_HIP(hipStreamSynchronize(c->stream2));
-        VJF_HIP(hipStreamSynchronize(c->stream3));
-        VJF_HIP(hipStreamSynchronize(c->stream4));
-        VJF_HIP(hipMemcpyAsync(&timed_out, f + 3, 4, hipMemcpyDeviceToHost, c->stream));
-        VJF_HIP(hipStreamSynchronize(c->stream));
-        c->queues_ok = timed_out == 0;
-        if (getenv("VJF_VERBOSE")) fprintf(stderr, "vjf: stream probe: %s\n", c->queues_ok ? "independent queues" : "streams share a hardware queue");
-    }
+    VJF_HIP(hipEventCreate(&c->ev_s));          // (default flags: the events are attached to kernel launches)
     return 0;
 }
 
-// The sequence on two streams.  Step t's work splits into
-//   chain A (caller's stream): K1 backward half(t) -> gradient Gram -> clip + SGD -> K1 forward half(t+1) -> E^T E Gram(t+1)
-//   chain B (second stream):   P += G/v, g -> Cholesky -> [K1 backward half(t) done] -> W, w_chol -> residual -> sigma
-// K1's backward half(t+1) needs W, w_chol, sigma of step t, nothing else on chain A does; chain B(t+1) needs only the
-// forward half's E rows.  So chain A of step t runs beside chain B of step t, and a step costs max(A, B) instead of A + B.
-// Results are those of the one-stream order bit for bit (same kernels, same sums).  RLS statistics alternate between two
-// reduce buffers so that chain A may produce step t+1's while chain B still reads step t's.
-int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
-                       const float* lv0, float* mu, float* lv, float* loss, uint32_t flags);
+// ---- the one-launch route (single rank; sgd + update, no warm-up): one cooperative launch of vjf_mega_kernel per chunk of steps
+int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
+                    const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
+    const VjfPlan& P = c->plan;
+    const size_t sz = (size_t)B * P.dz;
+    int rc = check_step_args(c, B, y, u, mu0, lv0, eps, eps + sz, mu, lv);
+    if (rc) return rc;
+    MegaShape m{};
+    if (!mega_shape(P, B, c->ncu, &m)) return fail(-26, "vjf_filter_seq: %d compute units are too few for the one-launch route", c->ncu);
+    VJF_HIP(hipSetDevice(c->cfg.device));
+    rc = refresh_aux(c);
+    if (rc) return rc;
+    unsigned* cnt = (unsigned*)(c->ws + c->cv.mg_cnt);
+    VJF_HIP(hipMemsetAsync(cnt, 0, (size_t)MG_C_WORDS * 4, c->stream));                 // every counter and flag of the launch starts at 0
+    const int nbl = (P.n + 31) / 32;
+    const unsigned npost = (unsigned)(2 * nbl + 1);
+    float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};
+    float* stw = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
+    VjfMegaArgs A{};
+    A.T = T; A.B = B; A.ntiles = m.ntiles;
+    A.n_rls = m.n_rls; A.n_trial = m.n_trial; A.n_gram = m.n_gram; A.n_prep = m.n_prep; A.n_sgd = m.n_sgd;
+    A.y = y; A.u = u; A.eps = eps; A.mu0 = mu0; A.lv0 = lv0; A.mu = mu; A.lv = lv; A.loss = loss;
+    A.state = c->state; A.aux = (float*)(c->ws + c->cv.aux);
+    A.E0 = (float*)(c->ws + c->cv.E); A.E1 = (float*)(c->ws + c->cv.E2);
+    A.slab_early = (float*)(c->ws + c->cv.mg_early); A.slab_late = (float*)(c->ws + c->cv.mg_late); A.gslab = (float*)(c->ws + c->cv.mg_gslab);
+    A.red0 = rede[0]; A.red1 = rede[1];
+    A.gbuf = (float*)(c->ws + c->cv.work);
+    A.cnt = cnt; A.flags = flags;
+    A.early_len = P.n * 16 + 8; A.late_len = P.train_len + 8;
+    A.gram_rows = m.gram_rows;
+    A.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.mg_stamps) : nullptr;
+    VjfCholArgs C{};
+    C.state = c->state; C.red = rede[0]; C.red2 = rede[1]; C.gbuf = A.gbuf; C.B_total = B; C.flags = flags;
+    C.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
+    float* dinv = (float*)(c->ws + c->cv.post);
+    C.post = 1; C.dinv_out = dinv; C.ok_out = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
+    C.lscr = (float*)(c->ws + c->cv.lscr); C.flags_out = cnt + MG_C_COLFLAGS; C.epoch = 1; C.no_triclean = 1;
+    C.pscr = (float*)(c->ws + c->cv.pscr); C.self_prep = 1; C.src_state = 1;
+    C.wait_count = cnt + MG_C_PDONE; C.wait_target = 0; C.wait_stride = npost;
+    C.stat_count = cnt + MG_C_STAT; C.stat_target = (unsigned)m.n_gram; C.stat_stride = (unsigned)m.n_gram;
+    C.nsteps = T; C.step0 = 0;
+    VjfPostArgs Q{};
+    Q.state = c->state; Q.dinv = dinv; Q.gbuf = A.gbuf; Q.lscr = C.lscr; Q.flags = cnt + MG_C_COLFLAGS; Q.epoch = 1; Q.status = stw;
+    Q.k1_done = cnt + MG_C_K1; Q.k1_target = (unsigned)m.n_trial; Q.k1_stride = (unsigned)m.n_trial;
+    Q.done = cnt + MG_C_PDONE; Q.started = cnt + MG_C_STARTED;
+    Q.red = rede[0]; Q.red2 = rede[1]; Q.B_total = B; Q.fold_sigma = 1; Q.stamps = C.stamps; Q.undo_P = 1;
+    Q.prep_count = cnt + MG_C_PREP; Q.prep_target = (unsigned)m.n_prep; Q.prep_stride = (unsigned)m.n_prep;
+    Q.nsteps = T; Q.step0 = 0; Q.role = 2;
+    VjfPlan Pk = P;
+    void* args[] = {(void*)&Pk, (void*)&A, (void*)&C, (void*)&Q};
+    const int grid = m.n_rls + m.n_trial + m.n_gram + m.n_prep + m.n_sgd;
+    VJF_HIP(hipLaunchCooperativeKernel((const void*)vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), args, (unsigned)kMegaLds, c->stream));
+    return 0;
+}
 
-int filter_seq_overlap(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
+// ---- the three-stream route (trials sharded over ranks, RCCL communicators in the context).  Step t's work splits into
+//   chain A (caller's stream): K1 backward half(t) -> gradient Gram -> [all-reduce] -> clip + SGD -> K1 forward half(t+1)
+//   chain B (second stream):   [gate: forward half(t)] E^T E Gram(t) -> [all-reduce] -> [gate: RLS(t-1)] P += G/v, g -> the RLS
+//                              update of step t as ONE launch (Cholesky workgroup, y / W workgroup, inverse workgroups)
+// K1's backward half(t+1) needs W, w_chol, sigma of step t, nothing else on chain A does; chain B(t+1) needs only the forward
+// half's rows.  So a step costs max(A, B) instead of A + B.  Every kernel that waits in-kernel (the gates, the backward half,
+// the y / W and inverse workgroups) waits for work that the host enqueued BEFORE it: whatever hardware queues the streams share,
+// the producers are dispatched first and run to completion.  Results are those of the one-stream order bit for bit (same
+// kernels, same sums).  RLS statistics alternate between two reduce buffers.
+int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
                        const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
-    // (single rank only: a collective library may synchronise the device when it sets something up lazily, which kernels that
-    //  stay resident for the whole sequence would turn into a time-out: vjf_comm_init runs the collectives once beforehand)
-    if (c->persistent && !c->overlap_serial) { int rc0 = ensure_stream2(c); if (rc0) return rc0; }
-    if (c->persistent && c->queues_ok && !c->overlap_serial && c->mfma_trial && c->post_kernels && c->plan.dz <= 16 && (!c->comm_a || getenv("VJF_NO_PERSISTENT_DIST") == nullptr)) {
-        // The persistent kernels wait (bounded) for kernels the host enqueues while they run.  The runtime multiplexes streams
-        // onto a few hardware queues; once in a while a launch of ours is held behind the persistent kernel's queue until that
-        // kernel's waits run out (seen under heavy stream churn: ~1 % of sequences, an 80 ms stall).  Such a sequence is not to
-        // be used: the state blob is checkpointed first, the status word read back at the end (one host synchronisation per
-        // sequence), and on a wait time-out the blob is restored, the hand-off counters are reset and the sequence runs again
-        // with a launch per step -- which does not depend on any kernel staying resident.  With communicators the ranks agree
-        // on it (one more all-reduce, of a flag, per sequence).
-        const bool guard = getenv("VJF_NO_SEQ_GUARD") == nullptr;
-        float* backup = (float*)(c->ws + c->cv.backup);
-        if (guard) VJF_HIP(hipMemcpyAsync(backup, c->state, (size_t)c->plan.n_state * 4, hipMemcpyDeviceToDevice, c->stream));
-        int rc1 = filter_seq_persist(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
-        if (rc1 || !guard) return rc1;
-        float stf = 0.f;
-        VJF_HIP(hipMemcpyAsync(&stf, c->state + c->plan.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, 4, hipMemcpyDeviceToHost, c->stream));
-        VJF_HIP(hipStreamSynchronize(c->stream));
-        float lost = ((unsigned)stf & 0x1ff00u) ? 1.f : 0.f;
-        if (c->comm_a) {
-            // sharded trials: every rank must take the same route -- the sum of the "lost" flags over the ranks (the gradient
-            // reduce buffer is free between sequences)
-            float* scratch = (float*)(c->ws + c->cv.red);
-            VJF_HIP(hipMemcpyAsync(scratch, &lost, 4, hipMemcpyHostToDevice, c->stream));
-            VJF_NCCL(nccl().all_reduce(scratch, scratch, 1, kNcclFloat, kNcclSum, c->comm_a, c->stream));
-            VJF_HIP(hipMemcpyAsync(&lost, scratch, 4, hipMemcpyDeviceToHost, c->stream));
-            VJF_HIP(hipStreamSynchronize(c->stream));
-        }
-        if (lost == 0.f) return 0;
-        if (getenv("VJF_VERBOSE")) fprintf(stderr, "vjf: a wait of the persistent sequence timed out (status 0x%x): re-running it with per-step launches\n", (unsigned)stf);
-        VJF_HIP(hipStreamSynchronize(c->stream2)); VJF_HIP(hipStreamSynchronize(c->stream3)); VJF_HIP(hipStreamSynchronize(c->stream4));
-        VJF_HIP(hipMemcpyAsync(c->state, backup, (size_t)c->plan.n_state * 4, hipMemcpyDeviceToDevice, c->stream));
-        VJF_HIP(hipMemsetAsync(c->ws + c->cv.flags, 0, 256, c->stream));
-        VJF_HIP(hipStreamSynchronize(c->stream));
-        c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0; c->stat_count = 0; c->prep_count = 0; c->start_count = 0;
-        c->phi_count = 0;
-        c->persistent = false;                                           // (this context stays on the per-step launches)
-    }
     int rc = ensure_stream2(c);
     if (rc) return rc;
     const VjfPlan& P = c->plan;
     const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
-    // (overlap_serial: the three chains share the caller's stream; every wait below is then satisfied when it is reached)
-    hipStream_t sa = c->stream, sb = c->overlap_serial ? sa : c->stream2, sc = c->overlap_serial ? sa : c->stream3;
-    hipStream_t sd = (c->overlap_serial || getenv("VJF_POST_ONE_LAUNCH")) ? sc : c->stream4;   // the post kernel's inverse workgroups
+    hipStream_t sa = c->stream, sb = c->stream2;
     float* redg = (float*)(c->ws + c->cv.red);                             // gradients + loss sums (chain A)
     float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};   // RLS statistics of even / odd steps (chain B)
-    const int Bt = B * c->world;                                           // trials of all ranks
+    const int fw = c->fake_world;
+    const int Bt = B * c->world * fw;                                      // trials of all ranks
     auto args = [&](int t) {
         return trial_args(c, B, y + t * sy, u ? u + t * su : nullptr, t ? mu + (t - 1) * sz : mu0, t ? lv + (t - 1) * sz : lv0,
                           eps + (size_t)t * 2 * sz, eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags, t & 1);
     };
-    rc = check_step_args(c, B, y, u, mu0, lv0, eps, eps + sz, mu, lv);
-    if (rc) return rc;
-    rc = refresh_aux(c);
-    if (rc) return rc;
-    const int ne = c->n_ejobs, ng = c->njobs - ne;
-    unsigned* fdone = (unsigned*)(c->ws + c->cv.flags) + 48;
-    float* stw = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
-    if ((rc = launch_trial(c, args(0), 1, sa, nullptr, true))) return rc;   // prologue: forward half of step 0
-    for (int t = 0; t < T; ++t) {
-        const unsigned post_before = c->post_count;                      // workgroups of post(0 .. t-1)
-        // sb: RLS statistics of step t as soon as its forward half is done, then (behind W, sigma of t-1) P += G/v, g, Cholesky
-        //     (no cross-stream events inside the loop: a kernel carrying a completion signal holds up the next one of its own
-        //     stream by ~10 us on this stack; one-wavefront gate kernels wait on workgroup counters instead)
-        if (c->sb_gates) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
-        if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, nullptr, t & 1, c->sb_gates ? nullptr : fdone, c->fwd_count))) return rc;
-        if (c->comm_b)                                                     // trials are sharded over ranks: sum [G | FDX | sums]
-            VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum,
-                                       c->comm_b, sb));
-        // backward half(t) and P += G/v, g (t) read W, w_chol, sigma of step t-1, ready when every workgroup of post(t-1) has
-        // its outputs in memory: the backward half waits for that count itself, behind the reloads of its forward half's rows
-        // (or starts behind a gate kernel: VJF_K1_GATE)
-        const unsigned* pdone = (const unsigned*)((unsigned*)(c->ws + c->cv.flags) + 32);
-        const bool fuse_sgd = !c->comm_a && getenv("VJF_FUSED_SGD") != nullptr;   // (see below)
-        const bool k1_waits = c->k1_inkernel && c->mfma_trial && !c->overlap_serial && !fuse_sgd;
-        if (t > 0 && !k1_waits) {
-            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sa, pdone, c->post_count, stw);
-            VJF_HIP(hipGetLastError());
-        }
-        if ((rc = launch_trial(c, args(t), 2, sa, nullptr, false, (t > 0 && k1_waits) ? pdone : nullptr, c->post_count))) return rc;
-        if (t == 0) {
-            // the post kernel writes only the block-upper half of w_chol (block-lower of w_pchol): the other halves are cleared
-            // once per blob (VJF_SC_TRI_CLEAN), here behind the backward half that may still read a full w_chol
-            hipLaunchKernelGGL(vjf_triclean_kernel, dim3(64), dim3(256), 0, sa, P, c->state);
-            hipLaunchKernelGGL(vjf_triclean_done_kernel, dim3(1), dim3(1), 0, sa, P, c->state);
-            VJF_HIP(hipGetLastError());
-        }
-        const unsigned* pd = (const unsigned*)((unsigned*)(c->ws + c->cv.flags) + 32);
-        const bool prepg_waits = !c->sb_gates || c->prepg_inkernel;      // the 13 workgroups of the operand kernel poll themselves
-        // t > 0: the Cholesky kernel prepares its own operand (launch_rls, self_prep) -- gate + operand kernel leave the cycle
-        // post(t-1) -> Cholesky(t) -> post(t).  It then spins on a whole CU until post(t-1) is done: that kernel is resident by
-        // then (the scalar workgroup of SGD(t-1) saw to it, and this kernel follows the forward half(t) that came after it).
-        const bool self_prep = c->self_prep && t > 0 && !c->overlap_serial && P.dz <= 16 && k1_waits;
-        if (!self_prep) {
-            if (!prepg_waits && t > 0) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, pd, post_before, stw);
-            if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, (t > 0 && prepg_waits) ? pd : nullptr, post_before))) return rc;
-        }
-        // Cholesky on sb; the post kernel on sc beside it (it takes the columns of L as they appear)
-        if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, sc, t == T - 1 ? c->ev_s : nullptr, true, sd, self_prep, pd, post_before))) return rc;
-        // (single rank only: the SGD kernel can sum the gradient slabs itself -- 7 us instead of 5 + 7 for reduce + SGD, but the
-        //  step as a whole came out 1 us SLOWER in A/B runs on one box: the forward half then starts earlier and runs
-        //  beside more of the Cholesky kernel.  Off unless VJF_FUSED_SGD is set.)
-        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1, nullptr, 0, fuse_sgd))) return rc;
-        if (c->comm_a) {                                                   // sum the gradients and the loss sums over ranks
-            VJF_NCCL(nccl().group_start());
-            int e1 = nccl().all_reduce(redg, redg, (size_t)P.train_len, kNcclFloat, kNcclSum, c->comm_a, sa);
-            int e2 = nccl().all_reduce(redg + P.red_SC, redg + P.red_SC, (size_t)RS_N, kNcclFloat, kNcclSum, c->comm_a, sa);
-            VJF_NCCL(nccl().group_end());
-            VJF_NCCL(e1);
-            VJF_NCCL(e2);
-        }
-        if (fuse_sgd) rc = launch_sgd(c, B, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, ne, ng, sa, t & 1);
-        else {
-            // (k1_waits: the scalar workgroup ends once Cholesky(t) and post(t) are resident, see VjfPrepArgs::run_word)
-            const unsigned* fl = (const unsigned*)(c->ws + c->cv.flags);
-            rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, nullptr, nullptr, 0,
-                             k1_waits ? fl + VJF_CHOL_MAXBLK + 2 : nullptr, c->epoch, fl + 24, c->start_count);
-        }
-        if (rc) return rc;
-        if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
-    }
-    VJF_HIP(hipEventRecord(c->ev_c, sb));
-    VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));                           // join: the caller's stream sees the final state
-    VJF_HIP(hipStreamWaitEvent(sa, c->ev_c, 0));
-    if (sd != sc) {
-        VJF_HIP(hipEventRecord(c->ev_d, sd));
-        VJF_HIP(hipStreamWaitEvent(sa, c->ev_d, 0));
-    }
-    return 0;
-}
-
-// The sequence with the RLS chain as persistent kernels.  Per step the host enqueues only
-//   sa (caller's stream): K1 backward half(t) [waits in-kernel for post(t-1)] -> gradient Gram -> reduce -> clip + SGD -> K1 forward half(t+1)
-//   sb:                   [gate: forward half(t) done] statistics Gram -> reduce (-> all-reduce) -> [gate: post(t-1) done, Cholesky(t) has
-//                         its operands] operand kernel (state's P += G/v, g)
-// and, once per sequence, on sc the Cholesky + y / W pair (two workgroups, a CU each) and on sd the 2 nbl inverse workgroups, each of
-// which loops over the T steps, taking its inputs as the counts say they are there.
-int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
-                       const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
-    int rc = ensure_stream2(c);
-    if (rc) return rc;
-    const VjfPlan& P = c->plan;
-    const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
-    hipStream_t sa = c->stream, sb = c->stream2, sc = c->stream3, sd = c->stream4;
-    float* redg = (float*)(c->ws + c->cv.red);
-    float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};
-    const int Bt = B * c->world;
-    auto args = [&](int t) {
-        return trial_args(c, B, y + t * sy, u ? u + t * su : nullptr, t ? mu + (t - 1) * sz : mu0, t ? lv + (t - 1) * sz : lv0,
-                          eps + (size_t)t * 2 * sz, eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags, t & 1);
+    auto all_reduce = [&](float* p, size_t nfl, void* comm, hipStream_t st) -> int {
+        if (!comm) return 0;
+        VJF_NCCL(nccl().all_reduce(p, p, nfl, kNcclFloat, kNcclSum, comm, st));
+        if (fw > 1) hipLaunchKernelGGL(vjf_scale_kernel, dim3(64), dim3(256), 0, st, p, (float)fw, (int)nfl);   // (test hook: fw identical ranks)
+        return 0;
     };
     rc = check_step_args(c, B, y, u, mu0, lv0, eps, eps + sz, mu, lv);
     if (rc) return rc;
@@ -967,186 +795,42 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     if (rc) return rc;
     const int ne = c->n_ejobs, ng = c->njobs - ne;
     unsigned* fl = (unsigned*)(c->ws + c->cv.flags);
-    unsigned* k1done = fl + 16; unsigned* started = fl + 24; unsigned* pdone = fl + 32; unsigned* statc = fl + 40; unsigned* prepc = fl + 44;
-    unsigned* fdone = fl + 48; unsigned* runw = fl + VJF_CHOL_MAXBLK + 2;
+    unsigned* fdone = fl + 48;
+    const unsigned* pdone = fl + 32;
     float* stw = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
-    const int nbl = (P.n + 31) / 32;
-    // fused: ONE trial-kernel launch per step (part 3): it signals "Phi rows written" before the recognition network runs and "all
-    // rows written" before it waits for the RLS update; Phi^T Phi is reduced behind the first signal (what the Cholesky loop
-    // waits for), Phi^T dx and sum |dx|^2 behind the second (what the operand kernel needs)
-    // (without the step-ahead Gram it loses; with communicators it needs it: the early and the late statistics are summed
-    //  over the ranks separately)
-    const bool fused = c->fused_seq && (c->ahead_ok || (getenv("VJF_FUSED_SEQ") && !c->comm_a)) && (!c->comm_a || getenv("VJF_NO_FUSED_DIST") == nullptr);
-    unsigned* phic = fl + 53;
-    const unsigned npost = (unsigned)(2 * nbl + 1), nblk = (unsigned)trial_blocks(c, B), nred = (unsigned)(fused ? ne : ne + 1),
-                   nprep = (unsigned)((P.n + 15) / 16);
-    {   // ---- the persistent kernels of this sequence
-        VjfCholArgs a{};
-        a.state = c->state; a.red = rede[0]; a.red2 = rede[1]; a.gbuf = (const float*)(c->ws + c->cv.work); a.B_total = Bt; a.flags = flags;
-        a.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.work + vjf_serial_work_floats(P) * 4) : nullptr;
-        float* dinv = (float*)(c->ws + c->cv.post);
-        a.post = 1; a.dinv_out = dinv; a.ok_out = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
-        a.lscr = (float*)(c->ws + c->cv.lscr); a.flags_out = fl; a.epoch = c->epoch + 1; a.no_triclean = 1;
-        a.pscr = (float*)(c->ws + c->cv.pscr); a.self_prep = 1; a.src_state = 1;
-        a.wait_count = pdone; a.wait_target = c->post_count; a.wait_stride = npost;
-        a.stat_count = statc; a.stat_target = c->stat_count + nred; a.stat_stride = nred;
-        a.nsteps = T; a.step0 = 0;
-        if (const char* inj = getenv("VJF_DEBUG_INJECT")) { const int k = atoi(inj); if (k >= 0 && k < T) a.inject_epoch = c->epoch + 1 + (unsigned)k; }
-        VjfPostArgs pa{};
-        pa.state = c->state; pa.dinv = dinv; pa.gbuf = a.gbuf; pa.lscr = a.lscr; pa.flags = fl; pa.epoch = a.epoch; pa.status = stw;
-        pa.k1_done = k1done; pa.k1_target = c->k1_count + nblk; pa.k1_stride = nblk;
-        pa.done = pdone; pa.started = started;
-        pa.red = rede[0]; pa.red2 = rede[1]; pa.B_total = Bt; pa.fold_sigma = 1; pa.stamps = a.stamps; pa.undo_P = 1;
-        pa.prep_count = prepc; pa.prep_target = c->prep_count + nprep; pa.prep_stride = nprep;
-        pa.nsteps = T; pa.step0 = 0;
-        // ONE launch: workgroup 0 the Cholesky loop, 1 the y / W loop, 2.. the inverse loops (three streams in all: a fourth
-        // tends to share a hardware queue with the caller's stream when other libraries hold streams of their own)
-        pa.role = 2;
-        const dim3 grid(2 + 2 * nbl);
-        switch (vjf_chol_dzp(P.dz)) {
-            case 4: hipLaunchKernelGGL(vjf_rls_pair_kernel<4>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
-            case 8: hipLaunchKernelGGL(vjf_rls_pair_kernel<8>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
-            case 12: hipLaunchKernelGGL(vjf_rls_pair_kernel<12>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
-            default: hipLaunchKernelGGL(vjf_rls_pair_kernel<16>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, sc, P, a, pa); break;
-        }
-        VJF_HIP(hipGetLastError());
-        (void)sd;
-    }
-    const unsigned epoch0 = c->epoch + 1;
-    c->epoch += (unsigned)T;
-    c->start_count += npost;
-    if (!fused && (rc = launch_trial(c, args(0), 1, sa, nullptr, true))) return rc;   // prologue: forward half of step 0
-    const bool dbg_gap = getenv("VJF_DEBUG_GAPS") != nullptr;
-    timespec ts_prev{};
-    if (dbg_gap) clock_gettime(CLOCK_MONOTONIC, &ts_prev);
-    timespec tk{};
-    if (dbg_gap) clock_gettime(CLOCK_MONOTONIC, &tk);
-    auto tick = [&](const char* what, int t) {
-        if (!dbg_gap) return;
-        timespec now{};
-        clock_gettime(CLOCK_MONOTONIC, &now);
-        const double ms = (now.tv_sec - tk.tv_sec) * 1e3 + (now.tv_nsec - tk.tv_nsec) * 1e-6;
-        if (ms > 20.0) fprintf(stderr, "vjf:   %.1f ms before '%s' returned (step %d)\n", ms, what, t);
-        tk = now;
-    };
+    if ((rc = launch_trial(c, args(0), 1, sa, true))) return rc;          // prologue: forward half of step 0
     for (int t = 0; t < T; ++t) {
-        if (dbg_gap) {
-            timespec now{};
-            clock_gettime(CLOCK_MONOTONIC, &now);
-            const double ms = (now.tv_sec - ts_prev.tv_sec) * 1e3 + (now.tv_nsec - ts_prev.tv_nsec) * 1e-6;
-            if (ms > 20.0) fprintf(stderr, "vjf: host took %.1f ms to reach step %d of %d\n", ms, t, T);
-            ts_prev = now;
-        }
-        const unsigned post_before = c->post_count;                      // workgroups of post(0 .. t-1)
-        if (fused) {
-            // sa: the whole trial kernel of step t (its backward part waits in-kernel for post(t-1)).  ahead: it also writes the
-            // Phi columns of step t+1, which depend only on this step's posterior
-            const bool ahead = c->ahead_ok;
-            const unsigned phi_before = c->phi_count;
-            c->epoch_k1 = epoch0 + (unsigned)t;
-            c->k1_own_phi = (!ahead || t == 0) ? 1 : 0;
-            // (VJF_PHI_IN_K1: the trial kernel writes Phi of step t+1 itself, behind its RLS wait, instead of vjf_phi_next_kernel)
-            const bool phi_in_k1 = c->phi_in_k1;
-            if (ahead && phi_in_k1 && t + 1 < T) {
-                c->k1_next_E = (float*)(c->ws + (((t + 1) & 1) ? c->cv.E2 : c->cv.E));
-                c->k1_next_eps = eps + (size_t)(t + 1) * 2 * sz; c->k1_next_u = u ? u + (size_t)(t + 1) * su : nullptr;
-            } else { c->k1_next_E = nullptr; c->k1_next_eps = nullptr; c->k1_next_u = nullptr; }
-            tick("loop top", t);
-            rc = launch_trial(c, args(t), 3, sa, nullptr, true, t > 0 ? pdone : nullptr, post_before);
-            tick("trial kernel launch", t);
-            c->k1_next_E = nullptr; c->k1_own_phi = 1;
-            if (rc) return rc;
-            // sb: Phi^T Phi of this step behind "Phi rows written" (not ahead, or step 0) ...
-            if (!ahead || t == 0) {
-                hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)phic, phi_before + nblk, stw);
-                if ((rc = launch_gram(c, B, 0, ne, 0u, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, c->comm_b ? nullptr : statc, 1u))) return rc;
-                if (c->comm_b) {                                         // sum Phi^T Phi over the ranks, then the count
-                    VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)P.n * P.n, kNcclFloat, kNcclSum, c->comm_b, sb));
-                    hipLaunchKernelGGL(vjf_count_kernel, dim3(1), dim3(64), 0, sb, statc, nred);
-                }
-            }
-            // ... Phi^T dx and sum |dx|^2 behind "all rows written" ...
-            hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
-            if ((rc = launch_gram(c, B, c->fdx_job0, ne - c->fdx_job0, kScRls, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, nullptr, 2u))) return rc;
-            if (c->comm_b)                                               // sum [Phi^T dx | sums] over the ranks (the operand kernel follows in this stream)
-                VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_FDX, rede[t & 1] + P.red_FDX, (size_t)(P.red_len - P.red_FDX), kNcclFloat, kNcclSum, c->comm_b, sb));
-        } else {
-        // sb: statistics of step t as soon as its forward half is done ...
+        const unsigned post_before = c->post_count;                      // workgroups of the RLS updates of steps 0 .. t-1
+        // sb: RLS statistics of step t as soon as its forward half is done (a one-wavefront gate on the workgroup count: no
+        //     cross-stream event inside the loop), then -- behind W, sigma of t-1 -- P += G/v, g, and the RLS update
         hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
-        if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, nullptr, t & 1, nullptr, 0, false, c->comm_b ? nullptr : statc))) return rc;
-        }
-        if (c->comm_b && !fused) {                                       // trials are sharded over ranks: sum [G | FDX | sums]
-            VJF_NCCL(nccl().all_reduce(rede[t & 1] + P.red_G, rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), kNcclFloat, kNcclSum,
-                                       c->comm_b, sb));
-            hipLaunchKernelGGL(vjf_count_kernel, dim3(1), dim3(64), 0, sb, statc, nred);
-        }
-        if (!(fused && c->ahead_ok) || t == 0) c->stat_count += nred;   // (ahead: step t's Phi^T Phi was reduced during step t-1)
-        // ... then, behind W and sigma of step t-1 and once the Cholesky loop holds P_old in registers, the state's P and g
-        hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)pdone, post_before, (const unsigned*)runw, epoch0 + (unsigned)t, stw);
-        VJF_HIP(hipGetLastError());
-        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, prepc))) return rc;
-        c->prep_count += nprep;
-        if (fused && c->ahead_ok && t + 1 < T) {
-            // ... and Phi^T Phi of step t+1, a step early: its reduce buffer was step t-1's, free once post(t-1) is done.  Phi(t+1)
-            // itself comes from this step's posterior (vjf_phi_next_kernel, behind "rows written" and post(t-1): both are implied
-            // by the operand kernel in front of it in this stream; the rows it overwrites were last read by step t-1's Phi^T dx Gram)
-            if (c->phi_in_k1) {
-                hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)phic, c->phi_count, (const unsigned*)pdone, post_before, stw);
-            } else {
-                VjfPhiNextArgs pn{};
-                pn.state = c->state; pn.mu_t = mu + (size_t)t * sz; pn.lv_t = lv + (size_t)t * sz;
-                pn.eps_s = eps + (size_t)(t + 1) * 2 * sz; pn.u = u ? u + (size_t)(t + 1) * su : nullptr;
-                pn.E = (float*)(c->ws + (((t + 1) & 1) ? c->cv.E2 : c->cv.E)); pn.B = B;
-                const size_t lds = ((size_t)P.n * P.dxu + P.n + (size_t)P.dxu * VJF_LDT) * 4;
-                hipLaunchKernelGGL(vjf_phi_next_kernel, dim3((B + 15) / 16), dim3(256), lds, sb, P, pn);
-            }
-            if ((rc = launch_gram(c, B, 0, ne, 0u, rede[(t + 1) & 1], sb, nullptr, (t + 1) & 1, nullptr, 0, false, c->comm_b ? nullptr : statc, 1u))) return rc;
-            if (c->comm_b) {
-                VJF_NCCL(nccl().all_reduce(rede[(t + 1) & 1] + P.red_G, rede[(t + 1) & 1] + P.red_G, (size_t)P.n * P.n, kNcclFloat, kNcclSum, c->comm_b, sb));
-                hipLaunchKernelGGL(vjf_count_kernel, dim3(1), dim3(64), 0, sb, statc, nred);
-            }
-            c->stat_count += nred;
-        }
-        // sa: backward half(t); it waits in-kernel for post(t-1), whose workgroups are resident
-        c->epoch_k1 = epoch0 + (unsigned)t;
-        if (!fused && (rc = launch_trial(c, args(t), 2, sa, nullptr, false, t > 0 ? pdone : nullptr, post_before))) return rc;
-        c->post_count += npost;
-        tick("statistics stream launches", t);
+        if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, t & 1))) return rc;
+        if ((rc = all_reduce(rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), c->comm_b, sb))) return rc;   // [G | FDX | sums]
+        // sa: backward half(t) waits in-kernel for the RLS update of step t-1, behind the reloads of its forward half's rows
+        if ((rc = launch_trial(c, args(t), 2, sa, false, t > 0 ? pdone : nullptr, c->post_count))) return rc;
         if (t == 0) {
+            // the inverse workgroups write only the block-upper half of w_chol (block-lower of w_pchol): the other halves are
+            // cleared once per blob (VJF_SC_TRI_CLEAN), here behind the backward half that may still read a full w_chol
             hipLaunchKernelGGL(vjf_triclean_kernel, dim3(64), dim3(256), 0, sa, P, c->state);
             hipLaunchKernelGGL(vjf_triclean_done_kernel, dim3(1), dim3(1), 0, sa, P, c->state);
             VJF_HIP(hipGetLastError());
-            tick("triclean launches", t);
         }
-        // single rank: the SGD kernel sums the gradient slabs itself (one launch instead of reduce + SGD; VJF_NO_FUSED_SGD: two)
-        const bool fuse_sgd = !c->comm_a && getenv("VJF_NO_FUSED_SGD") == nullptr;
-        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, nullptr, t & 1, nullptr, 0, fuse_sgd))) return rc;
-        if (c->comm_a) {
-            VJF_NCCL(nccl().group_start());
-            int e1 = nccl().all_reduce(redg, redg, (size_t)P.train_len, kNcclFloat, kNcclSum, c->comm_a, sa);
-            int e2 = nccl().all_reduce(redg + P.red_SC, redg + P.red_SC, (size_t)RS_N, kNcclFloat, kNcclSum, c->comm_a, sa);
-            VJF_NCCL(nccl().group_end());
-            VJF_NCCL(e1);
-            VJF_NCCL(e2);
+        if (t > 0) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, pdone, post_before, stw);
+        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb))) return rc;
+        if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, true, nullptr, true))) return rc;
+        if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, t & 1))) return rc;
+        if (c->comm_a) {                                                   // sum the gradients and the loss sums over ranks
+            if ((rc = all_reduce(redg, (size_t)P.train_len, c->comm_a, sa))) return rc;
+            if ((rc = all_reduce(redg + P.red_SC, (size_t)RS_N, c->comm_a, sa))) return rc;
         }
-        // (t == 0: nothing of step 1 starts before the persistent workgroups are resident -- a backward half spins on them)
-        if (fuse_sgd) {
-            if (t == 0) hipLaunchKernelGGL(vjf_gate2_kernel, dim3(1), dim3(64), 0, sa, (const unsigned*)runw, epoch0, (const unsigned*)started, c->start_count, stw);
-            rc = launch_sgd(c, B, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, ne, ng, sa, t & 1);
-        } else {
-            rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, nullptr, nullptr, 0,
-                             t == 0 ? runw : nullptr, epoch0, started, c->start_count);
-        }
-        tick("gradient Gram + SGD launches", t);
+        // (the scalar workgroup ends once the RLS workgroups of step t are resident: the next backward half spins on their results
+        //  and must not take the CUs they need before they are placed)
+        rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, fl + VJF_CHOL_MAXBLK + 2, c->epoch, fl + 24, c->start_count);
         if (rc) return rc;
-        if (!fused && t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, nullptr, true))) return rc;
+        if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, true))) return rc;
     }
     VJF_HIP(hipEventRecord(c->ev_c, sb));
-    VJF_HIP(hipEventRecord(c->ev_s, sc));
-    VJF_HIP(hipEventRecord(c->ev_d, sd));
     VJF_HIP(hipStreamWaitEvent(sa, c->ev_c, 0));                           // join: the caller's stream sees the final state
-    VJF_HIP(hipStreamWaitEvent(sa, c->ev_s, 0));
-    VJF_HIP(hipStreamWaitEvent(sa, c->ev_d, 0));
     return 0;
 }
 }  // namespace
@@ -1154,6 +838,7 @@ int filter_seq_persist(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
 int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
                      const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_local: null context");
+    VJF_HIP(hipSetDevice(c->cfg.device));
     return launch_local(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags, false);
 }
 
@@ -1164,7 +849,7 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
         const float* red = (const float*)(c->ws + c->cv.red);
         int rc = launch_prep(c, B_total, loss4, flags, red, 0, c->stream);
         if (rc) return rc;
-        return launch_rls(c, B_total, flags, red, c->stream, c->stream);
+        return launch_rls(c, B_total, flags, red, c->stream, false);
     }
     if (c->plan.n > 32 * VJF_CHOL_MAXBLK) {
         // feature counts beyond one CU's LDS: clip + SGD and scalars in the prep kernel, then the RLS update as a sequence of
@@ -1235,8 +920,36 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
     return 0;
 }
 
+namespace {
+// single rank, the step as the reference runs it (model.py:206-216: gradient step and closed-form updates) on a plan the
+// one-launch route serves
+bool mega_route(const vjf_ctx* c, uint32_t flags) {
+    return c->mega_ok && c->overlap && !c->comm_a && (!c->stamps || c->stamps_keep_overlap) &&
+           (flags & (VJF_FLAG_SGD | VJF_FLAG_UPDATE | VJF_FLAG_WARM_UP)) == (VJF_FLAG_SGD | VJF_FLAG_UPDATE);
+}
+int seq_chunk() {
+    // Long sequences go in chunks: the workgroups of one launch stay resident for its whole length, and a compute kernel that
+    // stays on the device for a minute is what drivers' lockup timers are for (16384 steps ~ 1 s at config B).
+    const char* ce = getenv("VJF_SEQ_CHUNK");                              // (tests)
+    return ce && atoi(ce) >= 1 ? atoi(ce) : 16384;
+}
+}  // namespace
+
 int vjf_filter_step(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
                     const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, float* loss4, uint32_t flags) {
+    if (!c) return fail(-1, "vjf_filter_step: null context");
+    if (mega_route(c, flags) && eps_s && eps_t && eps_t == eps_s + (size_t)B * c->plan.dz)          // (the sequence layout of eps: (2, B, dz))
+        return filter_seq_mega(c, 1, B, y, u, eps_s, mu_s, lv_s, mu_t, lv_t, loss4, flags);
+    if (mega_route(c, flags)) {
+        // the two draws are separate tensors: the sequence entry point wants them adjacent -- stage them in the workspace
+        int rc = check_step_args(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t);
+        if (rc) return rc;
+        float* st = (float*)(c->ws + c->cv.DEL);                           // (B, ldD >= 2 dz) floats, unused by this route
+        const size_t sz = (size_t)B * c->plan.dz;
+        VJF_HIP(hipMemcpyAsync(st, eps_s, sz * 4, hipMemcpyDeviceToDevice, c->stream));
+        VJF_HIP(hipMemcpyAsync(st + sz, eps_t, sz * 4, hipMemcpyDeviceToDevice, c->stream));
+        return filter_seq_mega(c, 1, B, y, u, st, mu_s, lv_s, mu_t, lv_t, loss4, flags);
+    }
     int rc = vjf_filter_local(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags);
     if (rc) return rc;
     return vjf_filter_global(c, B, loss4, flags);
@@ -1247,18 +960,18 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
     if (!c) return fail(-1, "vjf_filter_seq: null context");
     if (T < 1) return fail(-23, "vjf_filter_seq: T=%d", T);
     if (!y || !eps || !mu || !lv) return fail(-1, "vjf_filter_seq: null tensor");
-    if (c->overlap && (!c->stamps || c->stamps_keep_overlap) && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP)) {
-        // Long sequences go in chunks: the persistent RLS kernels of one chunk run for its whole length, and a compute kernel
-        // that stays on the device for a minute is what drivers' lockup timers are for (16384 steps ~ 1.2 s at config B).
-        const char* ce = getenv("VJF_SEQ_CHUNK");                          // (tests)
-        const int32_t chunk = ce && atoi(ce) > 1 ? atoi(ce) : 16384;
-        const size_t sy = (size_t)B * c->plan.dy, su = (size_t)B * c->plan.du, sz = (size_t)B * c->plan.dz;
+    const size_t sy = (size_t)B * c->plan.dy, su = (size_t)B * c->plan.du, sz = (size_t)B * c->plan.dz;
+    const bool streams = c->comm_a && c->overlap && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP) &&
+                         c->fast_chol && c->post_kernels && c->mfma_trial && (!c->stamps || c->stamps_keep_overlap);
+    if (mega_route(c, flags) || streams) {
+        const int32_t chunk = seq_chunk();
         for (int32_t t0 = 0; t0 < T; t0 += chunk) {
             int32_t n = T - t0 < chunk ? T - t0 : chunk;
-            if (T - t0 - n == 1) n += 1;                                   // (no chunk of a single step)
-            int rc = filter_seq_overlap(c, n, B, y + t0 * sy, u ? u + t0 * su : nullptr, eps + (size_t)t0 * 2 * sz,
-                                        t0 ? mu + (size_t)(t0 - 1) * sz : mu0, t0 ? lv + (size_t)(t0 - 1) * sz : lv0,
-                                        mu + (size_t)t0 * sz, lv + (size_t)t0 * sz, loss ? loss + 4 * (size_t)t0 : nullptr, flags);
+            if (streams && T - t0 - n == 1) n += 1;                        // (no chunk of a single step on the three-stream route)
+            auto route = streams ? filter_seq_streams : filter_seq_mega;
+            int rc = route(c, n, B, y + t0 * sy, u ? u + t0 * su : nullptr, eps + (size_t)t0 * 2 * sz,
+                           t0 ? mu + (size_t)(t0 - 1) * sz : mu0, t0 ? lv + (size_t)(t0 - 1) * sz : lv0,
+                           mu + (size_t)t0 * sz, lv + (size_t)t0 * sz, loss ? loss + 4 * (size_t)t0 : nullptr, flags);
             if (rc) return rc;
             if (n > chunk) break;
         }
@@ -1268,8 +981,8 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
         return fail(-24, "vjf_filter_seq: with communicators only the multi-stream schedule exists (update, no warm-up, T > 1, "
                          "fast kernels); use vjf_filter_local / vjf_filter_global around your own all-reduce otherwise");
     const VjfPlan& P = c->plan;
-    const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
     const float* ms = mu0; const float* ls = lv0;
+    VJF_HIP(hipSetDevice(c->cfg.device));
     for (int t = 0; t < T; ++t) {
         // the prep kernel keeps the transposed weight copies current inside a sequence; the generic
         // serial kernel does not, so that path refreshes them every step
@@ -1280,6 +993,7 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
         rc = vjf_filter_global(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags);
         if (rc) return rc;
         ms = mu + t * sz; ls = lv + t * sz;
+        (void)P;
     }
     return 0;
 }

@@ -105,3 +105,8 @@ __global__ void vjf_loss_kernel(int mode, const float* m1, const float* lv1, con
         out[0] = (float)(t / (double)B);
     }
 }
+
+// p[0..n) *= f   (test hook of the sharded route: a one-rank communicator standing in for f identical ranks)
+__global__ void vjf_scale_kernel(float* p, float f, int n) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) p[e] *= f;
+}

@@ -361,7 +361,9 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
                 float* Pm = A.state + P.off[VJF_SLOT_W_PREC];
                 const float* G = it_red + P.red_G;
                 const float inv_v = expf(-S[P.off[VJF_SLOT_TR_LOGVAR]]);
-                for (int e = tid; e < n * n; e += VJF_POST_THREADS) Pm[e] = fmaf(-G[e], inv_v, Pm[e]);
+                // (write-through: in the one-launch route the next step's operand workgroups, on other CUs, read these rows
+                //  with no kernel boundary in between)
+                for (int e = tid; e < n * n; e += VJF_POST_THREADS) vjf_store_wt(Pm + e, fmaf(-G[e], inv_v, Pm[e]));
             }
         }
         __syncthreads();
