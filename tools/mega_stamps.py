@@ -1,0 +1,43 @@
+"""Diagnostic (not a benchmark): s_memrealtime stamps (one 100 MHz clock for the whole device) of workgroup 0 of every role of the
+one-launch route, for the last steps of a sequence at the bench configuration.  python tools/mega_stamps.py [B] [T]"""
+import ctypes, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, vjf_amd
+from vjf_amd import _native as N
+torch.manual_seed(0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+dz, dy, n = 10, 50, 200
+m = vjf_amd.VJF.make_model(dy, dz, 0, n, [128], likelihood="gaussian", noise="device")
+y = torch.randn(T + 8, B, dy, device="cuda")
+m.filter_sequence(y[:8])
+N.check(m._backend().vjf_debug_stamps(m._ctx, 2, None))
+m.filter_sequence(y[8:])
+torch.cuda.synchronize()
+ev = []
+TR = ["step start", "theta there", "features done", "recognition done", "early slab out", "RLS(t-1) there", "var+mean done", "seeds+dxt done",
+      "backward+grads done", "late slab out", "next features out", "gram: rows there", "gram: partials out", "gram: reduced",
+      "operand: inputs there", "operand: done", "sgd: late slabs there", "sgd: done", "trial: step end", "trial: deltas done", "trial: inputs in LDS", "trial: xs done", "trial: wave0 variance tiles done", "trial: rec layers done", "trial: heads partials done", "trial: xt/post/decoder done", "trial: early slab stored", "trial: panel 0 + W staged", "trial: panels 0-1 done", "trial: panels 0-5 done", "trial: panels 0-9 done"]
+for t in range(max(0, T - 6), T):
+    o = (ctypes.c_uint64 * 32)()
+    N.check(m._backend().vjf_debug_stamps(m._ctx, 128 + (t & 31), o))
+    R = list(o)
+    for i, nm in enumerate(TR):
+        if R[i]:
+            ev.append((R[i], t, ("trial: " if i < 11 else "") + nm))
+    o = (ctypes.c_uint64 * 32)()
+    N.check(m._backend().vjf_debug_stamps(m._ctx, 16 + ((t + 1) & 7), o))      # RLS loops: ring entry = epoch % 8, epoch = step + 1
+    R = list(o)
+    for nm, i in (("chol: step start (stat wait)", 0), ("chol: operands + sigma there, chain starts", 1), ("chol: factor done", 2),
+                  ("y/W: first column staged", 17), ("y/W: forward done, factor good, trial readers done", 18), ("y/W: backward done", 19),
+                  ("y/W: W stored", 20), ("y/W: sigma stored", 21)):
+        if R[i]:
+            ev.append((R[i], t, nm))
+    for k in range(7):
+        if R[9 + k]:
+            ev.append((R[9 + k], t, f"chol: column {k} done"))
+ev.sort()
+t0 = ev[0][0]
+for tt, t, nm in ev:
+    print(f"{(tt - t0) / 100.0:9.2f} us  [{t}] {nm}")
+print("status", m.status())

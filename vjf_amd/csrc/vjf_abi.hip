@@ -162,30 +162,39 @@ bool mega_plan_ok(const VjfPlan& P) {
     if (vjf_post_lds_bytes(P) > kMegaLds) return false;
     if ((size_t)vjf_mega_trial_lds(P).total * 4 > kMegaLds) return false;                 // 32 trials' working set
     if (vjf_mega_gram_lds_floats(P) * 4 > kMegaLds || vjf_mega_prep_lds_floats(P) * 4 > kMegaLds) return false;
-    if (P.dxu > 3 * P.dz) return false;                                                  // xs' of the next step parks in 3 dz rows
+    if (P.du > 16) return false;                                                         // (one element of a 32 x du tile per thread)
     if (nbl * (nbl + 1) / 2 > VJF_MG_WAVES * VJF_MG_MAXQ) return false;
     return true;
 }
 
 bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
+    // one workgroup per compute unit: the RLS loops and the operand role have fixed sizes, the rest of the chip is dealt to the
+    // trial, Gram and SGD roles roughly 128 : 64 : 32 (at 256 CUs and 4096 trials: exactly that -- one 32-trial tile per
+    // trial workgroup, 64 rows of Phi per Gram workgroup)
     const int nbl = (P.n + 31) / 32;
     m->n_rls = 2 + 2 * nbl;
     m->n_prep = (P.n + 15) / 16;
-    m->n_sgd = (P.train_len + VJF_MG_THREADS - 1) / VJF_MG_THREADS;
-    if (m->n_sgd > 32) m->n_sgd = 32;
     m->ntiles = (B + VJF_MG_TR - 1) / VJF_MG_TR;
+    const int rest = ncu - m->n_rls - m->n_prep;
+    if (rest < 3) return false;
+    int cap_t = rest * 128 / 227, cap_g = rest * 64 / 227;
+    if (cap_t < 1) cap_t = 1;
+    if (cap_g < 1) cap_g = 1;
+    if (cap_t > kMegaMaxTrialWg) cap_t = kMegaMaxTrialWg;
+    if (cap_g > kMegaMaxGramWg) cap_g = kMegaMaxGramWg;
+    m->n_trial = m->ntiles < cap_t ? m->ntiles : cap_t;
     m->n_gram = (B + VJF_MG_GROWS - 1) / VJF_MG_GROWS;
-    if (m->n_gram > kMegaMaxGramWg) m->n_gram = kMegaMaxGramWg;
-    const int avail = ncu - m->n_rls - m->n_gram - m->n_prep - m->n_sgd;
-    if (avail < 1) return false;
-    m->n_trial = m->ntiles < avail ? m->ntiles : avail;
-    if (m->n_trial > kMegaMaxTrialWg) m->n_trial = kMegaMaxTrialWg;
+    if (m->n_gram > cap_g) m->n_gram = cap_g;
+    m->n_sgd = ((P.train_len / 4) * 8 + VJF_MG_THREADS - 1) / VJF_MG_THREADS;          // 8 lanes per quad of parameters
+    const int cap_s = rest - cap_t - cap_g > 32 ? 32 : rest - cap_t - cap_g;
+    if (m->n_sgd > cap_s) m->n_sgd = cap_s;
+    if (m->n_sgd < 1) m->n_sgd = 1;
     m->gram_rows = ((B + m->n_gram - 1) / m->n_gram + 1) & ~1;
     return true;
 }
 
 struct Carve {
-    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_meta, mg_E3; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -216,7 +225,9 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
         c.mg_late = take((size_t)kMegaMaxTrialWg * ((size_t)P.train_len + 8) * 4);
         c.mg_gslab = take((size_t)kMegaMaxGramWg * (nbl * (nbl + 1) / 2) * 1024 * 4);
         c.mg_cnt = take((size_t)MG_C_WORDS * 4);
-        c.mg_stamps = take(32 * 16 * 8);
+        c.mg_stamps = take(32 * 32 * 8);
+        c.mg_meta = take((size_t)P.train_len * 8);
+        c.mg_E3 = take((size_t)max_batch * P.ldE * 4);          // third set of Phi rows (the first two: E, E2)
     }
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
@@ -357,7 +368,20 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red2, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red3, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.flags, 0, 256, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs` (host) must outlive the copy
+    std::vector<int> meta;
+    if (c->mega_ok) {                                          // per trainable element: group | index of its transposed copy
+        meta.assign((size_t)P.train_len * 2, -1);
+        for (int t = 0; t < P.n_train; ++t) {
+            const int o = P.tr_off[t] - P.train_off, rows = P.tr_rows[t], cols = P.tr_cols[t];
+            for (int el = 0; el < rows * cols; ++el) {
+                const int r = el / cols, cc = el - r * cols;
+                meta[(size_t)(o + el) * 2] = P.tr_dec[t] ? 1 : 0;
+                meta[(size_t)(o + el) * 2 + 1] = P.tr_aux[t] >= 0 ? P.tr_aux[t] + cc * P.tr_auxld[t] + P.tr_auxcol[t] + r : -1;
+            }
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs`, `meta` (host) must outlive the copies
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
     allow_lds(vjf_serial_kernel, c->lds_k2);
     allow_lds(vjf_rls_post_kernel, c->lds_post);
@@ -443,9 +467,9 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status) {
 int vjf_debug_stamps(vjf_ctx* ctx, int enable, uint64_t* out32) {
     if (!ctx) return fail(-1, "vjf_debug_stamps: null context");
     int ring = 0;
-    if (enable >= 128) {                                     // 128 + k: the one-launch route's trial-role stamps of step k % 32 (16 words)
+    if (enable >= 128) {                                     // 128 + k: the one-launch route's role stamps of step k % 32 (32 words)
         if (out32 && ctx->mega_ok) {
-            VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.mg_stamps + (size_t)((enable - 128) & 31) * 128, 128, hipMemcpyDeviceToHost, ctx->stream));
+            VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.mg_stamps + (size_t)((enable - 128) & 31) * 256, 256, hipMemcpyDeviceToHost, ctx->stream));
             VJF_HIP(hipStreamSynchronize(ctx->stream));
         }
         return 0;
@@ -727,13 +751,15 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     A.n_rls = m.n_rls; A.n_trial = m.n_trial; A.n_gram = m.n_gram; A.n_prep = m.n_prep; A.n_sgd = m.n_sgd;
     A.y = y; A.u = u; A.eps = eps; A.mu0 = mu0; A.lv0 = lv0; A.mu = mu; A.lv = lv; A.loss = loss;
     A.state = c->state; A.aux = (float*)(c->ws + c->cv.aux);
-    A.E0 = (float*)(c->ws + c->cv.E); A.E1 = (float*)(c->ws + c->cv.E2);
+    A.E[0] = (float*)(c->ws + c->cv.E); A.E[1] = (float*)(c->ws + c->cv.E2); A.E[2] = (float*)(c->ws + c->cv.mg_E3);
     A.slab_early = (float*)(c->ws + c->cv.mg_early); A.slab_late = (float*)(c->ws + c->cv.mg_late); A.gslab = (float*)(c->ws + c->cv.mg_gslab);
     A.red0 = rede[0]; A.red1 = rede[1];
     A.gbuf = (float*)(c->ws + c->cv.work);
     A.cnt = cnt; A.flags = flags;
     A.early_len = P.n * 16 + 8; A.late_len = P.train_len + 8;
     A.gram_rows = m.gram_rows;
+    A.lds_floats = (int)(kMegaLds / 4) - 8;               // (a few static words beside the dynamic region)
+    A.meta = (const int*)(c->ws + c->cv.mg_meta);
     A.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.mg_stamps) : nullptr;
     VjfCholArgs C{};
     C.state = c->state; C.red = rede[0]; C.red2 = rede[1]; C.gbuf = A.gbuf; C.B_total = B; C.flags = flags;

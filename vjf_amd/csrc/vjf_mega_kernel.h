@@ -61,38 +61,57 @@ struct VjfMegaArgs {
     const float* y; const float* u; const float* eps; const float* mu0; const float* lv0;
     float* mu; float* lv; float* loss;
     float* state; float* aux;
-    float* E0; float* E1;                             // Phi rows of even / odd events, (B, ldE)
+    float* E[3];                                      // Phi rows of event e: E[e % 3], (B, ldE)
     float* slab_early; float* slab_late; float* gslab;
     float* red0; float* red1;                         // reduce buffers of even / odd steps ([G | FDX | sums], as the RLS loops read them)
     float* gbuf;                                      // g (n, dz)
     unsigned* cnt;
     unsigned flags;
     int early_len, late_len;                          // floats per trial workgroup
+    int lds_floats;                                   // dynamic LDS of the launch (floats): decides whether the parameters are staged in it
     int gram_rows;                                    // rows of Phi per Gram workgroup (a multiple of 2)
-    unsigned long long* stamps;                       // diagnostic (null in normal runs): s_memrealtime of trial workgroup 0, 16 per step
+    const int* meta;                                  // per trainable element (2 ints): group (-1 padding, 0 recognition, 1 decoder) | index of its transposed copy in aux (-1: none)
+    unsigned long long* stamps;                       // diagnostic (null in normal runs): s_memrealtime of workgroup 0 of each role, 32 per step
 };
 
 // ---- LDS of the trial role (floats); the host uses the same function to size the launch
 struct VjfMegaTrialLds {
-    int cen, iw, in, xu, phi, act, dd, mu, lv, xt, e2, pm, dmu, dlv, dx, py, dpy, one, zero, sc, red, plv, wg, total;
+    int cen, iw, in, xu, phi, act, dd, mu, lv, xt, e2, pm, dmu, dlv, dx, xn, py, dpy, one, zero, sc, red, plv, wg, part, total;
     int nd;
+    // the optimised parameters, staged once per step when they fit (theta = 1): matrices in their torch layout [rows][ld], ld = the
+    // row length rounded up to 2 (mod 4) -- the rows an MFMA operand read walks then fall on distinct banks
+    int theta, th_w[VJF_MAX_HIDDEN], th_ldw[VJF_MAX_HIDDEN], th_head, th_ldh, th_dec, th_ldd, th_b[VJF_MAX_HIDDEN], th_bl, th_bd;
 };
-__host__ __device__ inline VjfMegaTrialLds vjf_mega_trial_lds(const VjfPlan& P) {
+__host__ __device__ inline int vjf_mega_ld(int K) { return ((K + 1) & ~3) + 2; }
+__host__ __device__ inline VjfMegaTrialLds vjf_mega_trial_lds(const VjfPlan& P, int lds_limit_floats = 0) {
     VjfMegaTrialLds l;
     const int LD = VJF_MG_LD;
     int o = 0;
     auto take = [&](int nfl) { const int at = o; o += (nfl + 3) & ~3; return at; };
-    l.cen = take(P.n * P.dxu); l.iw = take(P.n);
+    l.cen = take(((P.n + 3) & ~3) * P.dxu); l.iw = take((P.n + 3) & ~3);   // centroids transposed [dxu][n rounded to 4]
     l.in = take(P.din * LD); l.xu = take(P.dxu * LD); l.phi = take(P.n * LD); l.act = take(P.hsum * LD);
     const bool compact = P.dy >= P.hmax;              // the first delta buffer lives in the (by then dead) decoder-mean rows
     l.nd = compact ? (P.L > 1 ? 1 : 0) : (P.L > 1 ? 2 : 1);
     l.dd = take(l.nd * P.hmax * LD);
     l.mu = take(P.dz * LD); l.lv = take(P.dz * LD); l.xt = take(P.dz * LD); l.e2 = take(P.dz * LD); l.pm = take(P.dz * LD);
-    l.dmu = take(P.dz * LD); l.dlv = take(P.dz * LD); l.dx = take(P.dz * LD);
+    l.dmu = take(P.dz * LD); l.dlv = take(P.dz * LD); l.dx = take(P.dz * LD); l.xn = take(P.dxu * LD);
     l.py = take(P.dy * LD); l.dpy = take(P.dy * LD);
     l.one = take(LD); l.zero = take(LD);
     l.sc = take(VJF_MG_TR * RS_N); l.red = take(VJF_MG_WAVES * VJF_MG_TR); l.plv = take(VJF_MG_TR); l.wg = take(16);
+    // partial tiles of the K-split products (heads, pt.mean), VJF_MG_WAVES x 16 rows: in the delta buffers (free until the backward
+    // pass) or the dpy rows (free until the losses) when those are large enough, else rows of their own
+    const int alias_rows = compact ? P.dy : l.nd * P.hmax;
+    l.part = alias_rows >= VJF_MG_WAVES * 16 ? (compact ? l.dpy : l.dd) : take(VJF_MG_WAVES * 16 * LD);
     l.total = o;
+    {
+        int prev = P.din;
+        for (int k = 0; k < VJF_MAX_HIDDEN; ++k) { l.th_w[k] = l.th_ldw[k] = l.th_b[k] = 0; }
+        for (int k = 0; k < P.L; ++k) { l.th_ldw[k] = vjf_mega_ld(prev); l.th_w[k] = take(P.h[k] * l.th_ldw[k]); l.th_b[k] = take(P.h[k]); prev = P.h[k]; }
+        l.th_ldh = vjf_mega_ld(prev); l.th_head = take(2 * P.dz * l.th_ldh); l.th_bl = take(P.dz);
+        l.th_ldd = vjf_mega_ld(P.dz); l.th_dec = take(P.dy * l.th_ldd); l.th_bd = take(P.dy);
+        l.theta = (lds_limit_floats > 0 && o <= lds_limit_floats) ? 1 : 0;
+        if (l.theta) l.total = o;
+    }
     return l;
 }
 // the mu / lv / xt / e2 / pm / dmu / dlv / dx rows must be adjacent in this order (the heads write 2 dz rows at mu, the ahead
@@ -105,80 +124,106 @@ static inline size_t vjf_mega_prep_lds_floats(const VjfPlan& P) {
     return (size_t)16 * VJF_PREPG_LDP(P.n) + (size_t)P.n * 17 + (size_t)VJF_MG_WAVES * 16 * 17 + 16 * 17 + 64;
 }
 
-// acc_g(row = 4*(lane>>4)+r, col = lane&15) += sum_{k<K} Ag[k*lda + m0 + row] * Xs[k*LD + 16 g + col]   (g = 0, 1)
-// rows m0 + i >= M contribute 0.  k runs in steps of 4, the operands of 8 steps in flight while the previous 8 steps' MFMAs issue.
+// acc_g(row = 4*(lane>>4)+r, col = lane&15) += sum_{kb <= k < ke} Ag[k*lda + m0 + row] * Xs[k*LD + 16 g + col]   (g = 0, 1)
+// Rows m0 + i >= M contribute 0 (their A operand is read from a clamped address and masked).  kb is a multiple of 4.  The A operands come straight from L2 (k-major matrices: row k contiguous over the output features), 16 k-steps per batch,
+// two batches in flight: while one batch's 32 MFMAs issue the next one's loads are on their way (and the SIMD's other wavefront
+// fills what latency is left).
 __device__ __forceinline__ void mg_mma2(vjf_f32x4& acc0, vjf_f32x4& acc1, const float* __restrict__ Ag, int lda, int M, int m0,
-                                        const float* Xs, int K, int lane) {
+                                        const float* Xs, int kb, int ke, int lane) {
     constexpr int LD = VJF_MG_LD;
     const int i = lane & 15, kk = lane >> 4;
     const bool rv = (m0 + i) < M;
-    const float* ap = Ag + (rv ? m0 + i : 0) + (size_t)kk * lda;
-    const float* xp = Xs + kk * LD + i;
-    const int K32 = K & ~31;
-    int k0 = 0;
-    if (K32 > 0) {
-        float a0[8], x0[8], y0[8], a1[8], x1[8], y1[8];
+    const unsigned row = rv ? (unsigned)(m0 + i) : 0u;
+    const unsigned ulda = (unsigned)lda;
+    const float* xp = Xs + i;
+    const int nst = (ke - kb + 3) >> 2;                // k-steps
+    const int klast = ke - 1;
+    auto ld16 = [&](float (&a)[16], int s0) {          // steps s0 .. s0 + 15: clamped rows, masked at use
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { a0[q] = ap[(size_t)(4 * q) * lda]; x0[q] = xp[(4 * q) * LD]; y0[q] = xp[(4 * q) * LD + 16]; }
-        for (; k0 < K32; k0 += 64) {
-            const bool more1 = k0 + 32 < K32;
-            if (more1) {
+        for (int q = 0; q < 16; ++q) { const int k = min(kb + 4 * (s0 + q) + kk, klast); const float v = Ag[row + (unsigned)k * ulda]; a[q] = rv ? v : 0.f; }
+    };
+    auto mm16 = [&](const float (&a)[16], int s0) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { a1[q] = ap[(size_t)(k0 + 32 + 4 * q) * lda]; x1[q] = xp[(k0 + 32 + 4 * q) * LD]; y1[q] = xp[(k0 + 32 + 4 * q) * LD + 16]; }
+        for (int q = 0; q < 16; ++q) {
+            if (s0 + q < nst) {                        // (uniform)
+                const int k = kb + 4 * (s0 + q) + kk;
+                const int kc = min(k, klast);
+                const float av = k < ke ? a[q] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD + 16], acc1, 0, 0, 0);
             }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float a = rv ? a0[q] : 0.f;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x0[q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, y0[q], acc1, 0, 0, 0);
-            }
-            if (!more1) { k0 += 32; break; }
-            const bool more0 = k0 + 64 < K32;
-            if (more0) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { a0[q] = ap[(size_t)(k0 + 64 + 4 * q) * lda]; x0[q] = xp[(k0 + 64 + 4 * q) * LD]; y0[q] = xp[(k0 + 64 + 4 * q) * LD + 16]; }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float a = rv ? a1[q] : 0.f;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x1[q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, y1[q], acc1, 0, 0, 0);
-            }
-            if (!more0) { k0 += 64; break; }
         }
-    }
-    if (k0 < K) {                                      // remainder (< 32 rows): clamped addresses, masked at use
-        float ar[8], xr[8], yr[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = k0 + 4 * q + kk;
-            const bool kv = k < K;
-            const int kc = kv ? k0 + 4 * q : 0;
-            const float av = ap[(size_t)kc * lda], xv = xp[kc * LD], yv = xp[kc * LD + 16];
-            ar[q] = (rv && kv) ? av : 0.f;
-            xr[q] = kv ? xv : 0.f;
-            yr[q] = kv ? yv : 0.f;
+    };
+    if (nst <= 0) return;
+    float a0[16], a1[16];
+    ld16(a0, 0);
+    if (nst > 16) ld16(a1, 16);
+    for (int s0 = 0; s0 < nst; s0 += 32) {
+        mm16(a0, s0);
+        if (s0 + 32 < nst) ld16(a0, s0 + 32);
+        if (s0 + 16 < nst) {
+            mm16(a1, s0 + 16);
+            if (s0 + 48 < nst) ld16(a1, s0 + 48);
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (k0 + 4 * q < K) {                      // (uniform)
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[q], xr[q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[q], yr[q], acc1, 0, 0, 0);
-            }
     }
 }
+
+// The same product with the A operand in LDS: Ws is a matrix [rows][ldw] as torch stores it.
+//   TR = false: A[m][k] = Ws[(m0 + m) * ldw + k]       (out = W x:  forward products)
+//   TR = true : A[m][k] = Ws[k * ldw + m0 + m]         (out = W^T x: backward products)
+template <bool TRN>
+__device__ __forceinline__ void mg_mma2_lds(vjf_f32x4& acc0, vjf_f32x4& acc1, const float* Ws, int ldw, int M, int m0, const float* Xs,
+                                            int kb, int ke, int lane) {
+    constexpr int LD = VJF_MG_LD;
+    const int i = lane & 15, kk = lane >> 4;
+    const bool rv = (m0 + i) < M;
+    const int mi = rv ? m0 + i : 0;
+    const float* xp = Xs + i;
+    const int klast = ke - 1;
+#pragma unroll 4
+    for (int ks = kb; ks < ke; ks += 4) {
+        const int k = ks + kk, kc = min(k, klast);
+        const float w = TRN ? Ws[kc * ldw + mi] : Ws[mi * ldw + kc];
+        const float av = (rv && k < ke) ? w : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD + 16], acc1, 0, 0, 0);
+    }
+}
+
+// 16-byte write-through store (the asm store is not counted by the compiler: every hand-off drains vmcnt by hand before it signals)
+__device__ __forceinline__ void mg_st4(float* p, float x, float y, float z, float w) {
+    vjf_f32x4 o = {x, y, z, w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(o) : "memory");
+}
+
+// e / d for e d < 2^32 without the ~30-instruction integer division: one v_mul_hi_u32 with m = ceil(2^32 / d) (d >= 2)
+__device__ __forceinline__ unsigned mg_magic(unsigned d) { return d < 2 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ int mg_div(int e, unsigned m) { return m ? (int)__umulhi((unsigned)e, m) : e; }
 
 __device__ __forceinline__ float mg_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mg_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // slab entry: the first tile of a workgroup in a step stores, later tiles add (the workgroup's own bytes, all through sc1)
 __device__ __forceinline__ void mg_slab(float* p, float v, bool first) { mg_st(p, first ? v : mg_ld(p) + v); }
 
+// L2 warm-up.  Parameters that another role has just rewritten (write-through) sit in memory, and the trial workgroups of an
+// XCD all walk them in the same order at the same time: every batch of operand loads would be a miss that all of them wait
+// for together.  Instead each workgroup first touches one sixteenth of the range (16-byte loads, all in flight, nothing kept):
+// between them the 16 trial workgroups that usually share an XCD bring all of it into that XCD's L2 in ONE round trip.
+// Which workgroups share an XCD is a placement guess (blockIdx round-robin); a wrong guess costs speed, never correctness.
+__device__ __forceinline__ void mg_warm(const float* base, int nfloats, int wg, int tid) {
+    const int nq = nfloats >> 2, per = (nq + 15) >> 4, q0 = ((wg >> 3) & 15) * per;
+    for (int q = q0 + tid; q < min(nq, q0 + per); q += VJF_MG_THREADS) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * 4);
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    }
+}
+
 #define VJF_MG_STAMP(i)                                                                     \
     do {                                                                                    \
         if (A.stamps && wg == 0 && tid == 0) {                                              \
             unsigned long long t_;                                                          \
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
-            A.stamps[(size_t)(t & 31) * 16 + (i)] = t_;                                     \
+            A.stamps[(size_t)(t & 31) * 32 + (i)] = t_;                                     \
         }                                                                                   \
     } while (0)
 
@@ -217,7 +262,9 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     const float* S = A.state;
     float* SCW = A.state + P.off[VJF_SLOT_SCALARS];
     const bool warm = false;                           // (this launch only runs sgd + update without warm-up)
-    const VjfMegaTrialLds Lo = vjf_mega_trial_lds(P);
+    const unsigned m_dy = mg_magic(dy), m_dz = mg_magic(dz), m_du = mg_magic(du > 0 ? du : 1), m_q4 = mg_magic(P.ldE >> 2);
+    const VjfMegaTrialLds Lo = vjf_mega_trial_lds(P, A.lds_floats);
+    const bool tl = Lo.theta != 0;                    // the optimised parameters are staged in LDS once per step
     float* s_cen = smem + Lo.cen; float* s_iw = smem + Lo.iw;
     float* s_in = smem + Lo.in; float* s_xu = smem + Lo.xu; float* s_phi = smem + Lo.phi; float* s_act = smem + Lo.act;
     float* s_dd = smem + Lo.dd;
@@ -229,6 +276,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     const bool compact = dy >= P.hmax;
     float* s_d0 = compact ? s_py : s_dd;               // compact: written only after the losses have consumed s_py
     float* s_d1 = compact ? s_dd : s_dd + P.hmax * LD; // used only when n_hidden > 1
+    float* s_part = smem + Lo.part;                    // partial tiles of the K-split products (heads, pt.mean)
+    constexpr int part_rows = VJF_MG_WAVES * 16;
+    int mean_nsl = 1;
+    bool have_phi = false;                             // xs and Phi of the coming step are in s_xu / s_phi (single-tile workgroups)
     unsigned* cnt = A.cnt;
     const unsigned npost = (unsigned)(A.n_rls - 1);
     float* late = A.slab_late + (size_t)wg * A.late_len;
@@ -236,28 +287,41 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     int ntl = 0;
     for (int tile = wg; tile < A.ntiles; tile += A.n_trial) ++ntl;
 
-    // centroids and -1/(2 w^2): constant for the launch (functional.py:11-22)
+    // centroids (transposed: [input dim][centre], 16-byte rows) and -1/(2 w^2): constant for the launch (functional.py:11-22)
+    const int npad = (n + 3) & ~3;
     {
         const float* cen = S + P.off[VJF_SLOT_CENTROID];
         const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
-        for (int e = tid; e < n * dxu; e += NT) s_cen[e] = cen[e];
-        for (int e = tid; e < n; e += NT) { const float w = expf(lw[e]); s_iw[e] = -0.5f / (w * w); }
+        for (int e = tid; e < npad * dxu; e += NT) { const int c = e / npad, k = e - c * npad; s_cen[e] = k < n ? cen[k * dxu + c] : 0.f; }
+        for (int e = tid; e < npad; e += NT) { float v = 0.f; if (e < n) { const float w = expf(lw[e]); v = -0.5f / (w * w); } s_iw[e] = v; }
         if (tid < LD) s_zero[tid] = 0.f;
     }
     __syncthreads();
 
-    // Phi(x) of the trials of one tile from xs' rows parked at `s_xn` -> rows of Eout (write-through: the Gram role takes them)
-    auto phi_rows = [&](const float* s_xn, float* Eout, int b0, int nb) {
-        for (int b = wave; b < nb; b += NW) {
-            float* erow = Eout + (size_t)(b0 + b) * P.ldE;
-            for (int k = lane; k < P.ldE; k += 64) {
-                float v = 0.f;
-                if (k < n) {
-                    float d2 = 0.f;
-                    for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
-                    v = expf(d2 * s_iw[k]);
+    // Phi(x) of the trials of one tile from xs' rows parked at `s_xn` -> rows of Eout (16-byte write-through stores: the Gram role
+    // takes them); per element the same operations in the same order as stage 1 below: the same bits
+    auto phi_rows = [&](const float* s_xn, float* Eout, int b0, int nb, float* keep) {
+        const int q4 = P.ldE >> 2;
+        for (int e = tid; e < nb * q4; e += NT) {
+            const int b = mg_div(e, m_q4), k = (e - b * q4) * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (k < npad) {
+                float d2[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < dxu; ++c) {
+                    const float x = s_xn[c * LD + b];
+                    const float4 cc = *reinterpret_cast<const float4*>(s_cen + c * npad + k);
+                    float d;
+                    d = x - cc.x; d2[0] = fmaf(d, d, d2[0]); d = x - cc.y; d2[1] = fmaf(d, d, d2[1]);
+                    d = x - cc.z; d2[2] = fmaf(d, d, d2[2]); d = x - cc.w; d2[3] = fmaf(d, d, d2[3]);
                 }
-                mg_st(erow + k, v);
+                const float4 iw = *reinterpret_cast<const float4*>(s_iw + k);
+                v[0] = expf(d2[0] * iw.x); v[1] = k + 1 < n ? expf(d2[1] * iw.y) : 0.f;
+                v[2] = k + 2 < n ? expf(d2[2] * iw.z) : 0.f; v[3] = k + 3 < n ? expf(d2[3] * iw.w) : 0.f;
+            }
+            mg_st4(Eout + (size_t)(b0 + b) * P.ldE + k, v[0], v[1], v[2], v[3]);
+            if (keep) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (k + r < n) keep[(k + r) * LD + b] = v[r];
             }
         }
     };
@@ -272,18 +336,14 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         float* mu_t = A.mu + (size_t)t * sz;
         float* lv_t = A.lv + (size_t)t * sz;
         const bool prior = (mu_s == nullptr);
-        float* E_now = (t & 1) ? A.E1 : A.E0;
-        float* E_next = (t & 1) ? A.E0 : A.E1;
+        // Phi rows rotate through three sets: the rows written now for event t + 1 were last read by the Gram of event t - 2, which
+        // the Cholesky loop of step t - 2 waited for -- long before this step's parameters existed
+        float* E_now = A.E[t % 3];
+        float* E_next = A.E[(t + 1) % 3];
         // early slabs alternate between two sets: the operand role may read step t's long after this workgroup has started
         // step t + 1 (it also waits for the Gram of step t); step t + 2 starts behind the RLS update of step t, which consumed them
         float* early = A.slab_early + ((size_t)(t & 1) * A.n_trial + wg) * A.early_len;
         VJF_MG_STAMP(0);
-        // theta of the previous step (the SGD role's write-through stores)
-        if (t > 0 && !vjf_wg_wait(cnt + MG_C_SGD, (unsigned)t * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS)) {
-            vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
-        }
-        if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
-        VJF_MG_STAMP(1);
         if (tid < 16) s_wg[tid] = 0.f;
         float sig = 0.f, rho = 0.f;
         bool tri = false;
@@ -293,61 +353,134 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             const int b0 = tile * TR;
             const int nb = min(TR, A.B - b0);
             __syncthreads();                           // (the previous tile's readers of the LDS matrices are done)
-            // ---- stage 0: inputs (coalesced global reads, transposed LDS writes), eps_t, xs
-            for (int b = wave; b < TR; b += NW) {
-                const bool ok = b < nb;
-                const size_t g = (size_t)(b0 + b);
-                for (int c = lane; c < din; c += 64) {
-                    float v = 0.f;
-                    if (ok) {
-                        if (c < dy) v = y_t[g * dy + c];
-                        else if (c < dy + du) v = u_t[g * du + (c - dy)];
-                        else if (c < dy + du + dz) { const int j = c - dy - du; v = prior ? S[P.off[VJF_SLOT_PRIOR_MEAN] + j] : mu_s[g * dz + j]; }
-                        else { const int j = c - dy - du - dz; v = prior ? S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j] : lv_s[g * dz + j]; }
+            float v_epsn = 0.f, v_un = 0.f;
+            // ---- stage 0: inputs.  A tile's rows of y / u / mu_s / lv_s / eps are contiguous in memory: flat coalesced reads, all of a
+            //      thread's loads in flight before its first (transposed) LDS write
+            {
+                auto cell = [&](const float* src, int d, unsigned md, int e, float& v, int& at) {   // element e of a (TR, d) tile -> value, LDS offset
+                    const int b = mg_div(e, md), c2 = e - b * d;
+                    v = (src != nullptr && b < nb) ? src[(size_t)b0 * d + e] : 0.f;
+                    at = c2 * LD + b;
+                };
+                float vy[4], vs[4], vu = 0.f; int ay[4], as[4], au = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { vy[q] = 0.f; ay[q] = -1; if (tid + q * NT < TR * dy) cell(y_t, dy, m_dy, tid + q * NT, vy[q], ay[q]); }
+                const bool sm = tid < TR * dz;                                  // (dz <= 16: one element of each small tile per thread)
+                if (sm) {
+                    cell(prior ? nullptr : mu_s, dz, m_dz, tid, vs[0], as[0]);
+                    cell(prior ? nullptr : lv_s, dz, m_dz, tid, vs[1], as[1]);
+                    cell(eps_s, dz, m_dz, tid, vs[2], as[2]);
+                    cell(eps_t, dz, m_dz, tid, vs[3], as[3]);
+                    if (prior) {
+                        const int j = tid - mg_div(tid, m_dz) * dz;
+                        vs[0] = S[P.off[VJF_SLOT_PRIOR_MEAN] + j]; vs[1] = S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j];
                     }
-                    s_in[c * LD + b] = v;
                 }
-            }
-            for (int e = tid; e < TR * dz; e += NT) {
-                const int b = e / dz, j = e - b * dz;
-                s_e2[j * LD + b] = (b < nb) ? eps_t[(size_t)(b0 + b) * dz + j] : 0.f;
-                s_xt[j * LD + b] = (b < nb) ? eps_s[(size_t)(b0 + b) * dz + j] : 0.f;      // eps_s parked in s_xt
+                if (du > 0 && tid < TR * du) cell(u_t, du, m_du, tid, vu, au);
+                if (t + 1 < A.T) {                                              // (for the next step's features, formed further down)
+                    int dummy;
+                    if (sm) cell(A.eps + (size_t)(t + 1) * 2 * sz, dz, m_dz, tid, v_epsn, dummy);
+                    if (du > 0 && tid < TR * du) cell(A.u + (size_t)(t + 1) * su, du, m_du, tid, v_un, dummy);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (ay[q] >= 0) s_in[ay[q]] = vy[q];
+                if (sm) {
+                    s_in[(dy + du) * LD + as[0]] = vs[0];
+                    s_in[(dy + du + dz) * LD + as[1]] = vs[1];
+                    s_xt[as[2]] = vs[2];                                        // eps_s parked in s_xt
+                    s_e2[as[3]] = vs[3];
+                }
+                if (du > 0 && tid < TR * du) s_in[dy * LD + au] = vu;
+                for (int e0 = tid + 4 * NT; e0 < TR * dy; e0 += 4 * NT) {       // (wide observations: further rounds of four)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { vy[q] = 0.f; ay[q] = -1; if (e0 + q * NT < TR * dy) cell(y_t, dy, m_dy, e0 + q * NT, vy[q], ay[q]); }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (ay[q] >= 0) s_in[ay[q]] = vy[q];
+                }
             }
             if (tid < LD) s_one[tid] = tid < nb ? 1.f : 0.f;
             __syncthreads();
-            for (int e = tid; e < TR * dxu; e += NT) {
-                const int c = e >> 5, b = e & 31;
-                float v;
-                if (c < dz) v = fmaf(s_xt[c * LD + b], expf(0.5f * s_in[(dy + du + dz + c) * LD + b]), s_in[(dy + du + c) * LD + b]);
-                else v = s_in[(dy + c - dz) * LD + b];
-                s_xu[c * LD + b] = v;
+            if (first) VJF_MG_STAMP(20);
+            if (!have_phi) {                           // (else: xs and Phi of this step are in LDS already, see the next step's features below)
+                for (int e = tid; e < TR * dxu; e += NT) {
+                    const int c = e >> 5, b = e & 31;
+                    float v;
+                    if (c < dz) v = fmaf(s_xt[c * LD + b], expf(0.5f * s_in[(dy + du + dz + c) * LD + b]), s_in[(dy + du + c) * LD + b]);
+                    else v = s_in[(dy + c - dz) * LD + b];
+                    s_xu[c * LD + b] = v;
+                }
+                __syncthreads();
+                if (first) VJF_MG_STAMP(21);
+                // ---- stage 1: RBF features (functional.py:11-22)
+                for (int e = tid; e < TR * n; e += NT) {
+                    const int k = e >> 5, b = e & 31;
+                    float d2 = 0.f;
+                    for (int c = 0; c < dxu; ++c) { const float d = s_xu[c * LD + b] - s_cen[c * npad + k]; d2 = fmaf(d, d, d2); }
+                    s_phi[k * LD + b] = expf(d2 * s_iw[k]);
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            // ---- stage 1: RBF features (functional.py:11-22)
-            for (int e = tid; e < TR * n; e += NT) {
-                const int k = e >> 5, b = e & 31;
-                float d2 = 0.f;
-                for (int c = 0; c < dxu; ++c) { const float d = s_xu[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
-                s_phi[k * LD + b] = expf(d2 * s_iw[k]);
-            }
-            __syncthreads();
+            have_phi = false;
             if (t == 0) {                              // first step of the launch: nobody wrote this step's rows a step ahead
-                phi_rows(s_xu, E_now, b0, nb);
+                phi_rows(s_xu, E_now, b0, nb, nullptr);
                 if (last) vjf_wg_signal_wt(cnt + MG_C_PHI, tid);                   // event 0
             }
             if (first) VJF_MG_STAMP(2);
+            // ---- theta of the previous step (the SGD role's write-through stores).  Nothing above depends on it: the inputs and the
+            //      features of a step are ready before the parameters are
+            if (first && t > 0) {
+                if (!vjf_wg_wait(cnt + MG_C_SGD, (unsigned)t * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS))
+                    vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
+                if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+                if (!tl) {
+                    mg_warm(A.aux, P.aux_len, wg, tid);                        // (see mg_warm)
+                    mg_warm(S + P.train_off, P.train_len, wg, tid);
+                }
+            }
+            if (first && tl) {
+                // the parameters of this step into LDS: flat coalesced reads of each tensor, up to 8 of a thread's loads in flight
+                auto stage = [&](int slot, int rows, int cols, int at, int ld) {
+                    const float* src = S + P.off[slot];
+                    float* dst = smem + at;
+                    const unsigned mc = mg_magic(cols);
+                    for (int e0 = tid; e0 < rows * cols; e0 += 8 * NT) {
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = (e0 + q * NT < rows * cols) ? src[e0 + q * NT] : 0.f;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int e = e0 + q * NT;
+                            if (e < rows * cols) { const int r = mg_div(e, mc); dst[r * ld + (e - r * cols)] = v[q]; }
+                        }
+                    }
+                };
+                int prev = din;
+                for (int l = 0; l < P.L; ++l) {
+                    stage(VJF_SLOT_REC_W0 + 2 * l, P.h[l], prev, Lo.th_w[l], Lo.th_ldw[l]);
+                    stage(VJF_SLOT_REC_B0 + 2 * l, 1, P.h[l], Lo.th_b[l], P.h[l]);
+                    prev = P.h[l];
+                }
+                stage(VJF_SLOT_MEAN_W, dz, prev, Lo.th_head, Lo.th_ldh);
+                stage(VJF_SLOT_LV_W, dz, prev, Lo.th_head + dz * Lo.th_ldh, Lo.th_ldh);
+                stage(VJF_SLOT_LV_B, 1, dz, Lo.th_bl, dz);
+                stage(VJF_SLOT_DEC_W, dy, dz, Lo.th_dec, Lo.th_ldd);
+                stage(VJF_SLOT_DEC_B, 1, dy, Lo.th_bd, dy);
+                __syncthreads();
+            }
+            if (first) VJF_MG_STAMP(1);
             // ---- stage 3: recognition forward (recognition.py:31-42)
             {
                 const float* xin = s_in;
                 int kin = din, aoff = 0;
                 for (int l = 0; l < P.L; ++l) {
                     const float* WT = A.aux + P.aux_recT[l];                   // (kin, hl)
-                    const float* bias = S + P.off[VJF_SLOT_REC_B0 + 2 * l];
+                    const float* bias = tl ? smem + Lo.th_b[l] : S + P.off[VJF_SLOT_REC_B0 + 2 * l];
                     float* out = s_act + aoff * LD;
                     const int hl = P.h[l], mt = (hl + 15) >> 4;
                     for (int tt = wave; tt < mt; tt += NW) {
                         vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                        mg_mma2(acc0, acc1, WT, hl, hl, tt * 16, xin, kin, lane);
+                        if (tl) mg_mma2_lds<false>(acc0, acc1, smem + Lo.th_w[l], Lo.th_ldw[l], hl, tt * 16, xin, 0, kin, lane);
+                        else mg_mma2(acc0, acc1, WT, hl, hl, tt * 16, xin, 0, kin, lane);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int f = tt * 16 + 4 * (lane >> 4) + r;
@@ -361,22 +494,30 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     __syncthreads();
                     xin = out; kin = hl; aoff += hl;
                 }
+                if (first) VJF_MG_STAMP(23);
+                // heads: 2 dz <= 32 rows = at most two 16-row tiles -- the K range is split over the wavefronts, partial tiles meet in
+                // LDS (s_part: a region that is free until the losses / the backward pass) and are summed in slice order
                 const float* HT = A.aux + P.aux_headT;                         // (hL, 2dz): mean rows then logvar rows
-                const float* bl = S + P.off[VJF_SLOT_LV_B];
                 const int mt = (2 * dz + 15) >> 4;
-                for (int tt = wave; tt < mt; tt += NW) {
+                const int nsl = min(NW / mt, part_rows / (16 * mt));
+                if (wave < mt * nsl) {
+                    const int tt = wave / nsl, sl = wave - tt * nsl;
+                    const int per = (((kin + 3) >> 2) + nsl - 1) / nsl * 4;
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2(acc0, acc1, HT, 2 * dz, 2 * dz, tt * 16, xin, kin, lane);
+                    if (tl) mg_mma2_lds<false>(acc0, acc1, smem + Lo.th_head, Lo.th_ldh, 2 * dz, tt * 16, xin, sl * per, min(kin, (sl + 1) * per), lane);
+                    else mg_mma2(acc0, acc1, HT, 2 * dz, 2 * dz, tt * 16, xin, sl * per, min(kin, (sl + 1) * per), lane);
+                    float* pr = s_part + (size_t)((sl * mt + tt) * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int f = tt * 16 + 4 * (lane >> 4) + r;
-                        if (f < 2 * dz) {
-                            float* row = f < dz ? s_mu + f * LD : s_lv + (f - dz) * LD;
-                            const float bf = f >= dz ? bl[f - dz] : 0.f;
-                            row[lane & 15] = acc0[r] + bf;
-                            row[16 + (lane & 15)] = acc1[r] + bf;
-                        }
-                    }
+                    for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
+                }
+                __syncthreads();
+                if (first) VJF_MG_STAMP(24);
+                const float* bl = tl ? smem + Lo.th_bl : S + P.off[VJF_SLOT_LV_B];
+                for (int e = tid; e < TR * 2 * dz; e += NT) {
+                    const int f = e >> 5, b = e & 31;
+                    float v = 0.f;
+                    for (int sl = 0; sl < nsl; ++sl) v += s_part[(size_t)((sl * mt + (f >> 4)) * 16 + (f & 15)) * LD + b];
+                    if (f < dz) s_mu[f * LD + b] = v; else s_lv[(f - dz) * LD + b] = v + bl[f - dz];
                 }
             }
             __syncthreads();
@@ -389,7 +530,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 s_dx[j * LD + b] = b < nb ? xt - s_xu[j * LD + b] : 0.f;
             }
             for (int e = tid; e < nb * dz; e += NT) {                          // coalesced posterior stores
-                const int b = e / dz, j = e - b * dz;
+                const int b = mg_div(e, m_dz), j = e - b * dz;
                 mu_t[(size_t)(b0 + b) * dz + j] = s_mu[j * LD + b];
                 lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
             }
@@ -405,11 +546,12 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             }
             {
                 const float* CT = A.aux + P.aux_decT;                          // (dz, dy)
-                const float* d = S + P.off[VJF_SLOT_DEC_B];
+                const float* d = tl ? smem + Lo.th_bd : S + P.off[VJF_SLOT_DEC_B];
                 const int mt = (dy + 15) >> 4;
                 for (int tt = wave; tt < mt; tt += NW) {
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2(acc0, acc1, CT, dy, dy, tt * 16, s_xt, dz, lane);
+                    if (tl) mg_mma2_lds<false>(acc0, acc1, smem + Lo.th_dec, Lo.th_ldd, dy, tt * 16, s_xt, 0, dz, lane);
+                    else mg_mma2(acc0, acc1, CT, dy, dy, tt * 16, s_xt, 0, dz, lane);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int f = tt * 16 + 4 * (lane >> 4) + r;
@@ -417,6 +559,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     }
                 }
             }
+            if (first) VJF_MG_STAMP(25);
             // early slab: Phi^T dx of this tile (module.py:94), 16 features x 16 columns per MFMA tile, K = 32 trials
             {
                 const int mt = (n + 15) >> 4;
@@ -448,13 +591,32 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 s_wg[RS_SDX2] += v;
                 if (last) mg_st(early + (size_t)n * 16 + RS_SDX2, s_wg[RS_SDX2]);
             }
+            if (first) VJF_MG_STAMP(26);
             if (last) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
             if (first) VJF_MG_STAMP(4);
+            // ---- features of the NEXT step (they depend only on this posterior): xs' = mu_t + eps_s' e^{lv_t/2}, the same operations in
+            //      the same order as stages 0 / 1 of the next step.  As early as the posterior exists: the Gram role needs the rows of
+            //      every trial workgroup before it can start on the next step's Phi^T Phi, and that must be reduced before sigma of this
+            //      step lands.  The write-through row stores drain during the wait for the RLS update below.
+            if (t + 1 < A.T) {
+                // (s_xu / s_phi of this step are still needed below: the next step recomputes its features -- before its parameters
+                //  arrive, i.e. in time it would spend waiting anyway)
+                const bool keep = false;
+                float* s_xn = keep ? s_xu : smem + Lo.xn;
+                if (tid < TR * dz) { const int b = mg_div(tid, m_dz), c2 = tid - b * dz; s_xn[c2 * LD + b] = fmaf(v_epsn, expf(0.5f * s_lv[c2 * LD + b]), s_mu[c2 * LD + b]); }
+                if (du > 0 && tid < TR * du) { const int b = mg_div(tid, m_du), c2 = tid - b * du; s_xn[(dz + c2) * LD + b] = v_un; }
+                __syncthreads();
+                phi_rows(s_xn, E_next, b0, nb, keep ? s_phi : nullptr);
+                have_phi = keep;
+                if (last) vjf_wg_signal_wt(cnt + (((t + 1) & 1) ? MG_C_PHI1 : MG_C_PHI), tid);   // event t + 1
+                if (first) VJF_MG_STAMP(10);
+            }
             // ---- the RLS update of the previous step (W, w_chol, sigma: write-through stores of the RLS roles)
             if (first) {
                 if (t > 0 && !vjf_wg_wait(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
                 if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+                if (t > 0) mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
                 sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
                 rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);
                 tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;                   // w_chol known upper triangular
@@ -472,24 +634,27 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     const int tt = ntile - 1 - idx, j0 = tt * 16;
                     const int K = tri ? min(n, j0 + 16) : n;
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2(acc0, acc1, Wc, n, n, j0, s_phi, K, lane);
+                    mg_mma2(acc0, acc1, Wc, n, n, j0, s_phi, 0, K, lane);
                     v2a = fmaf(acc0[0], acc0[0], fmaf(acc0[1], acc0[1], fmaf(acc0[2], acc0[2], fmaf(acc0[3], acc0[3], v2a))));
                     v2b = fmaf(acc1[0], acc1[0], fmaf(acc1[1], acc1[1], fmaf(acc1[2], acc1[2], fmaf(acc1[3], acc1[3], v2b))));
                 }
+                if (first) VJF_MG_STAMP(22);
                 v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
                 v2b += __shfl_xor(v2b, 16, 64); v2b += __shfl_xor(v2b, 32, 64);
                 if (lane < 16) { s_red[wave * TR + lane] = v2a; s_red[wave * TR + 16 + lane] = v2b; }
+                // pt.mean: dz <= 16 rows = one tile, K = n: every wavefront takes a K slice behind its variance tiles
                 const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
-                const int mt = (dz + 15) >> 4;
-                for (int tt = NW - 1 - wave; tt < mt; tt += NW) {              // (the last wavefront has the lightest variance share)
+                const int nsl = min(NW, part_rows / 16);
+                if (wave < nsl) {
+                    const int sl = nsl - 1 - wave;                             // (the last wavefronts have the lightest variance shares)
+                    const int per = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2(acc0, acc1, Wm, dz, dz, tt * 16, s_phi, n, lane);
+                    mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, sl * per, min(n, (sl + 1) * per), lane);
+                    float* pr = s_part + (size_t)(sl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = tt * 16 + 4 * (lane >> 4) + r, b = lane & 15;
-                        if (j < dz) { s_pm[j * LD + b] = s_xu[j * LD + b] + acc0[r]; s_pm[j * LD + 16 + b] = s_xu[j * LD + 16 + b] + acc1[r]; }
-                    }
+                    for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
                 }
+                mean_nsl = nsl;
             }
             __syncthreads();
             if (last && tid == 0) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
@@ -497,6 +662,12 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 float v = 0.f;
                 for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
                 s_plv[tid] = logf(v);
+            }
+            for (int e = tid; e < TR * dz; e += NT) {
+                const int j = e >> 5, b = e & 31;
+                float v = 0.f;
+                for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
+                s_pm[j * LD + b] = s_xu[j * LD + b] + v;
             }
             __syncthreads();
             if (first) VJF_MG_STAMP(6);
@@ -557,26 +728,27 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + tid];
                 s_wg[tid] += v;
             }
-            // ---- stage 6: backward.  dxt = dpy C ; dmu += dxt ; dlv += dxt eps_t exp(lv/2)/2
+            // ---- stage 6: backward.  dxt = dpy C ; dmu += dxt ; dlv += dxt eps_t exp(lv/2)/2.  Every product whose A
+            //      operand comes from memory runs BEFORE the first gradient tile goes out: a load issued behind write-through stores
+            //      waits for them to reach memory (vmcnt counts in order).
             int gbase = 0;                                                     // running tile count: gradient tiles go round the wavefronts
             auto grad_tensor = [&](const float* D, int M, const float* Bact, int Kin, int slotW, int slotB) {
                 const int dstW = P.off[slotW] - P.train_off, dstB = slotB >= 0 ? P.off[slotB] - P.train_off : -1;
                 const int ntm = (M + 15) >> 4, ntj = (Kin + 1 + 15) >> 4;
-                for (int q = 0; q < ntm * ntj; ++q)
-                    if (((gbase + q) & (NW - 1)) == wave) {
-                        const int tm = q / ntj, tj = q - tm * ntj;
-                        mg_grad_tile(D, M, tm * 16, Bact, Kin, tj * 16, s_one, s_zero, late, dstW, Kin, dstB, first, lane);
-                    }
+                const unsigned mj = mg_magic(ntj);
+                for (int q = (wave - gbase) & (NW - 1); q < ntm * ntj; q += NW) {                   // this wavefront's tiles of the tensor
+                    const int tm = mg_div(q, mj), tj = q - tm * ntj;
+                    mg_grad_tile(D, M, tm * 16, Bact, Kin, tj * 16, s_one, s_zero, late, dstW, Kin, dstB, first, lane);
+                }
                 gbase += ntm * ntj;
             };
-            // decoder gradients need only dpy and xt (model.py:28-30): before dpy's consumers move on
-            grad_tensor(s_dpy, dy, s_xt, dz, VJF_SLOT_DEC_W, VJF_SLOT_DEC_B);
             {
                 const float* C = S + P.off[VJF_SLOT_DEC_W];                    // (dy, dz): k-major for this product
                 const int mt = (dz + 15) >> 4;
                 for (int tt = wave; tt < mt; tt += NW) {
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2(acc0, acc1, C, dz, dz, tt * 16, s_dpy, dy, lane);
+                    if (tl) mg_mma2_lds<true>(acc0, acc1, smem + Lo.th_dec, Lo.th_ldd, dz, tt * 16, s_dpy, 0, dy, lane);
+                    else mg_mma2(acc0, acc1, C, dz, dz, tt * 16, s_dpy, 0, dy, lane);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int j = tt * 16 + 4 * (lane >> 4) + r;
@@ -584,10 +756,9 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
 #pragma unroll
                             for (int g = 0; g < 2; ++g) {
                                 const int b = 16 * g + (lane & 15);
-                                const float a = g ? acc1[r] : acc0[r];
-                                const float m = (b < nb) ? 1.f : 0.f;          // (padding trials carry no gradient)
-                                s_dmu[j * LD + b] += m * a;
-                                s_dlv[j * LD + b] = fmaf(m * a * s_e2[j * LD + b], 0.5f * expf(0.5f * s_lv[j * LD + b]), s_dlv[j * LD + b]);
+                                const float a = g ? acc1[r] : acc0[r];         // (padding trials: dpy = 0, so a = 0)
+                                s_dmu[j * LD + b] += a;
+                                s_dlv[j * LD + b] = fmaf(a * s_e2[j * LD + b], 0.5f * expf(0.5f * s_lv[j * LD + b]), s_dlv[j * LD + b]);
                             }
                         }
                     }
@@ -600,52 +771,61 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 const float* Wm = S + P.off[VJF_SLOT_MEAN_W];                  // (dz, hL): k-major for dh = dmu Wm + dlv Wl
                 const float* Wl = S + P.off[VJF_SLOT_LV_W];
                 const float* hact = s_act + (P.hsum - hL) * LD;
-                // head gradients: [dmu ; dlv]^T [h_L | 1]
-                grad_tensor(s_dmu, dz, hact, hL, VJF_SLOT_MEAN_W, -1);
-                grad_tensor(s_dlv, dz, hact, hL, VJF_SLOT_LV_W, VJF_SLOT_LV_B);
-                int mt = (hL + 15) >> 4;
-                for (int tt = wave; tt < mt; tt += NW) {
-                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2(acc0, acc1, Wm, hL, hL, tt * 16, s_dmu, dz, lane);
-                    mg_mma2(acc0, acc1, Wl, hL, hL, tt * 16, s_dlv, dz, lane);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int k = tt * 16 + 4 * (lane >> 4) + r, b = lane & 15;
-                        if (k < hL) {
-                            const float h0 = hact[k * LD + b], h1 = hact[k * LD + 16 + b];
-                            s_d0[k * LD + b] = acc0[r] * (1.f - h0 * h0);
-                            s_d0[k * LD + 16 + b] = acc1[r] * (1.f - h1 * h1);
+                // dh_{l-1} = da_l W_l (1 - h_{l-1}^2)  into `dst`   (l = L: the heads)
+                auto delta = [&](int l, const float* src, float* dst) {
+                    const int hp = P.h[l - 1];
+                    int aoff = 0;
+                    for (int q = 0; q < l - 1; ++q) aoff += P.h[q];
+                    const float* hprev = s_act + aoff * LD;
+                    const int mt = (hp + 15) >> 4;
+                    for (int tt = wave; tt < mt; tt += NW) {
+                        vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                        if (l == P.L) {
+                            if (tl) {
+                                mg_mma2_lds<true>(acc0, acc1, smem + Lo.th_head, Lo.th_ldh, hL, tt * 16, s_dmu, 0, dz, lane);
+                                mg_mma2_lds<true>(acc0, acc1, smem + Lo.th_head + dz * Lo.th_ldh, Lo.th_ldh, hL, tt * 16, s_dlv, 0, dz, lane);
+                            } else {
+                                mg_mma2(acc0, acc1, Wm, hL, hL, tt * 16, s_dmu, 0, dz, lane);
+                                mg_mma2(acc0, acc1, Wl, hL, hL, tt * 16, s_dlv, 0, dz, lane);
+                            }
+                        } else if (tl) {
+                            mg_mma2_lds<true>(acc0, acc1, smem + Lo.th_w[l], Lo.th_ldw[l], hp, tt * 16, src, 0, P.h[l], lane);
+                        } else {
+                            mg_mma2(acc0, acc1, S + P.off[VJF_SLOT_REC_W0 + 2 * l], hp, hp, tt * 16, src, 0, P.h[l], lane);   // (h_l, h_{l-1}): k-major
                         }
-                    }
-                }
-                __syncthreads();
-                int aoff = P.hsum - hL;
-                float* cur = s_d0; float* nxt = s_d1;
-                for (int l = P.L - 1; l >= 0; --l) {
-                    const int hl = P.h[l];
-                    const int hp = l > 0 ? P.h[l - 1] : din;
-                    const float* hprev = l > 0 ? s_act + (aoff - hp) * LD : s_in;
-                    grad_tensor(cur, hl, hprev, hp, VJF_SLOT_REC_W0 + 2 * l, VJF_SLOT_REC_B0 + 2 * l);
-                    if (l > 0) {
-                        const float* W = S + P.off[VJF_SLOT_REC_W0 + 2 * l];   // (hl, hp): k-major for dh_{l-1} = da_l W
-                        mt = (hp + 15) >> 4;
-                        for (int tt = wave; tt < mt; tt += NW) {
-                            vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                            mg_mma2(acc0, acc1, W, hp, hp, tt * 16, cur, hl, lane);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int k = tt * 16 + 4 * (lane >> 4) + r, b = lane & 15;
-                                if (k < hp) {
-                                    const float h0 = hprev[k * LD + b], h1 = hprev[k * LD + 16 + b];
-                                    nxt[k * LD + b] = acc0[r] * (1.f - h0 * h0);
-                                    nxt[k * LD + 16 + b] = acc1[r] * (1.f - h1 * h1);
-                                }
+                        for (int r = 0; r < 4; ++r) {
+                            const int k = tt * 16 + 4 * (lane >> 4) + r, b = lane & 15;
+                            if (k < hp) {
+                                const float h0 = hprev[k * LD + b], h1 = hprev[k * LD + 16 + b];
+                                dst[k * LD + b] = acc0[r] * (1.f - h0 * h0);
+                                dst[k * LD + 16 + b] = acc1[r] * (1.f - h1 * h1);
                             }
                         }
-                        __syncthreads();
-                        float* tmp = cur; cur = nxt; nxt = tmp;
-                        aoff -= hp;
                     }
+                };
+                auto layer_grads = [&](int l, const float* da) {               // weights / bias of recognition layer l from da_l and its input
+                    int aoff = 0;
+                    for (int q = 0; q < l - 1; ++q) aoff += P.h[q];
+                    grad_tensor(da, P.h[l], l > 0 ? s_act + aoff * LD : s_in, l > 0 ? P.h[l - 1] : din, VJF_SLOT_REC_W0 + 2 * l, VJF_SLOT_REC_B0 + 2 * l);
+                };
+                delta(P.L, nullptr, s_d0);                                     // da_{L-1}
+                __syncthreads();
+                if (P.L >= 2) { delta(P.L - 1, s_d0, s_d1); __syncthreads(); } // da_{L-2}
+                if (first) VJF_MG_STAMP(19);
+                // gradient tiles (write-through stores into the workgroup's late slab)
+                grad_tensor(s_dpy, dy, s_xt, dz, VJF_SLOT_DEC_W, VJF_SLOT_DEC_B);
+                grad_tensor(s_dmu, dz, hact, hL, VJF_SLOT_MEAN_W, -1);
+                grad_tensor(s_dlv, dz, hact, hL, VJF_SLOT_LV_W, VJF_SLOT_LV_B);
+                layer_grads(P.L - 1, s_d0);
+                if (P.L >= 2) layer_grads(P.L - 2, s_d1);
+                float* cur = s_d1; float* nxt = s_d0;                          // deeper networks: the two delta buffers alternate
+                for (int l = P.L - 3; l >= 0; --l) {
+                    __syncthreads();
+                    delta(l + 1, cur, nxt);
+                    __syncthreads();
+                    layer_grads(l, nxt);
+                    float* tmp = cur; cur = nxt; nxt = tmp;
                 }
             }
             if (first) VJF_MG_STAMP(8);
@@ -656,28 +836,8 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 vjf_wg_signal_wt(cnt + MG_C_BWD, tid);
                 VJF_MG_STAMP(9);
             }
-            // ---- features of the NEXT step (they depend only on this posterior): xs' = mu_t + eps_s' e^{lv_t/2}, the same operations
-            //      in the same order as stages 0 / 1 of the next step.  Behind the RLS wait: the rows they overwrite were read by the
-            //      Gram of two events ago, which the Cholesky loop of the previous step waited for.
-            if (t + 1 < A.T) {
-                const float* eps_n = A.eps + (size_t)(t + 1) * 2 * sz;
-                const float* u_n = A.u ? A.u + (size_t)(t + 1) * su : nullptr;
-                float* s_xn = s_dmu;                                           // dxu <= 3 dz rows: dmu, dlv, dx (host checks)
-                __syncthreads();
-                for (int e = tid; e < TR * dxu; e += NT) {
-                    const int c = e >> 5, b = e & 31;
-                    const size_t g = (size_t)(b0 + (b < nb ? b : 0));
-                    float v;
-                    if (c < dz) v = fmaf(eps_n[g * dz + c], expf(0.5f * s_lv[c * LD + b]), s_mu[c * LD + b]);
-                    else v = u_n[g * du + (c - dz)];
-                    s_xn[c * LD + b] = v;
-                }
-                __syncthreads();
-                phi_rows(s_xn, E_next, b0, nb);
-                if (last) vjf_wg_signal_wt(cnt + (((t + 1) & 1) ? MG_C_PHI1 : MG_C_PHI), tid);   // event t + 1
-            }
         }
-        VJF_MG_STAMP(10);
+        VJF_MG_STAMP(18);
     }
 }
 
@@ -687,6 +847,7 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
     constexpr int NT = VJF_MG_THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = P.n, nbl = (n + 31) / 32, ntri = nbl * (nbl + 1) / 2, ldE = P.ldE;
+    const unsigned m_l4 = mg_magic(ldE >> 2);
     float* SCW = A.state + P.off[VJF_SLOT_SCALARS];
     float* s_rows = lds;                               // [VJF_MG_GROWS][ldE]
     int* s_tab = reinterpret_cast<int*>(s_rows + (size_t)VJF_MG_GROWS * ldE);   // tile -> (bi << 8) | bj
@@ -700,7 +861,7 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
     float* myslab = A.gslab + (size_t)hg * ntri * 1024;
     const int c = lane & 31, kh = lane >> 5;
     for (int e = 0; e < A.T; ++e) {
-        const float* E = (e & 1) ? A.E1 : A.E0;
+        const float* E = A.E[e % 3];
         float* red = (e & 1) ? A.red1 : A.red0;
         if (!vjf_wg_wait(A.cnt + ((e & 1) ? MG_C_PHI1 : MG_C_PHI), (unsigned)(e / 2 + 1) * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
@@ -708,6 +869,7 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         if (e > 0 && !vjf_wg_wait(A.cnt + MG_C_STAT, (unsigned)e * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+        { const int wg = hg, t = e; VJF_MG_STAMP(11); }
         vjf_f32x16 acc[VJF_MG_MAXQ];
 #pragma unroll
         for (int q = 0; q < VJF_MG_MAXQ; ++q)
@@ -716,11 +878,19 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         for (int c0 = r0; c0 < r1; c0 += VJF_MG_GROWS) {
             __syncthreads();
             const int l4 = ldE >> 2;
-            for (int idx = tid; idx < VJF_MG_GROWS * l4; idx += NT) {          // rows beyond the range: zero
-                const int r = idx / l4, q4 = idx - r * l4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 + r < r1) v = *reinterpret_cast<const float4*>(E + (size_t)(c0 + r) * ldE + 4 * q4);
-                *reinterpret_cast<float4*>(s_rows + (size_t)r * ldE + 4 * q4) = v;
+            for (int i0 = tid; i0 < VJF_MG_GROWS * l4; i0 += 8 * NT) {         // 8 float4 per thread in flight; rows beyond the range: zero
+                float4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int idx = i0 + q * NT, r = mg_div(idx, m_l4), q4 = idx - r * l4;
+                    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx < VJF_MG_GROWS * l4 && c0 + r < r1) v[q] = *reinterpret_cast<const float4*>(E + (size_t)(c0 + r) * ldE + 4 * q4);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int idx = i0 + q * NT, r = mg_div(idx, m_l4), q4 = idx - r * l4;
+                    if (idx < VJF_MG_GROWS * l4) *reinterpret_cast<float4*>(s_rows + (size_t)r * ldE + 4 * q4) = v[q];
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -741,40 +911,62 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
                 }
             }
         }
-        // partial tiles out (write-through), accumulator layout: column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        // partial tiles out, 16-byte write-through stores.  Accumulator: column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
+        // slab element ((j*64 + lane)*4 + r) = register 4 j + r of that lane
 #pragma unroll
         for (int q = 0; q < VJF_MG_MAXQ; ++q) {
             const int tt = wave + VJF_MG_WAVES * q;
             if (tt < ntri) {
                 float* sl = myslab + (size_t)tt * 1024;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) mg_st(sl + ((i & 3) + 8 * (i >> 2) + 4 * kh) * 32 + c, acc[q][i]);
+                for (int j = 0; j < 4; ++j) mg_st4(sl + (j * 64 + lane) * 4, acc[q][4 * j], acc[q][4 * j + 1], acc[q][4 * j + 2], acc[q][4 * j + 3]);
             }
         }
         vjf_wg_signal_wt(A.cnt + MG_C_GRAM, tid);
+        { const int wg = hg, t = e; VJF_MG_STAMP(12); }
         if (!vjf_wg_wait(A.cnt + MG_C_GRAM, (unsigned)(e + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
-        // this workgroup's share of the sum over the slabs, in workgroup order
-        for (int idx = hg * NT + tid; idx < ntri * 1024; idx += A.n_gram * NT) {
-            float v = 0.f;
-            int h = 0;
-            for (; h + 16 <= A.n_gram; h += 16) {
-                float tq[16];
+        // this workgroup's share of the sum over the slabs: a quad of elements per 4 lanes, lane p sums the slabs [p npq, (p+1) npq)
+        // (all of them in flight), then (s0 + s1) + (s2 + s3): a fixed order
+        {
+            const int npq = (A.n_gram + 3) >> 2;
+            const int part = tid & 3;
+            for (int quad = (hg * NT + tid) >> 2; quad < ntri * 256; quad += (A.n_gram * NT) >> 2) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* src = A.gslab + (size_t)quad * 4;
+                for (int h0 = part * npq; h0 < min(A.n_gram, (part + 1) * npq); h0 += 16) {
+                    float4 tq[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) tq[q] = A.gslab[(size_t)(h + q) * ntri * 1024 + idx];
+                    for (int q = 0; q < 16; ++q)
+                        tq[q] = (h0 + q < min(A.n_gram, (part + 1) * npq)) ? *reinterpret_cast<const float4*>(src + (size_t)(h0 + q) * ntri * 1024)
+                                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) v += tq[q];
-            }
-            for (; h < A.n_gram; ++h) v += A.gslab[(size_t)h * ntri * 1024 + idx];
-            const int tt = idx >> 10, el = idx & 1023, code = s_tab[tt];
-            const int gr = (code >> 8) * 32 + (el >> 5), gc = (code & 255) * 32 + (el & 31);
-            if (gr < n && gc <= gr) {
-                mg_st(red + P.red_G + (size_t)gr * n + gc, v);
-                mg_st(red + P.red_G + (size_t)gc * n + gr, v);
+                    for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
+                }
+                float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vv[r] += __shfl_xor(vv[r], 1, 64);
+                    vv[r] += __shfl_xor(vv[r], 2, 64);
+                }
+                if (part == 0) {
+                    const int idx = quad * 4, tt = idx >> 10, el = idx & 1023, code = s_tab[tt];
+                    const int j = el >> 8, ln = (el >> 2) & 63;
+                    const int gc = (code & 255) * 32 + (ln & 31);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gr = (code >> 8) * 32 + r + 8 * j + 4 * (ln >> 5);
+                        if (gr < n && gc <= gr) {
+                            mg_st(red + P.red_G + (size_t)gr * n + gc, vv[r]);
+                            mg_st(red + P.red_G + (size_t)gc * n + gr, vv[r]);
+                        }
+                    }
+                }
             }
         }
         vjf_wg_signal_wt(A.cnt + MG_C_STAT, tid);
+        { const int wg = hg, t = e; VJF_MG_STAMP(13); }
     }
 }
 
@@ -800,39 +992,59 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
         ok = vjf_wg_wait(runw, (unsigned)(t + 1), tid, SCW + VJF_SC_STATUS) && ok;      // the Cholesky loop holds its operands (it reads the state's P at step 0)
         if (!ok) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_OPERAND);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
-        // Phi^T dx rows i0 .. i0 + 15: sum over the trial workgroups in workgroup order
-        if (tid < 256) {
-            const int r = tid >> 4, cc = tid & 15;
-            float v = 0.f;
+        { const int wg = pw; VJF_MG_STAMP(14); }
+        // Phi^T dx rows i0 .. i0 + 15 (16 x 16 entries = 64 quads): 8 lanes per quad, lane p sums the early slabs [p npq, (p+1) npq)
+        // (all in flight), then a fixed xor tree
+        {
+            const float* base = A.slab_early + (size_t)(t & 1) * A.n_trial * A.early_len;
+            const int npq = (A.n_trial + 7) >> 3, part = tid & 7, quad = tid >> 3;      // quad = row * 4 + column quad
+            const int r = quad >> 2, c4 = (quad & 3) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i0 + r < n) {
-                const float* src = A.slab_early + (size_t)(t & 1) * A.n_trial * A.early_len + (size_t)(i0 + r) * 16 + cc;
-                int w = 0;
-                for (; w + 16 <= A.n_trial; w += 16) {
-                    float tq[16];
+                const float* src = base + (size_t)(i0 + r) * 16 + c4;
+                const int w1 = min(A.n_trial, (part + 1) * npq);
+                for (int w0 = part * npq; w0 < w1; w0 += 16) {
+                    float4 tq[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) tq[q] = src[(size_t)(w + q) * A.early_len];
+                    for (int q = 0; q < 16; ++q)
+                        tq[q] = (w0 + q < w1) ? *reinterpret_cast<const float4*>(src + (size_t)(w0 + q) * A.early_len) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) v += tq[q];
+                    for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
                 }
-                for (; w < A.n_trial; ++w) v += src[(size_t)w * A.early_len];
-                if (cc < dz) mg_st(red + P.red_FDX + (size_t)(i0 + r) * dz + cc, v);
             }
-            s_f[r * 17 + cc] = v;
-        } else if (pw == 0 && tid == 256) {
-            float v = 0.f;
-            for (int w = 0; w < A.n_trial; ++w) v += A.slab_early[((size_t)(t & 1) * A.n_trial + w) * A.early_len + (size_t)n * 16 + RS_SDX2];
-            mg_st(red + P.red_SC + RS_SDX2, v);
+            float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                vv[q] += __shfl_xor(vv[q], 1, 64);
+                vv[q] += __shfl_xor(vv[q], 2, 64);
+                vv[q] += __shfl_xor(vv[q], 4, 64);
+            }
+            if (part == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s_f[r * 17 + c4 + q] = vv[q];
+                    if (i0 + r < n && c4 + q < dz) mg_st(red + P.red_FDX + (size_t)(i0 + r) * dz + c4 + q, vv[q]);
+                }
+            }
+            if (pw == 0 && tid < 64) {                                             // sum |dx|^2: one wavefront, strided partial sums, xor tree
+                float q2 = 0.f;
+                for (int w = tid; w < A.n_trial; w += 64) q2 += base[(size_t)w * A.early_len + (size_t)n * 16 + RS_SDX2];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
+                if (tid == 0) mg_st(red + P.red_SC + RS_SDX2, q2);
+            }
         }
         const float inv_v = expf(-mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]));
         float* Pm = S + P.off[VJF_SLOT_W_PREC];
         const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
         const float* G = red + P.red_G;
         const int n4 = n >> 2;
+        const unsigned m_n4 = mg_magic(n4);
         for (int e0 = tid; e0 < 16 * n4; e0 += 4 * NT) {
             float4 p[4], g[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int e = e0 + q * NT, row = e / n4, c4 = (e - row * n4) * 4;
+                const int e = e0 + q * NT, row = mg_div(e, m_n4), c4 = (e - row * n4) * 4;
                 const bool in = e < 16 * n4 && i0 + row < n;
                 const size_t off = in ? (size_t)(i0 + row) * n + c4 : 0;
                 p[q] = *reinterpret_cast<const float4*>(Pm + off);
@@ -840,16 +1052,13 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int e = e0 + q * NT, row = e / n4, c4 = (e - row * n4) * 4;
+                const int e = e0 + q * NT, row = mg_div(e, m_n4), c4 = (e - row * n4) * 4;
                 if (e >= 16 * n4) continue;
                 const bool in = i0 + row < n;
                 float* d = s_p + row * ldp + c4;
                 d[0] = in ? p[q].x : 0.f; d[1] = in ? p[q].y : 0.f; d[2] = in ? p[q].z : 0.f; d[3] = in ? p[q].w : 0.f;
-                if (in) {
-                    float* dstp = Pm + (size_t)(i0 + row) * n + c4;
-                    mg_st(dstp, fmaf(g[q].x, inv_v, p[q].x)); mg_st(dstp + 1, fmaf(g[q].y, inv_v, p[q].y));
-                    mg_st(dstp + 2, fmaf(g[q].z, inv_v, p[q].z)); mg_st(dstp + 3, fmaf(g[q].w, inv_v, p[q].w));
-                }
+                if (in) mg_st4(Pm + (size_t)(i0 + row) * n + c4, fmaf(g[q].x, inv_v, p[q].x), fmaf(g[q].y, inv_v, p[q].y),
+                               fmaf(g[q].z, inv_v, p[q].z), fmaf(g[q].w, inv_v, p[q].w));
             }
         }
         for (int e = tid; e < n * 16; e += NT) {
@@ -879,6 +1088,7 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
             }
         }
         vjf_wg_signal_wt(A.cnt + MG_C_PREP, tid);
+        { const int wg = pw; VJF_MG_STAMP(15); }
     }
 }
 
@@ -894,6 +1104,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
         if (!vjf_wg_wait(A.cnt + MG_C_BWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
             vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
         if (vjf_abort_seen(SC + VJF_SC_STATUS)) return;
+        { const int wg = sw; VJF_MG_STAMP(16); }
         // loss sums of the step: fp64, 32 strided partial sums per scalar, then a fixed xor tree (every SGD workgroup, for the guards)
         if (tid < 32 * RS_SDX2) {
             const int sc = tid >> 5, l = tid & 31;
@@ -909,34 +1120,48 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
         if (grad_ok) {
             const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
             const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
-            for (int e = sw * NT + tid; e < P.train_len; e += A.n_sgd * NT) {
-                int tens = -1;
-                for (int q = 0; q < P.n_train; ++q) {
-                    const int o = P.tr_off[q] - P.train_off;
-                    if (e >= o && e < o + P.tr_rows[q] * P.tr_cols[q]) { tens = q; break; }
+            // a quad of parameters per 8 lanes: lane p sums the late slabs [p npq, (p+1) npq) (16-byte loads, all in flight together with
+            // the quad's old values and its table entries), then a fixed xor tree; lane 0 of the group clips and steps its four
+            // parameters (model.py:210-211)
+            const int npq = (A.n_trial + 7) >> 3;
+            const int part = tid & 7;
+            for (int quad = (sw * NT + tid) >> 3; quad < (P.train_len >> 2); quad += (A.n_sgd * NT) >> 3) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* src = A.slab_late + (size_t)quad * 4;
+                const int w1 = min(A.n_trial, (part + 1) * npq);
+                float4 wo = make_float4(0.f, 0.f, 0.f, 0.f);
+                int4 m0 = make_int4(-1, -1, -1, -1), m1 = m0;
+                if (part == 0) {
+                    wo = *reinterpret_cast<const float4*>(S + P.train_off + (size_t)quad * 4);
+                    m0 = *reinterpret_cast<const int4*>(A.meta + (size_t)quad * 8);
+                    m1 = *reinterpret_cast<const int4*>(A.meta + (size_t)quad * 8 + 4);
                 }
-                if (tens < 0) continue;                                        // (alignment padding between tensors)
-                const bool dec = P.tr_dec[tens] != 0;
-                if (dec && freeze) continue;
-                float v = 0.f;
-                int w = 0;
-                const float* src = A.slab_late + e;
-                for (; w + 16 <= A.n_trial; w += 16) {
-                    float tq[16];
+                for (int w0 = part * npq; w0 < w1; w0 += 16) {
+                    float4 tq[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) tq[q] = src[(size_t)(w + q) * A.late_len];
+                    for (int q = 0; q < 16; ++q)
+                        tq[q] = (w0 + q < w1) ? *reinterpret_cast<const float4*>(src + (size_t)(w0 + q) * A.late_len) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) v += tq[q];
+                    for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
                 }
-                for (; w < A.n_trial; ++w) v += src[(size_t)w * A.late_len];
-                float g = v * invB;
-                g = fminf(fmaxf(g, -1.f), 1.f);                                // clip_grad_value_ (model.py:210)
-                const float wn = S[P.train_off + e] - (dec ? lr_dec : lr_rec) * g;
-                mg_st(S + P.train_off + e, wn);
-                if (P.tr_aux[tens] >= 0) {
-                    const int cols = P.tr_cols[tens], rel = e - (P.tr_off[tens] - P.train_off);
-                    const int r = rel / cols, cc = rel - r * cols;
-                    mg_st(A.aux + P.tr_aux[tens] + (size_t)cc * P.tr_auxld[tens] + P.tr_auxcol[tens] + r, wn);
+                float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vv[r] += __shfl_xor(vv[r], 1, 64);
+                    vv[r] += __shfl_xor(vv[r], 2, 64);
+                    vv[r] += __shfl_xor(vv[r], 4, 64);
+                }
+                if (part != 0) continue;
+                const float wold[4] = {wo.x, wo.y, wo.z, wo.w};
+                const int grp[4] = {m0.x, m0.z, m1.x, m1.z}, ax[4] = {m0.y, m0.w, m1.y, m1.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (grp[r] < 0 || (grp[r] == 1 && freeze)) continue;        // (alignment padding between tensors; frozen decoder)
+                    float g = vv[r] * invB;
+                    g = fminf(fmaxf(g, -1.f), 1.f);                            // clip_grad_value_ (model.py:210)
+                    const float wn = wold[r] - (grp[r] == 1 ? lr_dec : lr_rec) * g;
+                    mg_st(S + P.train_off + quad * 4 + r, wn);
+                    if (ax[r] >= 0) mg_st(A.aux + ax[r], wn);
                 }
             }
         }
@@ -978,6 +1203,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
         }
         __syncthreads();
         vjf_wg_signal_wt(A.cnt + MG_C_SGD, tid);
+        { const int wg = sw; VJF_MG_STAMP(17); }
     }
     // (the launch's last act on the triangle flag: set once every SGD workgroup has cleared its share -- they all have signalled
     //  step 0 by then; the kernel boundary makes it visible to the next launch)
