@@ -121,8 +121,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="one-stream order inside filter_sequence (A/B of the schedule)")
     ap.add_argument("--config", default="B", choices=sorted(OTHER_CFGS) + ["B"],
                     help="B: the headline workload (BASELINE configs[1]); C / E: configs[2] / [4], extra lines, not the headline")
-    ap.add_argument("--serial-schedule", action="store_true",
-                    help="the multi-stream schedule's kernels on ONE stream: use under rocprofv3 --pmc, which serialises kernels")
+    ap.add_argument("--serial-schedule", action="store_true", help="(obsolete: the one-launch route is a single kernel)")
+    ap.add_argument("--streams-route", action="store_true", help="A/B: the per-step three-stream route instead of the one-launch route")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1 only: run the sharded path (local half, RCCL all-reduce, global half) with a one-rank group")
     a = ap.parse_args()
@@ -155,8 +155,8 @@ def main():
     model = vjf_amd.VJF.make_model(c["dy"], c["dz"], c["du"], c["n"], c["hidden"], likelihood=c["lik"], noise="device")
     if a.no_overlap:
         model.set_overlap(False)
-    if a.serial_schedule:
-        model.set_overlap(2)
+    if a.streams_route:
+        model.set_overlap(3)
     y = synth_data(c, T, 1234 + rank, dev)                      # each rank filters its own trials
     eps = torch.randn(T, 2, c["B"], c["dz"], device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + rank))
 

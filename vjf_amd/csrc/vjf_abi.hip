@@ -265,6 +265,7 @@ struct vjf_ctx {
     size_t lds_chol;
     int n_ejobs;           // jobs [0, n_ejobs) are the E^T E tiles, the rest gradient tiles
     bool overlap;          // 1: single rank -> the one-launch route, ranks -> the three-stream per-step route; 0: one-stream order
+    bool force_streams;    // vjf_set_overlap(ctx, 3): the three-stream per-step route on a single rank too (A/B measurements)
     bool mega_ok;          // the plan fits the one-launch route (vjf_mega_kernel.h)
     int ncu;               // compute units of the device: the one-launch grid has one workgroup per CU
     hipStream_t stream2, stream3;
@@ -349,7 +350,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->mfma_trial = c->lds_k1m <= kMaxLds - 1024;
     c->n_ejobs = 0;
     for (const VjfJob& j : jobs) c->n_ejobs += j.kind == 0;
-    c->overlap = true;
+    c->overlap = true; c->force_streams = false;
     c->mega_ok = mega_plan_ok(P);
     {
         int v = 0;
@@ -416,7 +417,8 @@ int vjf_ctx_destroy(vjf_ctx* ctx) {
 int vjf_set_overlap(vjf_ctx* ctx, int enable) {
     if (!ctx) return fail(-1, "vjf_set_overlap: null context");
     ctx->overlap = enable != 0;
-    return ctx->overlap ? 1 : 0;
+    ctx->force_streams = enable == 3;
+    return ctx->overlap ? (ctx->force_streams ? 3 : 1) : 0;
 }
 
 int vjf_comm_unique_id(void* ids256) {
@@ -950,7 +952,7 @@ namespace {
 // single rank, the step as the reference runs it (model.py:206-216: gradient step and closed-form updates) on a plan the
 // one-launch route serves
 bool mega_route(const vjf_ctx* c, uint32_t flags) {
-    return c->mega_ok && c->overlap && !c->comm_a && (!c->stamps || c->stamps_keep_overlap) &&
+    return c->mega_ok && c->overlap && !c->comm_a && !c->force_streams && (!c->stamps || c->stamps_keep_overlap) &&
            (flags & (VJF_FLAG_SGD | VJF_FLAG_UPDATE | VJF_FLAG_WARM_UP)) == (VJF_FLAG_SGD | VJF_FLAG_UPDATE);
 }
 int seq_chunk() {
@@ -987,7 +989,7 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
     if (T < 1) return fail(-23, "vjf_filter_seq: T=%d", T);
     if (!y || !eps || !mu || !lv) return fail(-1, "vjf_filter_seq: null tensor");
     const size_t sy = (size_t)B * c->plan.dy, su = (size_t)B * c->plan.du, sz = (size_t)B * c->plan.dz;
-    const bool streams = c->comm_a && c->overlap && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP) &&
+    const bool streams = (c->comm_a || c->force_streams) && c->overlap && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP) &&
                          c->fast_chol && c->post_kernels && c->mfma_trial && (!c->stamps || c->stamps_keep_overlap);
     if (mega_route(c, flags) || streams) {
         const int32_t chunk = seq_chunk();

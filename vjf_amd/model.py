@@ -285,7 +285,7 @@ class VJF(Module):
     def set_overlap(self, enable: bool = True):
         """filter_sequence runs a step's RLS chain on a second stream beside the trial / SGD chain (default);
         False forces the one-stream order.  Results are bit-identical either way."""
-        self._overlap = int(enable) if enable in (0, 1, 2, True, False) else 1     # 2: same schedule on one stream (profilers)
+        self._overlap = int(enable) if enable in (0, 1, 2, 3, True, False) else 1     # 3: the per-step three-stream route on one rank
         if self._ctx is not None:
             rc = self._backend().vjf_set_overlap(self._ctx, int(self._overlap))       # returns the resulting setting
             if rc < 0:
