@@ -134,8 +134,16 @@ def init_state(ydim, xdim, udim, n_rbf, hidden, likelihood, rng: np.random.Gener
 
 
 # --------------------------------------------------------------------------- operators
+RBF_GEMM = False      # bench.py's cpu_baseline leg sets this: squared distances by the matmul expansion, as torch.cdist computes them
+                      # for more than 25 rows (vjf/functional.py:20) -- one BLAS call instead of a pass per input dimension
+
+
 def rbf(x: np.ndarray, c: np.ndarray, w: np.ndarray) -> np.ndarray:
     """Gaussian radial basis features  exp(-1/2 (|x-c|/w)^2)   (vjf/functional.py:11-22)."""
+    if RBF_GEMM:
+        d2 = (x * x).sum(1)[:, None] + (c * c).sum(1)[None, :] - 2.0 * (x @ c.T)
+        np.maximum(d2, 0.0, out=d2)
+        return np.exp(-0.5 * d2 / (w * w)[None, :]).astype(x.dtype)
     d2 = np.zeros((x.shape[0], c.shape[0]), x.dtype)
     for j in range(x.shape[1]):                  # one (batch, basis) pass per input dimension: no 3-D temporary
         diff = x[:, j:j + 1] - c[None, :, j]

