@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""Headline benchmark: VJF online filtering step throughput (trial-timesteps/sec).
+"""Headline benchmark: VJF online filtering step throughput (trial-timesteps/sec) + ELBO.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d "config B"): 4096 trials per GPU, d_z=10,
-d_y=50, 200 RBF centres, recognition hidden=[128], Gaussian likelihood, fp32, synthetic "RBF
-data", explicit pre-drawn noise, sgd=True / update=True / warm_up=False.  One "step" = one
-VJF.filter call on the whole batch (all kernels of the step, incl. the serial RLS update).
-With N > 1 GPUs the trials are sharded (4096 per GPU, weak scaling) with one RCCL all-reduce of
-the gradient / RLS-statistics buffer per step.
+Workload (BASELINE.json configs[1], SURVEY.md 8d "config B"): 4096 trials per GPU, d_z=10, d_y=50, 200 RBF centres,
+recognition hidden=[128], Gaussian likelihood, fp32, synthetic "RBF data", explicit pre-drawn noise, sgd=True / update=True /
+warm_up=False.  One "step" = one VJF.filter call on the whole batch (everything of the step, incl. the serial RLS update).
+W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize -> `value`.  After that region the
+sequence continues for --repeats - 1 further regions of K steps (reported as `ms_per_step_repeats` with their median: the
+spread of the measurement; they do not enter `value`).  The ELBO of the first timed steps is compared with the
+fp64 oracle run from the model's own state on the same inputs (after the timed region).  With N > 1 GPUs the trials are
+sharded (4096 per GPU, weak scaling); the sums over trials go through RCCL inside the step.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import copy
 import json
 import os
 import sys
@@ -27,15 +30,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CFG = dict(B=4096, dz=10, dy=50, du=0, n=200, hidden=[128], lik="gaussian")     # BASELINE.json configs[1]: the headline workload
-OTHER_CFGS = {"C": dict(B=4096, dz=10, dy=200, du=0, n=200, hidden=[128], lik="poisson"),          # configs[2]
-              "E": dict(B=4096, dz=64, dy=512, du=0, n=1000, hidden=[512, 512], lik="gaussian")}   # configs[4]
-# torch.distributed is the control plane only (rendezvous, barrier, max of the wall times, the RCCL ids): the data path's two
-# all-reduces per step are RCCL calls inside vjf_filter_seq on its own streams
+CFGS = {"A": dict(B=1, dz=3, dy=10, du=0, n=100, hidden=[20], lik="gaussian"),                     # configs[0]: one Lorenz trial (plumbing)
+        "B": dict(B=4096, dz=10, dy=50, du=0, n=200, hidden=[128], lik="gaussian"),                # configs[1]: the headline workload
+        "C": dict(B=4096, dz=10, dy=200, du=0, n=200, hidden=[128], lik="poisson"),                # configs[2]
+        "E": dict(B=4096, dz=64, dy=512, du=0, n=1000, hidden=[512, 512], lik="gaussian")}         # configs[4]
+CFG_INDEX = dict(A=0, B=1, C=2, E=4)
+# torch.distributed is the control plane only (rendezvous, barrier, max of the wall times, the RCCL ids)
 CTRL_BACKEND = os.environ.get("VJF_BENCH_BACKEND", "nccl")
-PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 vector == f32 MFMA peak
+PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 vector == f32 MFMA peak (v_mfma_f32_*_f32 is exact fp32 at that rate)
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic_current.json")   # tools/pmc_traffic.sh on this build
+ELBO_RTOL = 5e-5             # tolerance of the parity tests (fp32 device path against the fp64 oracle)
+# measured by the survey on the UNMODIFIED reference, 8 Xeon cores, torch CPU fp32: trial-timesteps/s
+REFERENCE_CPU = {"A": {"as_is": 533}, "B": {"as_is": 96700, "with_O(B)_variance": 256600},
+                 "C": {"as_is": 109900, "with_O(B)_variance": 336500}, "E": {"as_is": 393, "with_usable_rbf_init": 25100}}
 
 
 def algorithmic_work(c):
@@ -53,8 +60,8 @@ def algorithmic_work(c):
     return flops, bytes_trial, bytes_shared, serial_flops
 
 
-def synth_data(c, T, seed, device):
-    """'RBF data' of SURVEY.md 8d: x[t+1] = x[t] + Phi_true(x[t]) W_true + 0.1 xi, y = x C + d + 0.1 N(0,1)."""
+def synth_data(c, T, seed, device, config):
+    """config A: one z-scored Lorenz trial; else the 'RBF data' of SURVEY.md 8d.  y = x C + d + 0.1 N(0,1) (script/example.py:23-33)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     B, dz, dy = c["B"], c["dz"], c["dy"]
     cen = (torch.rand(50, dz, generator=g) * 4 - 2).to(device)
@@ -62,6 +69,10 @@ def synth_data(c, T, seed, device):
     C = torch.randn(dz, dy, generator=g).to(device)
     d = torch.randn(dy, generator=g).to(device)
     gd = torch.Generator(device=device).manual_seed(seed + 1)
+    if config == "A":
+        from vjf_amd.data import lorenz
+        x = lorenz(T).float().to(device)[:, None, :]
+        return x @ C + d + 0.1 * torch.randn(T, B, dy, device=device, generator=gd)
     x = torch.randn(B, dz, device=device, generator=gd)
     y = torch.empty(T, B, dy, device=device)
     w2 = float(dz)
@@ -74,57 +85,67 @@ def synth_data(c, T, seed, device):
     return y
 
 
-def cpu_baseline(c, y_cpu, eps_cpu, budget_s=15.0):
-    """The numpy oracle (a port of the reference's step, O(B) variance form) timed on the host cores
-    on a bounded sample of the same workload; plus a short faithful-cost (B x B) sample."""
+def cpu_baseline(c, config, s32, q0, y_cpu, eps_cpu, budget_s=12.0):
+    """The oracle -- a numpy/BLAS port of the reference's step, started from the SAME state and inputs as the timed GPU run, in
+    fp32 as the reference runs -- timed on this box's host cores on a bounded sample: the O(B) variance form (row sums of squares,
+    squared distances by one GEMM as torch.cdist does), then two steps of the reference's own cost form (the (B, B) product whose
+    diagonal vjf/module.py:76 takes)."""
     from oracle import vjf_oracle as orc
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count() or 1
-    rng = np.random.default_rng(0)
-    s = orc.init_state(c["dy"], c["dz"], c["du"], c["n"], c["hidden"], c["lik"], rng, dtype=np.float32)
-    mu = lv = None
-    t0 = time.perf_counter()
-    o = orc.filter_step(s, y_cpu[0], None, mu, lv, eps_cpu[0, 0], eps_cpu[0, 1])      # discard step 0 (allocator warm-up)
-    mu, lv = o.mu_t, o.lv_t
-    o = orc.filter_step(s, y_cpu[1], None, mu, lv, eps_cpu[1, 0], eps_cpu[1, 1])
-    mu, lv = o.mu_t, o.lv_t
-    t1 = (time.perf_counter() - t0) / 2
-    nstep = int(min(max(budget_s / max(t1, 1e-4), 5), y_cpu.shape[0] - 4))
-    t0 = time.perf_counter()
-    for t in range(2, 2 + nstep):
-        o = orc.filter_step(s, y_cpu[t], None, mu, lv, eps_cpu[t, 0], eps_cpu[t, 1])
-        mu, lv = o.mu_t, o.lv_t
-    dt = time.perf_counter() - t0
-    val = c["B"] * nstep / dt
-    t0 = time.perf_counter()
-    nf = 2
-    for t in range(2 + nstep, 2 + nstep + nf):
-        o = orc.filter_step(s, y_cpu[t], None, mu, lv, eps_cpu[t, 0], eps_cpu[t, 1], faithful_cost=True)
-        mu, lv = o.mu_t, o.lv_t
-    dtf = time.perf_counter() - t0
+    s = copy.deepcopy(s32)
+    mu, lv = (None, None) if q0 is None else (q0[0].astype(np.float32), q0[1].astype(np.float32))
+    y_cpu, eps_cpu = y_cpu.astype(np.float32), eps_cpu.astype(np.float32)
+    orc.RBF_GEMM = True
+    try:
+        t0 = time.perf_counter()
+        for t in range(2):                                       # discard two steps (allocator / thread-pool warm-up)
+            o = orc.filter_step(s, y_cpu[t], None, mu, lv, eps_cpu[t, 0], eps_cpu[t, 1])
+            mu, lv = o.mu_t, o.lv_t
+        t1 = (time.perf_counter() - t0) / 2
+        nstep = int(min(max(budget_s / max(t1, 1e-5), 5), y_cpu.shape[0] - 5))
+        t0 = time.perf_counter()
+        for t in range(2, 2 + nstep):
+            o = orc.filter_step(s, y_cpu[t], None, mu, lv, eps_cpu[t, 0], eps_cpu[t, 1])
+            mu, lv = o.mu_t, o.lv_t
+        dt = time.perf_counter() - t0
+        val = c["B"] * nstep / dt
+        nf = 2
+        t0 = time.perf_counter()
+        for t in range(2 + nstep, 2 + nstep + nf):
+            o = orc.filter_step(s, y_cpu[t], None, mu, lv, eps_cpu[t, 0], eps_cpu[t, 1], faithful_cost=True)
+            mu, lv = o.mu_t, o.lv_t
+        dtf = time.perf_counter() - t0
+    finally:
+        orc.RBF_GEMM = False
+    ref = REFERENCE_CPU.get(config, {})
     return {"value": val, "unit": "trial-timesteps/s", "cores": int(threads), "kind": "port",
-            "sample": f"{nstep} steps of the bench workload (B={c['B']}, fp32 numpy/OpenBLAS oracle, O(B) variance form), "
-                      f"{dt:.1f} s; faithful-cost (B x B product, as the reference computes it): "
-                      f"{c['B'] * nf / dtf:.0f} trial-timesteps/s over {nf} steps"}
+            "sample": f"{nstep} steps of the bench workload from the timed run's own state (B={c['B']}, fp32 numpy/BLAS oracle, O(B) variance "
+                      f"form, GEMM distances), {dt:.1f} s; the reference's cost form ((B,B) product for its diagonal): "
+                      f"{c['B'] * nf / dtf:.0f} trial-timesteps/s over {nf} steps; the UNMODIFIED reference (torch CPU) on the survey's 8 Xeon "
+                      f"cores, BASELINE.md section 2: {json.dumps(ref)}",
+            "reference_cost_form_value": c["B"] * nf / dtf, "reference_measured_8_xeon_cores": ref}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="regions of --steps steps each (the sequence continues): the first is `value`, "
+                                                           "all are listed with their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--breakdown-steps", type=int, default=20)
-    ap.add_argument("--no-overlap", action="store_true", help="one-stream order inside filter_sequence (A/B of the schedule)")
-    ap.add_argument("--config", default="B", choices=sorted(OTHER_CFGS) + ["B"],
-                    help="B: the headline workload (BASELINE configs[1]); C / E: configs[2] / [4], extra lines, not the headline")
-    ap.add_argument("--serial-schedule", action="store_true", help="(obsolete: the one-launch route is a single kernel)")
+    ap.add_argument("--no-elbo-check", action="store_true")
+    ap.add_argument("--elbo-steps", type=int, default=10)
+    ap.add_argument("--no-overlap", action="store_true", help="A/B: the per-step kernels in the one-stream order")
     ap.add_argument("--streams-route", action="store_true", help="A/B: the per-step three-stream route instead of the one-launch route")
+    ap.add_argument("--config", default="B", choices=sorted(CFGS),
+                    help="B: the headline workload (BASELINE configs[1]); A / C / E: configs[0] / [2] / [4], extra lines, not the headline")
     ap.add_argument("--force-dist", action="store_true",
-                    help="N = 1 only: run the sharded path (local half, RCCL all-reduce, global half) with a one-rank group")
+                    help="N = 1 only: run the sharded route (RCCL communicators inside the context) with a one-rank group")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,23 +162,29 @@ def main():
     elif a.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ["VJF_FORCE_DIST"] = "1"
         dist.init_process_group(CTRL_BACKEND, rank=0, world_size=1, **({"device_id": dev} if CTRL_BACKEND == "nccl" else {}))
 
     import vjf_amd
-    from vjf_amd import _native as N
-    c = dict(CFG if a.config == "B" else OTHER_CFGS[a.config])
-    K, W = a.steps, a.warmup
-    if a.config == "E" and a.steps == 500:
-        K, W = 40, 5                                            # ms-scale steps: keep the default run short
-    T = W + K
-    torch.manual_seed(0)                                       # identical parameters on every rank
+    c = dict(CFGS[a.config])
+    K, W, R = a.steps, a.warmup, max(1, a.repeats)
+    if a.config == "E" and a.steps == 200:
+        K, W, R = 40, 5, 3                                      # ms-scale steps: keep the default run short
+    if a.config == "A" and a.steps == 200:
+        K = 2000                                                # T_meas = 2000 for the single-trial configuration
+    T = W + K * R
+    torch.manual_seed(0)                                        # identical parameters on every rank
     model = vjf_amd.VJF.make_model(c["dy"], c["dz"], c["du"], c["n"], c["hidden"], likelihood=c["lik"], noise="device")
+    if c["dz"] >= 32:      # the default RBF init underflows every feature at d_z = 64: SURVEY 8d's init
+        r = float(np.sqrt(c["dz"]))
+        model.transition.velocity.feature.centroid.uniform_(-r, r)
+        model.transition.velocity.feature.logwidth.fill_(float(np.log(r)))
     if a.no_overlap:
         model.set_overlap(False)
     if a.streams_route:
         model.set_overlap(3)
-    y = synth_data(c, T, 1234 + rank, dev)                      # each rank filters its own trials
+    y = synth_data(c, T, 1234 + rank, dev, a.config)            # each rank filters its own trials
     eps = torch.randn(T, 2, c["B"], c["dz"], device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + rank))
 
     def barrier():
@@ -166,52 +193,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up (untimed): also sizes the context and, for N > 1, the RCCL communicator
+    # warm-up (untimed): also sizes the context and, for N > 1, the RCCL communicators
     q = None
     if W > 0:
         mu, lv, _ = model.filter_sequence(y[:W], eps=eps[:W])
         q = vjf_amd.Gaussian(mu[-1], lv[-1])
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    mu, lv, loss = model.filter_sequence(y[W:], qs=q, eps=eps[W:])
-    enq = time.perf_counter() - t0                             # host time to enqueue the K steps (asynchronous launches)
-    ev1.record()
-    barrier()
-    wall = time.perf_counter() - t0
-    dev_s = ev0.elapsed_time(ev1) * 1e-3
-    tt = torch.tensor([wall], device=dev if CTRL_BACKEND == "nccl" else "cpu", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    wall_max = float(tt.item())
+    # the oracle's copies of the state the timed region starts from (the checker of the ELBO and the CPU baseline; nothing of the
+    # timed path goes through them)
+    checker = rank == 0 and world == 1 and not (a.no_elbo_check and a.no_cpu_baseline)
+    s64 = s32 = None
+    q0 = None if q is None else (q.mean.cpu().numpy().astype(np.float64), q.logvar.cpu().numpy().astype(np.float64))
+    if checker:
+        from tests.helpers import load_oracle_state
+        s64, s32 = load_oracle_state(model, np.float64), load_oracle_state(model, np.float32)
+    walls, devs, enqs, elbos, first_losses = [], [], [], [], None
+    stream = torch.cuda.current_stream()                         # the stream vjf_filter_seq launches on (vjf_set_stream)
+    for r in range(R):
+        lo = W + r * K
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        mu, lv, loss = model.filter_sequence(y[lo:lo + K], qs=q, eps=eps[lo:lo + K])
+        enq = time.perf_counter() - t0                           # host time to enqueue the K steps (asynchronous)
+        ev1.record(stream)
+        barrier()
+        wall = time.perf_counter() - t0
+        tt = torch.tensor([wall], device=dev if CTRL_BACKEND == "nccl" else "cpu", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        walls.append(float(tt.item())); devs.append(ev0.elapsed_time(ev1) * 1e-3); enqs.append(enq)
+        elbos.append(float(-loss[:, 0].mean().item()))
+        if r == 0:
+            first_losses = loss[:min(a.elbo_steps, K)].cpu().numpy().astype(np.float64)
+        q = vjf_amd.Gaussian(mu[-1], lv[-1])
     status = model.status()
-    elbo = float(-loss[:, 0].mean().item())
+    wall_max, dev_s, enq = walls[0], devs[0], enqs[0]           # `value`: the first region = exactly K steps after W warm-up steps
 
-    # per-half breakdown on the same stream, outside the timed region
-    nb = a.breakdown_steps
-    loc = glob = 0.0
-    if nb > 0 and world == 1:
-        model._ensure_ctx(c["B"])
-        L, ctx = model._backend(), model._ctx
-        flags = N.FLAG_SGD | N.FLAG_UPDATE
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        loss4 = torch.empty(4, device=dev)
-        ms, ls = mu[-1].clone(), lv[-1].clone()
-        mo, lo = torch.empty_like(ms), torch.empty_like(ls)
-        for t in range(nb):
-            tt_ = W + (t % K)
-            e[0].record()
-            N.check(L.vjf_filter_local(ctx, c["B"], N.ptr(y[tt_]), None, N.ptr(ms), N.ptr(ls), N.ptr(eps[tt_, 0]), N.ptr(eps[tt_, 1]),
-                                       N.ptr(mo), N.ptr(lo), flags))
-            e[1].record()
-            N.check(L.vjf_filter_global(ctx, c["B"], N.ptr(loss4), flags))
-            e[2].record()
-            torch.cuda.synchronize()
-            loc += e[0].elapsed_time(e[1])
-            glob += e[1].elapsed_time(e[2])
-            ms, ls = mo.clone(), lo.clone()
-        loc, glob = loc / nb * 1e3, glob / nb * 1e3      # us
+    # ELBO of the first timed steps against the oracle on identical state / inputs / noise
+    elbo_check = None
+    if s64 is not None and not a.no_elbo_check:
+        from oracle import vjf_oracle as orc
+        s = copy.deepcopy(s64)
+        om, ol = (None, None) if q0 is None else q0
+        ne = first_losses.shape[0]
+        ref = np.empty(ne)
+        yc, ec = y[W:W + ne].cpu().numpy().astype(np.float64), eps[W:W + ne].cpu().numpy().astype(np.float64)
+        for t in range(ne):
+            o = orc.filter_step(s, yc[t], None, om, ol, ec[t, 0], ec[t, 1])
+            om, ol = o.mu_t, o.lv_t
+            ref[t] = o.loss
+        rel = float(np.max(np.abs(first_losses[:, 0] - ref) / np.maximum(np.abs(ref), 1e-12)))
+        elbo_check = {"steps": int(ne), "max_rel_err": rel, "rtol": ELBO_RTOL, "elbo_gpu": float(-first_losses[:, 0].mean()),
+                      "elbo_oracle_fp64": float(-ref.mean()), "ok": bool(rel < ELBO_RTOL)}
 
     if rank == 0:
         flops, b_trial, b_shared, serial_flops = algorithmic_work(c)
@@ -220,53 +255,54 @@ def main():
         step_s = dev_s / K
         ach_tf = (flops * c["B"] + serial_flops) / step_s / 1e12
         ach_gbs = (b_trial * c["B"] + b_shared) / step_s / 1e9
-        traffic = None
-        try:                                                    # HBM bytes per step from the committed PMC run of this build
-            traffic = float(json.load(open(TRAFFIC_FILE))["bytes_per_step_corrected"])
+        traffic = traffic_note = None
+        try:                                                    # HBM-side bytes per step from the committed PMC passes of this build
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            traffic, traffic_note = float(tj["bytes_per_step_corrected"]), tj.get("note")
         except Exception:
             pass
         kstats = None
-        try:                                                    # per-kernel averages of the committed rocprofv3 --stats run of this build
+        try:                                                    # the committed rocprofv3 --kernel-trace --stats summary of this build
             import csv
-            import re
-            ks = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_kernel_stats.csv")),
-                        key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])     # r01_v10 after r01_v9
-            rows = list(csv.DictReader(open(ks[-1])))
-            # (one operand kernel / Cholesky / serial kernel per step; the persistent RLS kernels are one launch per sequence)
-            steps_in_profile = max(int(r["Calls"]) for r in rows if "prepg" in r["Name"] or "chol" in r["Name"] or "serial" in r["Name"])
-            kstats = {"file": "profiles/" + os.path.basename(ks[-1]),
-                      "kernels": [{"name": r["Name"].split("(")[0].replace("void ", ""), "avg_us": float(r["AverageNs"]) / 1e3,
-                                   "launches_per_step": round(int(r["Calls"]) / steps_in_profile, 2)}
-                                  for r in rows if int(r["Calls"]) >= steps_in_profile]}
+            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv"))))
+            meta = json.load(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_meta.json")))
+            kstats = {"file": "profiles/r02_kernel_stats.csv", "command": meta.get("command"), "steps_per_launch": meta.get("steps_per_launch"),
+                      "kernels": [{"name": r_["Name"].split("(")[0].replace("void ", ""), "calls": int(r_["Calls"]), "avg_us": float(r_["AverageNs"]) / 1e3}
+                                  for r_ in rows if "vjf_" in r_["Name"]]}
         except Exception:
             pass
+        one_launch = world == 1 and not a.no_overlap and not a.streams_route and not a.force_dist and model.route() == "one-launch"
+        spl = K if one_launch else 1
         out = {
             "metric": "trial-timesteps/sec", "value": value, "unit": "trial-timesteps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": wall_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[{dict(B=1, C=2, E=4)[a.config]}]: VJF.filter, {c['B']} trials/GPU, d_z={c['dz']}, d_y={c['dy']}, "
-                                    f"RBF({c['n']}), hidden={c['hidden']}, {c['lik'].capitalize()} likelihood, sgd+update, explicit noise"),
+            "config": {"workload": (f"BASELINE configs[{CFG_INDEX[a.config]}]: VJF.filter, {c['B']} trials/GPU, d_z={c['dz']}, d_y={c['dy']}, "
+                                    f"RBF({c['n']}), hidden={c['hidden']}, {c['lik'].capitalize()} likelihood, sgd+update, explicit noise"
+                                    + (", one Lorenz trial" if a.config == "A" else "")),
                        "global_batch": c["B"] * world, "trials_per_gpu": c["B"], "parallelism": f"trial-shard x{world}"},
-            "elbo": elbo, "status_bits": status,
+            "repeats": R, "ms_per_step_repeats": [w / K * 1e3 for w in walls], "ms_per_step_median": float(np.median(walls)) / K * 1e3,
+            "elbo": elbos[0], "elbo_check": elbo_check, "status_bits": status,
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per step: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, "
-                                         "summed over the kernels of a step (profiles/pmc_traffic_current.json); algorithmic bytes "
-                                         "per step = bytes_per_trial_step x trials",
-                         "kernel": "one filter step = vjf_trial_mfma_kernel (one launch: forward part, row signals, in-kernel wait for the "
-                                   "RLS update, backward part), vjf_gram_kernel x3 (Phi^T Phi a step ahead, Phi^T dx, gradients), "
-                                   "vjf_gram_reduce_kernel x2, vjf_sgd_kernel, vjf_prepg_kernel, gate kernels, and one step's share "
-                                   "of the persistent vjf_rls_pair_kernel (Cholesky, y/W and inverse workgroups) that "
-                                   "serve the whole sequence; three streams (HIP events around the timed region / steps)",
+                         "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": None if traffic is None else traffic * spl, "traffic_note": traffic_note,
+                         "kernel": ("vjf_mega_kernel: ONE cooperative launch carries the K timed steps (the trial, Gram, operand, SGD and RLS "
+                                    "roles are workgroups of one resident grid); a launch processes K x trials trial-timesteps; its duration "
+                                    "is measured with HIP events on its stream around the timed region" if one_launch else
+                                    "one filter step = the per-step kernels of the route in use (HIP events around the timed region / steps)"),
+                         "launch_us": dev_s * 1e6 if one_launch else step_s * 1e6, "steps_per_launch": spl,
+                         "algorithmic_flops_per_launch": (flops * c["B"] + serial_flops) * spl,
                          "flops_per_trial_step": flops, "serial_flops_per_step": serial_flops,
                          "rocprof_kernel_averages": kstats,
-                         "step_us": step_s * 1e6, "host_enqueue_us_per_step": enq / K * 1e6, "trial_half_us": loc, "serial_half_us": glob,
+                         "step_us": step_s * 1e6, "host_enqueue_us_per_step": enq / K * 1e6,
                          "hbm_achieved_GBs": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
                          "bytes_per_trial_step": b_trial + b_shared / c["B"]},
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(c, y.cpu().numpy(), eps.cpu().numpy())
+        if not a.no_cpu_baseline and s32 is not None:
+            out["cpu_baseline"] = cpu_baseline(c, a.config, s32, q0, y[W:].cpu().numpy(), eps[W:].cpu().numpy())
         print(json.dumps(out), flush=True)
+        if elbo_check is not None and not elbo_check["ok"]:
+            print(f"bench.py: the ELBO of the timed steps differs from the oracle: {elbo_check}", file=sys.stderr)
+            sys.exit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -125,12 +125,19 @@ int vjf_set_stream(vjf_ctx* ctx, void* stream);
 /* Synchronises the stream, returns and clears the sticky status bits. */
 int vjf_get_status(vjf_ctx* ctx, uint32_t* status);
 
-/* vjf_filter_seq runs the RLS chain of a step on a second (internal, non-blocking) stream beside the trial / SGD
- * chain when the fast kernels apply (default on; results are bit-identical either way).  enable = 0 forces the
- * one-stream order; enable = 2 keeps the multi-stream schedule's kernels and hand-offs but enqueues them on the caller's
- * stream alone -- for tools that serialise kernels (rocprofv3 --pmc): a kernel that waits in-kernel for one that the tool has
- * not let run yet would only time out.  Returns the resulting setting (2 / 1 / 0), or a negative error code. */
+/* Which schedule vjf_filter_seq / vjf_filter_step use on a single rank (results agree to summation order; the one-launch and
+ * three-stream routes are bit-identical to each other):
+ *   1 (default)  the one-launch route: ONE cooperative launch carries the whole call; the trial, Gram, operand, SGD and RLS
+ *                roles are workgroups of one resident grid that hand over through counters in memory (plans it serves: see
+ *                vjf_route);
+ *   3            the per-step route on three internal streams (the route the RCCL path uses), for A/B measurements;
+ *   0            the per-step kernels in the one-stream order (also what tools that serialise kernels need).
+ * Returns the resulting setting, or a negative error code. */
 int vjf_set_overlap(vjf_ctx* ctx, int enable);
+
+/* The route a vjf_filter_seq call with these flags would take now: 1 one-launch, 3 three-stream per-step (with communicators:
+ * the RCCL route), 0 one-stream per-step.  Negative on error. */
+int vjf_route(vjf_ctx* ctx, uint32_t flags);
 
 /* Trials sharded over ranks, one process per GPU: with communicators attached, vjf_filter_seq sums the RLS statistics and
  * the gradients over ranks itself (two RCCL all-reduces per step, one on each chain of its schedule) and B in its

@@ -51,6 +51,7 @@ SIGNATURES = {
     "vjf_set_stream": [_P, _P],
     "vjf_get_status": [_P, C.POINTER(_U)],
     "vjf_set_overlap": [_P, _I],
+    "vjf_route": [_P, _U],
     "vjf_comm_unique_id": [_P],
     "vjf_comm_init": [_P, _P, _I, _I],
     "vjf_debug_stamps": [_P, _I, C.POINTER(C.c_uint64)],

@@ -983,6 +983,14 @@ int vjf_filter_step(vjf_ctx* c, int32_t B, const float* y, const float* u, const
     return vjf_filter_global(c, B, loss4, flags);
 }
 
+int vjf_route(vjf_ctx* c, uint32_t flags) {
+    if (!c) return fail(-1, "vjf_route: null context");
+    if (mega_route(c, flags)) return 1;
+    const bool streams = (c->comm_a || c->force_streams) && c->overlap && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP) &&
+                         c->fast_chol && c->post_kernels && c->mfma_trial && (!c->stamps || c->stamps_keep_overlap);
+    return streams ? 3 : 0;
+}
+
 int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
                    const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_seq: null context");
