@@ -22,6 +22,11 @@ for t in range(max(0, T - 6), T):
     o = (ctypes.c_uint64 * 32)()
     N.check(m._backend().vjf_debug_stamps(m._ctx, 128 + (t & 31), o))
     R = list(o)
+    for i, nm in ((27, "trial: LAST workgroup has theta"), (28, "trial: LAST early slab out"), (29, "trial: LAST late slab out")):
+        if R[i]:
+            ev.append((R[i], t, nm))
+    if R[30]:
+        ev.append(((~R[30]) & 0xffffffffffffffff, t, "trial: FIRST late slab out"))
     for i, nm in enumerate(TR):
         if R[i]:
             ev.append((R[i], t, ("trial: " if i < 11 else "") + nm))

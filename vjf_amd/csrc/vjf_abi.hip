@@ -168,33 +168,35 @@ bool mega_plan_ok(const VjfPlan& P) {
 }
 
 bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
-    // one workgroup per compute unit: the RLS loops and the operand role have fixed sizes, the rest of the chip is dealt to the
-    // trial, Gram and SGD roles roughly 128 : 64 : 32 (at 256 CUs and 4096 trials: exactly that -- one 32-trial tile per
-    // trial workgroup, 64 rows of Phi per Gram workgroup)
+    // one workgroup per compute unit: the RLS loops and the operand role have fixed sizes; the trial role gets 128 / 227 of the
+    // rest (one 32-trial tile per workgroup at 256 CUs and 4096 trials), the SGD role one 8-lane group per quad of parameters when
+    // half of what is left allows it (a single round of slab loads per step), the Gram role whatever remains (<= 96 rows each in
+    // one pass)
     const int nbl = (P.n + 31) / 32;
     m->n_rls = 2 + 2 * nbl;
     m->n_prep = (P.n + 15) / 16;
     m->ntiles = (B + VJF_MG_TR - 1) / VJF_MG_TR;
     const int rest = ncu - m->n_rls - m->n_prep;
     if (rest < 3) return false;
-    int cap_t = rest * 128 / 227, cap_g = rest * 64 / 227;
+    int cap_t = rest * 128 / 227;
     if (cap_t < 1) cap_t = 1;
-    if (cap_g < 1) cap_g = 1;
     if (cap_t > kMegaMaxTrialWg) cap_t = kMegaMaxTrialWg;
-    if (cap_g > kMegaMaxGramWg) cap_g = kMegaMaxGramWg;
     m->n_trial = m->ntiles < cap_t ? m->ntiles : cap_t;
-    m->n_gram = (B + VJF_MG_GROWS - 1) / VJF_MG_GROWS;
-    if (m->n_gram > cap_g) m->n_gram = cap_g;
+    const int left = rest - m->n_trial;                                               // >= 2
     m->n_sgd = ((P.train_len / 4) * 8 + VJF_MG_THREADS - 1) / VJF_MG_THREADS;          // 8 lanes per quad of parameters
-    const int cap_s = rest - cap_t - cap_g > 32 ? 32 : rest - cap_t - cap_g;
-    if (m->n_sgd > cap_s) m->n_sgd = cap_s;
+    if (m->n_sgd > left / 2) m->n_sgd = left / 2;
+    if (m->n_sgd > 64) m->n_sgd = 64;
     if (m->n_sgd < 1) m->n_sgd = 1;
+    m->n_gram = (B + 63) / 64;
+    if (m->n_gram > left - m->n_sgd) m->n_gram = left - m->n_sgd;
+    if (m->n_gram > kMegaMaxGramWg) m->n_gram = kMegaMaxGramWg;
+    if (m->n_gram < 1) m->n_gram = 1;
     m->gram_rows = ((B + m->n_gram - 1) / m->n_gram + 1) & ~1;
     return true;
 }
 
 struct Carve {
-    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_meta, mg_E3; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_meta, mg_img, mg_imgidx; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -227,7 +229,8 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
         c.mg_cnt = take((size_t)MG_C_WORDS * 4);
         c.mg_stamps = take(32 * 32 * 8);
         c.mg_meta = take((size_t)P.train_len * 8);
-        c.mg_E3 = take((size_t)max_batch * P.ldE * 4);          // third set of Phi rows (the first two: E, E2)
+        c.mg_img = take((size_t)vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).th_len * 4 + 64);   // the parameters in the trial role's LDS layout
+        c.mg_imgidx = take((size_t)P.train_len * 4);
     }
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
@@ -369,7 +372,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red2, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red3, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.flags, 0, 256, c->stream);
-    std::vector<int> meta;
+    std::vector<int> meta, imgidx;
     if (c->mega_ok) {                                          // per trainable element: group | index of its transposed copy
         meta.assign((size_t)P.train_len * 2, -1);
         for (int t = 0; t < P.n_train; ++t) {
@@ -381,6 +384,27 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
             }
         }
         if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, c->stream);
+        // ... and its place in the image of the trial role's LDS region (vjf_mega_trial_lds)
+        const VjfMegaTrialLds Lo = vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8);
+        imgidx.assign((size_t)P.train_len, -1);
+        auto place = [&](int slot, int rows, int cols, int at, int ld) {
+            const int o = P.off[slot] - P.train_off;
+            for (int r = 0; r < rows; ++r)
+                for (int cc = 0; cc < cols; ++cc) imgidx[(size_t)o + (size_t)r * cols + cc] = at - Lo.th0 + r * ld + cc;
+        };
+        int prev = P.din;
+        for (int l = 0; l < P.L; ++l) {
+            place(VJF_SLOT_REC_W0 + 2 * l, P.h[l], prev, Lo.th_w[l], Lo.th_ldw[l]);
+            place(VJF_SLOT_REC_B0 + 2 * l, 1, P.h[l], Lo.th_b[l], P.h[l]);
+            prev = P.h[l];
+        }
+        place(VJF_SLOT_MEAN_W, P.dz, prev, Lo.th_head, Lo.th_ldh);
+        place(VJF_SLOT_LV_W, P.dz, prev, Lo.th_head + P.dz * Lo.th_ldh, Lo.th_ldh);
+        place(VJF_SLOT_LV_B, 1, P.dz, Lo.th_bl, P.dz);
+        place(VJF_SLOT_DEC_W, P.dy, P.dz, Lo.th_dec, Lo.th_ldd);
+        place(VJF_SLOT_DEC_B, 1, P.dy, Lo.th_bd, P.dy);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_imgidx, imgidx.data(), imgidx.size() * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.mg_img, 0, (size_t)Lo.th_len * 4, c->stream);   // (its padding stays 0)
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs`, `meta` (host) must outlive the copies
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
@@ -742,6 +766,9 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     VJF_HIP(hipSetDevice(c->cfg.device));
     rc = refresh_aux(c);
     if (rc) return rc;
+    hipLaunchKernelGGL(vjf_img_kernel, dim3(16), dim3(256), 0, c->stream, (const float*)(c->state + P.train_off), (const int*)(c->ws + c->cv.mg_imgidx),
+                       (float*)(c->ws + c->cv.mg_img), P.train_len);
+    VJF_HIP(hipGetLastError());
     unsigned* cnt = (unsigned*)(c->ws + c->cv.mg_cnt);
     VJF_HIP(hipMemsetAsync(cnt, 0, (size_t)MG_C_WORDS * 4, c->stream));                 // every counter and flag of the launch starts at 0
     const int nbl = (P.n + 31) / 32;
@@ -753,7 +780,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     A.n_rls = m.n_rls; A.n_trial = m.n_trial; A.n_gram = m.n_gram; A.n_prep = m.n_prep; A.n_sgd = m.n_sgd;
     A.y = y; A.u = u; A.eps = eps; A.mu0 = mu0; A.lv0 = lv0; A.mu = mu; A.lv = lv; A.loss = loss;
     A.state = c->state; A.aux = (float*)(c->ws + c->cv.aux);
-    A.E[0] = (float*)(c->ws + c->cv.E); A.E[1] = (float*)(c->ws + c->cv.E2); A.E[2] = (float*)(c->ws + c->cv.mg_E3);
+    A.img = (const float*)(c->ws + c->cv.mg_img); A.imgidx = (const int*)(c->ws + c->cv.mg_imgidx);
     A.slab_early = (float*)(c->ws + c->cv.mg_early); A.slab_late = (float*)(c->ws + c->cv.mg_late); A.gslab = (float*)(c->ws + c->cv.mg_gslab);
     A.red0 = rede[0]; A.red1 = rede[1];
     A.gbuf = (float*)(c->ws + c->cv.work);

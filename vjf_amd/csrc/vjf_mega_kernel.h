@@ -33,7 +33,7 @@
 #define VJF_MG_WAVES 8
 #define VJF_MG_TR 32                 // trials per tile: two column groups of v_mfma_f32_16x16x4_f32 share every A operand
 #define VJF_MG_LD 33                 // LDS matrices are feature-major [feature][32 trials + 1 pad]
-#define VJF_MG_GROWS 64              // rows of Phi staged per pass of the Gram role
+#define VJF_MG_GROWS 96              // rows of Phi formed per pass of the Gram role
 #define VJF_MG_MAXQ 4                // 32x32 tiles of Phi^T Phi per wavefront of a Gram workgroup (28 lower tiles / 8)
 
 // counters: one per 64-byte line of the block that the host zeroes before every launch
@@ -61,7 +61,8 @@ struct VjfMegaArgs {
     const float* y; const float* u; const float* eps; const float* mu0; const float* lv0;
     float* mu; float* lv; float* loss;
     float* state; float* aux;
-    float* E[3];                                      // Phi rows of event e: E[e % 3], (B, ldE)
+    const float* img;                                 // the optimised parameters as the trial role's LDS holds them (vjf_mega_trial_lds: theta region)
+    const int* imgidx;                                // per trainable element: its index in `img` (-1: alignment padding)
     float* slab_early; float* slab_late; float* gslab;
     float* red0; float* red1;                         // reduce buffers of even / odd steps ([G | FDX | sums], as the RLS loops read them)
     float* gbuf;                                      // g (n, dz)
@@ -80,6 +81,7 @@ struct VjfMegaTrialLds {
     int nd;
     // the optimised parameters, staged once per step when they fit (theta = 1): matrices in their torch layout [rows][ld], ld = the
     // row length rounded up to 2 (mod 4) -- the rows an MFMA operand read walks then fall on distinct banks
+    int th0, th_len;                                  // first float / length (a multiple of 4) of the region
     int theta, th_w[VJF_MAX_HIDDEN], th_ldw[VJF_MAX_HIDDEN], th_head, th_ldh, th_dec, th_ldd, th_b[VJF_MAX_HIDDEN], th_bl, th_bd;
 };
 __host__ __device__ inline int vjf_mega_ld(int K) { return ((K + 1) & ~3) + 2; }
@@ -105,10 +107,12 @@ __host__ __device__ inline VjfMegaTrialLds vjf_mega_trial_lds(const VjfPlan& P, 
     l.total = o;
     {
         int prev = P.din;
+        l.th0 = o;
         for (int k = 0; k < VJF_MAX_HIDDEN; ++k) { l.th_w[k] = l.th_ldw[k] = l.th_b[k] = 0; }
         for (int k = 0; k < P.L; ++k) { l.th_ldw[k] = vjf_mega_ld(prev); l.th_w[k] = take(P.h[k] * l.th_ldw[k]); l.th_b[k] = take(P.h[k]); prev = P.h[k]; }
         l.th_ldh = vjf_mega_ld(prev); l.th_head = take(2 * P.dz * l.th_ldh); l.th_bl = take(P.dz);
         l.th_ldd = vjf_mega_ld(P.dz); l.th_dec = take(P.dy * l.th_ldd); l.th_bd = take(P.dy);
+        l.th_len = o - l.th0;
         l.theta = (lds_limit_floats > 0 && o <= lds_limit_floats) ? 1 : 0;
         if (l.theta) l.total = o;
     }
@@ -119,7 +123,10 @@ __host__ __device__ inline VjfMegaTrialLds vjf_mega_trial_lds(const VjfPlan& P, 
 // addresses through the struct's offsets only -- it does (no pointer arithmetic across fields except mu -> lv and dmu -> dlv,
 // which are handled explicitly).
 
-static inline size_t vjf_mega_gram_lds_floats(const VjfPlan& P) { return (size_t)VJF_MG_GROWS * P.ldE + 64; }
+static inline size_t vjf_mega_gram_lds_floats(const VjfPlan& P) {      // rows of Phi | tile table | centroids^T | -1/(2 w^2) | xs rows
+    const size_t npad = (size_t)((P.n + 3) & ~3);
+    return (size_t)VJF_MG_GROWS * P.ldE + 64 + npad * P.dxu + npad + (size_t)VJF_MG_GROWS * P.dxu + 16;
+}
 static inline size_t vjf_mega_prep_lds_floats(const VjfPlan& P) {
     return (size_t)16 * VJF_PREPG_LDP(P.n) + (size_t)P.n * 17 + (size_t)VJF_MG_WAVES * 16 * 17 + 16 * 17 + 64;
 }
@@ -227,6 +234,17 @@ __device__ __forceinline__ void mg_warm(const float* base, int nfloats, int wg, 
         }                                                                                   \
     } while (0)
 
+// latest (i) / earliest (j, stored complemented) time over ALL trial workgroups
+#define VJF_MG_STAMPX(i, j)                                                                 \
+    do {                                                                                    \
+        if (A.stamps && tid == 0) {                                                         \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+            atomicMax(A.stamps + (size_t)(t & 31) * 32 + (i), t_);                          \
+            if ((j) >= 0) atomicMax(A.stamps + (size_t)(t & 31) * 32 + (j), ~t_);           \
+        }                                                                                   \
+    } while (0)
+
 // one 16x16 tile of  G[m][j] = sum_{b<32} D[m0+m][b] * Bop[j0+j][b],  Bop = [Bact (Kin rows) | ones | 0..]  -> slab
 __device__ __forceinline__ void mg_grad_tile(const float* D, int M, int m0, const float* Bact, int Kin, int j0, const float* s_one,
                                              const float* s_zero, float* slab, int dstW, int ld, int dstB, bool first, int lane) {
@@ -255,14 +273,22 @@ __device__ __forceinline__ void mg_grad_tile(const float* D, int M, int m0, cons
 }
 
 // ------------------------------------------------------------------------------------------------ trial role
+#define MG_PHASE()                                                        \
+    do {                                                                  \
+        tid = tid0;                                                       \
+        asm volatile("" : "+v"(tid));                                     \
+        lane = tid & 63;                                                  \
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);                  \
+    } while (0)
+
 __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaArgs& A, float* smem, const int wg) {
     constexpr int LD = VJF_MG_LD, NW = VJF_MG_WAVES, NT = VJF_MG_THREADS, TR = VJF_MG_TR;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x;
     const int dz = P.dz, dy = P.dy, du = P.du, n = P.n, din = P.din, dxu = P.dxu;
     const float* S = A.state;
     float* SCW = A.state + P.off[VJF_SLOT_SCALARS];
     const bool warm = false;                           // (this launch only runs sgd + update without warm-up)
-    const unsigned m_dy = mg_magic(dy), m_dz = mg_magic(dz), m_du = mg_magic(du > 0 ? du : 1), m_q4 = mg_magic(P.ldE >> 2);
+    const unsigned m_dy = mg_magic(dy), m_dz = mg_magic(dz), m_du = mg_magic(du > 0 ? du : 1);
     const VjfMegaTrialLds Lo = vjf_mega_trial_lds(P, A.lds_floats);
     const bool tl = Lo.theta != 0;                    // the optimised parameters are staged in LDS once per step
     float* s_cen = smem + Lo.cen; float* s_iw = smem + Lo.iw;
@@ -279,7 +305,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     float* s_part = smem + Lo.part;                    // partial tiles of the K-split products (heads, pt.mean)
     constexpr int part_rows = VJF_MG_WAVES * 16;
     int mean_nsl = 1;
-    bool have_phi = false;                             // xs and Phi of the coming step are in s_xu / s_phi (single-tile workgroups)
+    __shared__ int s_try;
     unsigned* cnt = A.cnt;
     const unsigned npost = (unsigned)(A.n_rls - 1);
     float* late = A.slab_late + (size_t)wg * A.late_len;
@@ -290,6 +316,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     // centroids (transposed: [input dim][centre], 16-byte rows) and -1/(2 w^2): constant for the launch (functional.py:11-22)
     const int npad = (n + 3) & ~3;
     {
+        const int tid = tid0;
         const float* cen = S + P.off[VJF_SLOT_CENTROID];
         const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
         for (int e = tid; e < npad * dxu; e += NT) { const int c = e / npad, k = e - c * npad; s_cen[e] = k < n ? cen[k * dxu + c] : 0.f; }
@@ -298,35 +325,12 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     }
     __syncthreads();
 
-    // Phi(x) of the trials of one tile from xs' rows parked at `s_xn` -> rows of Eout (16-byte write-through stores: the Gram role
-    // takes them); per element the same operations in the same order as stage 1 below: the same bits
-    auto phi_rows = [&](const float* s_xn, float* Eout, int b0, int nb, float* keep) {
-        const int q4 = P.ldE >> 2;
-        for (int e = tid; e < nb * q4; e += NT) {
-            const int b = mg_div(e, m_q4), k = (e - b * q4) * 4;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (k < npad) {
-                float d2[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int c = 0; c < dxu; ++c) {
-                    const float x = s_xn[c * LD + b];
-                    const float4 cc = *reinterpret_cast<const float4*>(s_cen + c * npad + k);
-                    float d;
-                    d = x - cc.x; d2[0] = fmaf(d, d, d2[0]); d = x - cc.y; d2[1] = fmaf(d, d, d2[1]);
-                    d = x - cc.z; d2[2] = fmaf(d, d, d2[2]); d = x - cc.w; d2[3] = fmaf(d, d, d2[3]);
-                }
-                const float4 iw = *reinterpret_cast<const float4*>(s_iw + k);
-                v[0] = expf(d2[0] * iw.x); v[1] = k + 1 < n ? expf(d2[1] * iw.y) : 0.f;
-                v[2] = k + 2 < n ? expf(d2[2] * iw.z) : 0.f; v[3] = k + 3 < n ? expf(d2[3] * iw.w) : 0.f;
-            }
-            mg_st4(Eout + (size_t)(b0 + b) * P.ldE + k, v[0], v[1], v[2], v[3]);
-            if (keep) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (k + r < n) keep[(k + r) * LD + b] = v[r];
-            }
-        }
-    };
-
     for (int t = 0; t < A.T; ++t) {
+        // (the thread index is made opaque at every phase boundary: what the compiler derives from it -- dozens of per-thread LDS and
+        //  memory offsets, one set per loop of the step -- is then formed in the phase that uses it instead of at the top of the step,
+        //  where it was kept, and spilled to scratch memory, across the whole step)
+        int tid = tid0, lane, wave;
+        MG_PHASE();
         const float* y_t = A.y + (size_t)t * sy;
         const float* u_t = A.u ? A.u + (size_t)t * su : nullptr;
         const float* mu_s = t ? A.mu + (size_t)(t - 1) * sz : A.mu0;
@@ -336,24 +340,19 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         float* mu_t = A.mu + (size_t)t * sz;
         float* lv_t = A.lv + (size_t)t * sz;
         const bool prior = (mu_s == nullptr);
-        // Phi rows rotate through three sets: the rows written now for event t + 1 were last read by the Gram of event t - 2, which
-        // the Cholesky loop of step t - 2 waited for -- long before this step's parameters existed
-        float* E_now = A.E[t % 3];
-        float* E_next = A.E[(t + 1) % 3];
         // early slabs alternate between two sets: the operand role may read step t's long after this workgroup has started
         // step t + 1 (it also waits for the Gram of step t); step t + 2 starts behind the RLS update of step t, which consumed them
         float* early = A.slab_early + ((size_t)(t & 1) * A.n_trial + wg) * A.early_len;
         VJF_MG_STAMP(0);
         if (tid < 16) s_wg[tid] = 0.f;
         float sig = 0.f, rho = 0.f;
-        bool tri = false;
+        bool tri = false, rls_in = false;
         int it = 0;
         for (int tile = wg; tile < A.ntiles; tile += A.n_trial, ++it) {
             const bool first = it == 0, last = it == ntl - 1;
             const int b0 = tile * TR;
             const int nb = min(TR, A.B - b0);
-            __syncthreads();                           // (the previous tile's readers of the LDS matrices are done)
-            float v_epsn = 0.f, v_un = 0.f;
+            __syncthreads(); MG_PHASE();                           // (the previous tile's readers of the LDS matrices are done)
             // ---- stage 0: inputs.  A tile's rows of y / u / mu_s / lv_s / eps are contiguous in memory: flat coalesced reads, all of a
             //      thread's loads in flight before its first (transposed) LDS write
             {
@@ -377,11 +376,6 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     }
                 }
                 if (du > 0 && tid < TR * du) cell(u_t, du, m_du, tid, vu, au);
-                if (t + 1 < A.T) {                                              // (for the next step's features, formed further down)
-                    int dummy;
-                    if (sm) cell(A.eps + (size_t)(t + 1) * 2 * sz, dz, m_dz, tid, v_epsn, dummy);
-                    if (du > 0 && tid < TR * du) cell(A.u + (size_t)(t + 1) * su, du, m_du, tid, v_un, dummy);
-                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) if (ay[q] >= 0) s_in[ay[q]] = vy[q];
                 if (sm) {
@@ -399,9 +393,9 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
             }
             if (tid < LD) s_one[tid] = tid < nb ? 1.f : 0.f;
-            __syncthreads();
+            __syncthreads(); MG_PHASE();
             if (first) VJF_MG_STAMP(20);
-            if (!have_phi) {                           // (else: xs and Phi of this step are in LDS already, see the next step's features below)
+            {
                 for (int e = tid; e < TR * dxu; e += NT) {
                     const int c = e >> 5, b = e & 31;
                     float v;
@@ -409,7 +403,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     else v = s_in[(dy + c - dz) * LD + b];
                     s_xu[c * LD + b] = v;
                 }
-                __syncthreads();
+                __syncthreads(); MG_PHASE();
                 if (first) VJF_MG_STAMP(21);
                 // ---- stage 1: RBF features (functional.py:11-22)
                 for (int e = tid; e < TR * n; e += NT) {
@@ -418,14 +412,29 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     for (int c = 0; c < dxu; ++c) { const float d = s_xu[c * LD + b] - s_cen[c * npad + k]; d2 = fmaf(d, d, d2); }
                     s_phi[k * LD + b] = expf(d2 * s_iw[k]);
                 }
-                __syncthreads();
-            }
-            have_phi = false;
-            if (t == 0) {                              // first step of the launch: nobody wrote this step's rows a step ahead
-                phi_rows(s_xu, E_now, b0, nb, nullptr);
-                if (last) vjf_wg_signal_wt(cnt + MG_C_PHI, tid);                   // event 0
+                __syncthreads(); MG_PHASE();
             }
             if (first) VJF_MG_STAMP(2);
+            // ---- the RLS update of the previous step (W, w_chol, sigma: write-through stores of the RLS roles), if it is complete
+            //      already: its acquire and the L2 warm-up then cost nothing on the path parameters -> forward -> backward.  If not,
+            //      the same happens behind the forward pass (below): the values read are the same either way.
+            if (first) {
+                rls_in = t == 0;
+                if (t > 0) {
+                    if (tid == 0) {
+                        const bool there = (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
+                        if (there) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                        s_try = there ? 1 : 0;
+                    }
+                    __syncthreads(); MG_PHASE();
+                    rls_in = s_try != 0;
+                    if (rls_in) mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
+                }
+                if (rls_in) {
+                    sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
+                    tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;               // w_chol known upper triangular
+                }
+            }
             // ---- theta of the previous step (the SGD role's write-through stores).  Nothing above depends on it: the inputs and the
             //      features of a step are ready before the parameters are
             if (first && t > 0) {
@@ -437,37 +446,23 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     mg_warm(S + P.train_off, P.train_len, wg, tid);
                 }
             }
+            if (first) rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);            // (the SGD role's)
             if (first && tl) {
-                // the parameters of this step into LDS: flat coalesced reads of each tensor, up to 8 of a thread's loads in flight
-                auto stage = [&](int slot, int rows, int cols, int at, int ld) {
-                    const float* src = S + P.off[slot];
-                    float* dst = smem + at;
-                    const unsigned mc = mg_magic(cols);
-                    for (int e0 = tid; e0 < rows * cols; e0 += 8 * NT) {
-                        float v[8];
+                // the parameters of this step into LDS: the image the SGD role keeps has the layout of the region, so this is a flat
+                // 16-byte copy with all of a thread's loads in flight -- one round trip
+                const float4* src = reinterpret_cast<const float4*>(A.img);
+                float4* dst = reinterpret_cast<float4*>(smem + Lo.th0);
+                const int n4 = Lo.th_len >> 2;
+                for (int q0 = tid; q0 < n4; q0 += 8 * NT) {
+                    float4 v[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = (e0 + q * NT < rows * cols) ? src[e0 + q * NT] : 0.f;
+                    for (int q = 0; q < 8; ++q) if (q0 + q * NT < n4) v[q] = src[q0 + q * NT];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int e = e0 + q * NT;
-                            if (e < rows * cols) { const int r = mg_div(e, mc); dst[r * ld + (e - r * cols)] = v[q]; }
-                        }
-                    }
-                };
-                int prev = din;
-                for (int l = 0; l < P.L; ++l) {
-                    stage(VJF_SLOT_REC_W0 + 2 * l, P.h[l], prev, Lo.th_w[l], Lo.th_ldw[l]);
-                    stage(VJF_SLOT_REC_B0 + 2 * l, 1, P.h[l], Lo.th_b[l], P.h[l]);
-                    prev = P.h[l];
+                    for (int q = 0; q < 8; ++q) if (q0 + q * NT < n4) dst[q0 + q * NT] = v[q];
                 }
-                stage(VJF_SLOT_MEAN_W, dz, prev, Lo.th_head, Lo.th_ldh);
-                stage(VJF_SLOT_LV_W, dz, prev, Lo.th_head + dz * Lo.th_ldh, Lo.th_ldh);
-                stage(VJF_SLOT_LV_B, 1, dz, Lo.th_bl, dz);
-                stage(VJF_SLOT_DEC_W, dy, dz, Lo.th_dec, Lo.th_ldd);
-                stage(VJF_SLOT_DEC_B, 1, dy, Lo.th_bd, dy);
-                __syncthreads();
+                __syncthreads(); MG_PHASE();
             }
-            if (first) VJF_MG_STAMP(1);
+            if (first) { VJF_MG_STAMP(1); VJF_MG_STAMPX(27, -1); }
             // ---- stage 3: recognition forward (recognition.py:31-42)
             {
                 const float* xin = s_in;
@@ -491,7 +486,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                             }
                         }
                     }
-                    __syncthreads();
+                    __syncthreads(); MG_PHASE();
                     xin = out; kin = hl; aoff += hl;
                 }
                 if (first) VJF_MG_STAMP(23);
@@ -510,7 +505,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
                 }
-                __syncthreads();
+                __syncthreads(); MG_PHASE();
                 if (first) VJF_MG_STAMP(24);
                 const float* bl = tl ? smem + Lo.th_bl : S + P.off[VJF_SLOT_LV_B];
                 for (int e = tid; e < TR * 2 * dz; e += NT) {
@@ -520,7 +515,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     if (f < dz) s_mu[f * LD + b] = v; else s_lv[(f - dz) * LD + b] = v + bl[f - dz];
                 }
             }
-            __syncthreads();
+            __syncthreads(); MG_PHASE();
             if (first) VJF_MG_STAMP(3);
             // ---- stage 4: xt, dx, posterior out, py = xt C^T + d (model.py:28-30)
             for (int e = tid; e < TR * dz; e += NT) {
@@ -531,10 +526,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             }
             for (int e = tid; e < nb * dz; e += NT) {                          // coalesced posterior stores
                 const int b = mg_div(e, m_dz), j = e - b * dz;
-                mu_t[(size_t)(b0 + b) * dz + j] = s_mu[j * LD + b];
-                lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
+                mg_st(mu_t + (size_t)(b0 + b) * dz + j, s_mu[j * LD + b]);         // (write-through: the Gram role forms the next step's
+                mg_st(lv_t + (size_t)(b0 + b) * dz + j, s_lv[j * LD + b]);         //  features from them)
             }
-            __syncthreads();
+            __syncthreads(); MG_PHASE();
             {
                 // sum |dx|^2 per trial (16 lanes each), then the tile's sum in trial order
                 constexpr int LPT = NT / TR;
@@ -584,7 +579,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads(); MG_PHASE();
             if (tid == 0) {
                 float v = 0.f;
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + RS_SDX2];
@@ -594,34 +589,17 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (first) VJF_MG_STAMP(26);
             if (last) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
             if (first) VJF_MG_STAMP(4);
-            // ---- features of the NEXT step (they depend only on this posterior): xs' = mu_t + eps_s' e^{lv_t/2}, the same operations in
-            //      the same order as stages 0 / 1 of the next step.  As early as the posterior exists: the Gram role needs the rows of
-            //      every trial workgroup before it can start on the next step's Phi^T Phi, and that must be reduced before sigma of this
-            //      step lands.  The write-through row stores drain during the wait for the RLS update below.
-            if (t + 1 < A.T) {
-                // (s_xu / s_phi of this step are still needed below: the next step recomputes its features -- before its parameters
-                //  arrive, i.e. in time it would spend waiting anyway)
-                const bool keep = false;
-                float* s_xn = keep ? s_xu : smem + Lo.xn;
-                if (tid < TR * dz) { const int b = mg_div(tid, m_dz), c2 = tid - b * dz; s_xn[c2 * LD + b] = fmaf(v_epsn, expf(0.5f * s_lv[c2 * LD + b]), s_mu[c2 * LD + b]); }
-                if (du > 0 && tid < TR * du) { const int b = mg_div(tid, m_du), c2 = tid - b * du; s_xn[(dz + c2) * LD + b] = v_un; }
-                __syncthreads();
-                phi_rows(s_xn, E_next, b0, nb, keep ? s_phi : nullptr);
-                have_phi = keep;
-                if (last) vjf_wg_signal_wt(cnt + (((t + 1) & 1) ? MG_C_PHI1 : MG_C_PHI), tid);   // event t + 1
-                if (first) VJF_MG_STAMP(10);
-            }
-            // ---- the RLS update of the previous step (W, w_chol, sigma: write-through stores of the RLS roles)
-            if (first) {
-                if (t > 0 && !vjf_wg_wait(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS))
+            if (last) VJF_MG_STAMPX(28, -1);
+            // ---- the RLS update of the previous step, if it had not landed before the forward pass
+            if (first && !rls_in) {
+                if (!vjf_wg_wait(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
                 if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
-                if (t > 0) mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
+                mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
                 sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
-                rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);
-                tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;                   // w_chol known upper triangular
-                VJF_MG_STAMP(5);
+                tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
             }
+            if (first) VJF_MG_STAMP(5);
             // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
             {
                 const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
@@ -656,7 +634,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
                 mean_nsl = nsl;
             }
-            __syncthreads();
+            __syncthreads(); MG_PHASE();
             if (last && tid == 0) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
             if (tid < TR) {
                 float v = 0.f;
@@ -669,7 +647,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
                 s_pm[j * LD + b] = s_xu[j * LD + b] + v;
             }
-            __syncthreads();
+            __syncthreads(); MG_PHASE();
             if (first) VJF_MG_STAMP(6);
             // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
             {
@@ -722,7 +700,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     s_sc[b * RS_N + RS_SSEY] = ok ? ssey : 0.f;
                 }
             }
-            __syncthreads();
+            __syncthreads(); MG_PHASE();
             if (tid < RS_SDX2) {                                               // (RS_LRECON, RS_LDYN, RS_ENT, RS_SSEY)
                 float v = 0.f;
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + tid];
@@ -764,7 +742,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads(); MG_PHASE();
             if (first) VJF_MG_STAMP(7);
             {
                 const int hL = P.h[P.L - 1];
@@ -810,8 +788,8 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     grad_tensor(da, P.h[l], l > 0 ? s_act + aoff * LD : s_in, l > 0 ? P.h[l - 1] : din, VJF_SLOT_REC_W0 + 2 * l, VJF_SLOT_REC_B0 + 2 * l);
                 };
                 delta(P.L, nullptr, s_d0);                                     // da_{L-1}
-                __syncthreads();
-                if (P.L >= 2) { delta(P.L - 1, s_d0, s_d1); __syncthreads(); } // da_{L-2}
+                __syncthreads(); MG_PHASE();
+                if (P.L >= 2) { delta(P.L - 1, s_d0, s_d1); __syncthreads(); MG_PHASE(); } // da_{L-2}
                 if (first) VJF_MG_STAMP(19);
                 // gradient tiles (write-through stores into the workgroup's late slab)
                 grad_tensor(s_dpy, dy, s_xt, dz, VJF_SLOT_DEC_W, VJF_SLOT_DEC_B);
@@ -821,9 +799,9 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 if (P.L >= 2) layer_grads(P.L - 2, s_d1);
                 float* cur = s_d1; float* nxt = s_d0;                          // deeper networks: the two delta buffers alternate
                 for (int l = P.L - 3; l >= 0; --l) {
-                    __syncthreads();
+                    __syncthreads(); MG_PHASE();
                     delta(l + 1, cur, nxt);
-                    __syncthreads();
+                    __syncthreads(); MG_PHASE();
                     layer_grads(l, nxt);
                     float* tmp = cur; cur = nxt; nxt = tmp;
                 }
@@ -831,10 +809,11 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (first) VJF_MG_STAMP(8);
             if (last) {
                 // the workgroup's late slab is complete: loss sums, then the signal the SGD role waits for
-                __syncthreads();
+                __syncthreads(); MG_PHASE();
                 if (tid < RS_SDX2) mg_st(late + P.train_len + tid, s_wg[tid]);
                 vjf_wg_signal_wt(cnt + MG_C_BWD, tid);
                 VJF_MG_STAMP(9);
+                VJF_MG_STAMPX(29, 30);
             }
         }
         VJF_MG_STAMP(18);
@@ -842,15 +821,31 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
 }
 
 // ------------------------------------------------------------------------------------------------ Gram role
-// Phi^T Phi of event e (the features of step e), lower 32x32 tiles, from the rows the trial role wrote
+// Phi^T Phi of event e (the features of step e), lower 32x32 tiles.  The rows of Phi are formed here, from the posterior of step
+// e - 1 and the noise of step e -- operation for operation what the trial role does for its own tile (stages 0 / 1), so the two
+// hold the same bits -- as soon as every trial workgroup has its forward pass of step e - 1 behind it: a step AHEAD of the RLS
+// update that consumes the sum.
 __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArgs& A, float* lds, const int hg) {
     constexpr int NT = VJF_MG_THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = P.n, nbl = (n + 31) / 32, ntri = nbl * (nbl + 1) / 2, ldE = P.ldE;
     const unsigned m_l4 = mg_magic(ldE >> 2);
     float* SCW = A.state + P.off[VJF_SLOT_SCALARS];
+    const int dz = P.dz, du = P.du, dxu = P.dxu, npad = (n + 3) & ~3;
     float* s_rows = lds;                               // [VJF_MG_GROWS][ldE]
     int* s_tab = reinterpret_cast<int*>(s_rows + (size_t)VJF_MG_GROWS * ldE);   // tile -> (bi << 8) | bj
+    float* s_cen = s_rows + (size_t)VJF_MG_GROWS * ldE + 64;                    // [dxu][npad]
+    float* s_iw = s_cen + (size_t)npad * dxu;                                   // [npad]
+    float* s_x = s_iw + npad;                                                   // [VJF_MG_GROWS][dxu]
+    const float* S = A.state;
+    {
+        const float* cen = S + P.off[VJF_SLOT_CENTROID];
+        const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
+        for (int e = tid; e < npad * dxu; e += NT) { const int c = e / npad, k = e - c * npad; s_cen[e] = k < n ? cen[k * dxu + c] : 0.f; }
+        for (int e = tid; e < npad; e += NT) { float v = 0.f; if (e < n) { const float w = expf(lw[e]); v = -0.5f / (w * w); } s_iw[e] = v; }
+    }
+    const size_t sz = (size_t)A.B * dz, su = (size_t)A.B * du;
+    const unsigned m_dxu = mg_magic(dxu);
     if (tid < ntri) {
         int bi = 0;
         while ((bi + 1) * (bi + 2) / 2 <= tid) ++bi;
@@ -861,9 +856,13 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
     float* myslab = A.gslab + (size_t)hg * ntri * 1024;
     const int c = lane & 31, kh = lane >> 5;
     for (int e = 0; e < A.T; ++e) {
-        const float* E = A.E[e % 3];
         float* red = (e & 1) ? A.red1 : A.red0;
-        if (!vjf_wg_wait(A.cnt + ((e & 1) ? MG_C_PHI1 : MG_C_PHI), (unsigned)(e / 2 + 1) * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS))
+        const float* mu_s = e ? A.mu + (size_t)(e - 1) * sz : A.mu0;
+        const float* lv_s = e ? A.lv + (size_t)(e - 1) * sz : A.lv0;
+        const float* eps_s = A.eps + (size_t)e * 2 * sz;
+        const float* u_e = A.u ? A.u + (size_t)e * su : nullptr;
+        // (the posterior of step e - 1: write-through stores of the trial role, in memory before its early slab's signal)
+        if (e > 0 && !vjf_wg_wait(A.cnt + MG_C_FWD, (unsigned)e * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         // (the slab of the previous event: every Gram workgroup has summed its share)
         if (e > 0 && !vjf_wg_wait(A.cnt + MG_C_STAT, (unsigned)e * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS))
@@ -878,19 +877,40 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         for (int c0 = r0; c0 < r1; c0 += VJF_MG_GROWS) {
             __syncthreads();
             const int l4 = ldE >> 2;
-            for (int i0 = tid; i0 < VJF_MG_GROWS * l4; i0 += 8 * NT) {         // 8 float4 per thread in flight; rows beyond the range: zero
-                float4 v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int idx = i0 + q * NT, r = mg_div(idx, m_l4), q4 = idx - r * l4;
-                    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (idx < VJF_MG_GROWS * l4 && c0 + r < r1) v[q] = *reinterpret_cast<const float4*>(E + (size_t)(c0 + r) * ldE + 4 * q4);
+            // xs = mu + eps e^{lv/2} (model.py:97-99; the prior at the first step of a run: model.py:188-190) and the inputs u
+            for (int i = tid; i < VJF_MG_GROWS * dxu; i += NT) {
+                const int r = mg_div(i, m_dxu), c2 = i - r * dxu, b = c0 + r;
+                float v = 0.f;
+                if (b < r1) {
+                    if (c2 < dz) {
+                        const float m = mu_s ? mu_s[(size_t)b * dz + c2] : S[P.off[VJF_SLOT_PRIOR_MEAN] + c2];
+                        const float l = mu_s ? lv_s[(size_t)b * dz + c2] : S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c2];
+                        v = fmaf(eps_s[(size_t)b * dz + c2], expf(0.5f * l), m);
+                    } else {
+                        v = u_e[(size_t)b * du + c2 - dz];
+                    }
                 }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int idx = i0 + q * NT, r = mg_div(idx, m_l4), q4 = idx - r * l4;
-                    if (idx < VJF_MG_GROWS * l4) *reinterpret_cast<float4*>(s_rows + (size_t)r * ldE + 4 * q4) = v[q];
+                s_x[i] = v;
+            }
+            __syncthreads();
+            // RBF features (functional.py:11-22), four centres per thread and pass; rows beyond the range and columns beyond n: zero
+            for (int i = tid; i < VJF_MG_GROWS * l4; i += NT) {
+                const int r = mg_div(i, m_l4), k = (i - r * l4) * 4;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + r < r1 && k < npad) {
+                    float d2[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int c2 = 0; c2 < dxu; ++c2) {
+                        const float x = s_x[r * dxu + c2];
+                        const float4 cc = *reinterpret_cast<const float4*>(s_cen + c2 * npad + k);
+                        float d;
+                        d = x - cc.x; d2[0] = fmaf(d, d, d2[0]); d = x - cc.y; d2[1] = fmaf(d, d, d2[1]);
+                        d = x - cc.z; d2[2] = fmaf(d, d, d2[2]); d = x - cc.w; d2[3] = fmaf(d, d, d2[3]);
+                    }
+                    const float4 iw = *reinterpret_cast<const float4*>(s_iw + k);
+                    o.x = expf(d2[0] * iw.x); o.y = k + 1 < n ? expf(d2[1] * iw.y) : 0.f;
+                    o.z = k + 2 < n ? expf(d2[2] * iw.z) : 0.f; o.w = k + 3 < n ? expf(d2[3] * iw.w) : 0.f;
                 }
+                *reinterpret_cast<float4*>(s_rows + (size_t)r * ldE + k) = o;
             }
             __syncthreads();
 #pragma unroll
@@ -1100,69 +1120,82 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     float* S = A.state;
     float* SC = S + P.off[VJF_SLOT_SCALARS];
     const float Bf = (float)A.B, invB = 1.0f / Bf;
+    // (set by the host between launches, never inside one)
+    const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
+    const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
+    const bool tl = vjf_mega_trial_lds(P, A.lds_floats).theta != 0;   // the trial role reads the LDS image (else: the state and its transposed copies)
+    // a quad of parameters per 8 lanes: lane p sums the late slabs [p npq, (p+1) npq) (16-byte loads, all in flight together with
+    // the quad's old values, its table entries and the step's loss sums), then a fixed xor tree; lane 0 of the group clips and
+    // steps its four parameters (model.py:210-211)
+    const int npq = (A.n_trial + 7) >> 3, part = tid & 7;
+    const int nquad = P.train_len >> 2, qstride = (A.n_sgd * NT) >> 3;
+    const int w1 = min(A.n_trial, (part + 1) * npq);
     for (int t = 0; t < A.T; ++t) {
         if (!vjf_wg_wait(A.cnt + MG_C_BWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
             vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
         if (vjf_abort_seen(SC + VJF_SC_STATUS)) return;
         { const int wg = sw; VJF_MG_STAMP(16); }
-        // loss sums of the step: fp64, 32 strided partial sums per scalar, then a fixed xor tree (every SGD workgroup, for the guards)
-        if (tid < 32 * RS_SDX2) {
-            const int sc = tid >> 5, l = tid & 31;
-            double v = 0.0;
-            for (int w = l; w < A.n_trial; w += 32) v += (double)A.slab_late[(size_t)w * A.late_len + P.train_len + sc];
-            v = vjf_sum32(v);
-            if (l == 0) s_sc[sc] = (float)v;
-        }
-        __syncthreads();
-        float l_recon = s_sc[RS_LRECON] * invB, l_dyn = s_sc[RS_LDYN] * invB, ent = s_sc[RS_ENT] * invB;
-        const bool ok_r = isfinite(l_recon), ok_d = isfinite(l_dyn), ok_h = isfinite(ent);
-        const bool grad_ok = ok_r && ok_h && ok_d;
-        if (grad_ok) {
-            const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
-            const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
-            // a quad of parameters per 8 lanes: lane p sums the late slabs [p npq, (p+1) npq) (16-byte loads, all in flight together with
-            // the quad's old values and its table entries), then a fixed xor tree; lane 0 of the group clips and steps its four
-            // parameters (model.py:210-211)
-            const int npq = (A.n_trial + 7) >> 3;
-            const int part = tid & 7;
-            for (int quad = (sw * NT + tid) >> 3; quad < (P.train_len >> 2); quad += (A.n_sgd * NT) >> 3) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float* src = A.slab_late + (size_t)quad * 4;
-                const int w1 = min(A.n_trial, (part + 1) * npq);
-                float4 wo = make_float4(0.f, 0.f, 0.f, 0.f);
-                int4 m0 = make_int4(-1, -1, -1, -1), m1 = m0;
-                if (part == 0) {
-                    wo = *reinterpret_cast<const float4*>(S + P.train_off + (size_t)quad * 4);
-                    m0 = *reinterpret_cast<const int4*>(A.meta + (size_t)quad * 8);
-                    m1 = *reinterpret_cast<const int4*>(A.meta + (size_t)quad * 8 + 4);
-                }
-                for (int w0 = part * npq; w0 < w1; w0 += 16) {
-                    float4 tq[16];
+        float l_recon = 0.f, l_dyn = 0.f, ent = 0.f;
+        bool ok_r = true, ok_d = true, ok_h = true, grad_ok = true, have_sums = false;
+        for (int q0 = (sw * NT) >> 3; q0 < nquad || !have_sums; q0 += qstride) {     // (uniform over the workgroup: it holds a barrier)
+            const int quad = q0 + (tid >> 3);
+            const bool act = quad < nquad;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), wo = v;
+            int4 m0 = make_int4(-1, -1, -1, -1), m1 = m0, ix = m0;
+            float4 tq[16];
+            const float* src = A.slab_late + (size_t)(act ? quad : 0) * 4;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        tq[q] = (w0 + q < w1) ? *reinterpret_cast<const float4*>(src + (size_t)(w0 + q) * A.late_len) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
+            for (int q = 0; q < 16; ++q)
+                tq[q] = (act && part * npq + q < w1) ? *reinterpret_cast<const float4*>(src + (size_t)(part * npq + q) * A.late_len) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act && part == 0) {
+                wo = *reinterpret_cast<const float4*>(S + P.train_off + (size_t)quad * 4);
+                m0 = *reinterpret_cast<const int4*>(A.meta + (size_t)quad * 8);
+                m1 = *reinterpret_cast<const int4*>(A.meta + (size_t)quad * 8 + 4);
+                ix = *reinterpret_cast<const int4*>(A.imgidx + (size_t)quad * 4);
+            }
+            if (!have_sums) {
+                // loss sums of the step: fp64, 32 strided partial sums per scalar, then a fixed xor tree (every SGD workgroup, for the guards)
+                if (tid < 32 * RS_SDX2) {
+                    const int sc = tid >> 5, l = tid & 31;
+                    double d = 0.0;
+                    for (int w = l; w < A.n_trial; w += 32) d += (double)A.slab_late[(size_t)w * A.late_len + P.train_len + sc];
+                    d = vjf_sum32(d);
+                    if (l == 0) s_sc[sc] = (float)d;
                 }
-                float vv[4] = {v.x, v.y, v.z, v.w};
+                __syncthreads();
+                l_recon = s_sc[RS_LRECON] * invB; l_dyn = s_sc[RS_LDYN] * invB; ent = s_sc[RS_ENT] * invB;
+                ok_r = isfinite(l_recon); ok_d = isfinite(l_dyn); ok_h = isfinite(ent);
+                grad_ok = ok_r && ok_h && ok_d;
+                have_sums = true;
+            }
+            for (int wq = part * npq + 16; wq < w1; wq += 16) {                   // (more than 128 trial workgroups: further rounds)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    vv[r] += __shfl_xor(vv[r], 1, 64);
-                    vv[r] += __shfl_xor(vv[r], 2, 64);
-                    vv[r] += __shfl_xor(vv[r], 4, 64);
-                }
-                if (part != 0) continue;
-                const float wold[4] = {wo.x, wo.y, wo.z, wo.w};
-                const int grp[4] = {m0.x, m0.z, m1.x, m1.z}, ax[4] = {m0.y, m0.w, m1.y, m1.w};
+                for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (grp[r] < 0 || (grp[r] == 1 && freeze)) continue;        // (alignment padding between tensors; frozen decoder)
-                    float g = vv[r] * invB;
-                    g = fminf(fmaxf(g, -1.f), 1.f);                            // clip_grad_value_ (model.py:210)
-                    const float wn = wold[r] - (grp[r] == 1 ? lr_dec : lr_rec) * g;
-                    mg_st(S + P.train_off + quad * 4 + r, wn);
-                    if (ax[r] >= 0) mg_st(A.aux + ax[r], wn);
-                }
+                for (int q = 0; q < 16; ++q)
+                    tq[q] = (act && wq + q < w1) ? *reinterpret_cast<const float4*>(src + (size_t)(wq + q) * A.late_len) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
+            float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                vv[r] += __shfl_xor(vv[r], 1, 64);
+                vv[r] += __shfl_xor(vv[r], 2, 64);
+                vv[r] += __shfl_xor(vv[r], 4, 64);
+            }
+            if (!act || part != 0 || !grad_ok) continue;
+            const float wold[4] = {wo.x, wo.y, wo.z, wo.w};
+            const int grp[4] = {m0.x, m0.z, m1.x, m1.z}, ax[4] = {m0.y, m0.w, m1.y, m1.w}, im[4] = {ix.x, ix.y, ix.z, ix.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (grp[r] < 0 || (grp[r] == 1 && freeze)) continue;            // (alignment padding between tensors; frozen decoder)
+                float g = vv[r] * invB;
+                g = fminf(fmaxf(g, -1.f), 1.f);                                // clip_grad_value_ (model.py:210)
+                const float wn = wold[r] - (grp[r] == 1 ? lr_dec : lr_rec) * g;
+                mg_st(S + P.train_off + quad * 4 + r, wn);
+                if (tl) { if (im[r] >= 0) mg_st(const_cast<float*>(A.img) + im[r], wn); }
+                else if (ax[r] >= 0) mg_st(A.aux + ax[r], wn);
             }
         }
         if (t == 0 && mg_ld(SC + VJF_SC_TRI_CLEAN) == 0.f) {
