@@ -101,29 +101,46 @@ def cpu_baseline(c, config, s32, q0, y_cpu, eps_cpu, budget_s=12.0):
     y_cpu, eps_cpu = y_cpu.astype(np.float32), eps_cpu.astype(np.float32)
     orc.RBF_GEMM = True
     try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    step = [0]
+
+    def run(nsteps, **kw):
+        nonlocal mu, lv
         t0 = time.perf_counter()
-        for t in range(2):                                       # discard two steps (allocator / thread-pool warm-up)
-            o = orc.filter_step(s, y_cpu[t], None, mu, lv, eps_cpu[t, 0], eps_cpu[t, 1])
+        for _ in range(nsteps):
+            t = step[0]; step[0] += 1
+            o = orc.filter_step(s, y_cpu[t], None, mu, lv, eps_cpu[t, 0], eps_cpu[t, 1], **kw)
             mu, lv = o.mu_t, o.lv_t
-        t1 = (time.perf_counter() - t0) / 2
-        nstep = int(min(max(budget_s / max(t1, 1e-5), 5), y_cpu.shape[0] - 5))
-        t0 = time.perf_counter()
-        for t in range(2, 2 + nstep):
-            o = orc.filter_step(s, y_cpu[t], None, mu, lv, eps_cpu[t, 0], eps_cpu[t, 1])
-            mu, lv = o.mu_t, o.lv_t
-        dt = time.perf_counter() - t0
-        val = c["B"] * nstep / dt
+        return (time.perf_counter() - t0) / nsteps
+    try:
+        run(2)                                                   # discard two steps (allocator / thread-pool warm-up)
+        # BLAS threads: these matrices are small, every core of a large host is not the fastest setting -- take the best of a few
+        best = (run(3), threads)
+        if threadpool_limits is not None:
+            for nt in (8, 16, 32, 64):
+                if nt < threads:
+                    with threadpool_limits(limits=nt):
+                        tt = run(3)
+                    if tt < best[0]:
+                        best = (tt, nt)
+        t1, threads = best
+        nstep = int(min(max(budget_s / max(t1, 1e-5), 5), y_cpu.shape[0] - step[0] - 3, 400))
         nf = 2
-        t0 = time.perf_counter()
-        for t in range(2 + nstep, 2 + nstep + nf):
-            o = orc.filter_step(s, y_cpu[t], None, mu, lv, eps_cpu[t, 0], eps_cpu[t, 1], faithful_cost=True)
-            mu, lv = o.mu_t, o.lv_t
-        dtf = time.perf_counter() - t0
+        if threadpool_limits is not None:
+            with threadpool_limits(limits=threads):
+                dt = run(nstep) * nstep
+                dtf = run(nf, faithful_cost=True) * nf
+        else:
+            dt = run(nstep) * nstep
+            dtf = run(nf, faithful_cost=True) * nf
+        val = c["B"] * nstep / dt
     finally:
         orc.RBF_GEMM = False
     ref = REFERENCE_CPU.get(config, {})
     return {"value": val, "unit": "trial-timesteps/s", "cores": int(threads), "kind": "port",
-            "sample": f"{nstep} steps of the bench workload from the timed run's own state (B={c['B']}, fp32 numpy/BLAS oracle, O(B) variance "
+            "sample": f"(BLAS threads: the fastest of 8/16/32/64/all over 3 steps each) {nstep} steps of the bench workload from the timed run's own state (B={c['B']}, fp32 numpy/BLAS oracle, O(B) variance "
                       f"form, GEMM distances), {dt:.1f} s; the reference's cost form ((B,B) product for its diagonal): "
                       f"{c['B'] * nf / dtf:.0f} trial-timesteps/s over {nf} steps; the UNMODIFIED reference (torch CPU) on the survey's 8 Xeon "
                       f"cores, BASELINE.md section 2: {json.dumps(ref)}",
@@ -195,23 +212,32 @@ def main():
 
     # warm-up (untimed): also sizes the context and, for N > 1, the RCCL communicators
     q = None
-    if W > 0:
-        mu, lv, _ = model.filter_sequence(y[:W], eps=eps[:W])
+    if W > 0:                                                   # (two calls when W > 1: the second takes the posterior of the first, as the timed calls do)
+        w1 = W - 1 if W > 1 else W
+        mu, lv, _ = model.filter_sequence(y[:w1], eps=eps[:w1])
         q = vjf_amd.Gaussian(mu[-1], lv[-1])
-    barrier()
-    # the oracle's copies of the state the timed region starts from (the checker of the ELBO and the CPU baseline; nothing of the
-    # timed path goes through them)
+        if w1 < W:
+            mu, lv, _ = model.filter_sequence(y[w1:W], qs=q, eps=eps[w1:W])
+            q = vjf_amd.Gaussian(mu[-1], lv[-1])
+    # (the allocator's cache holds blocks of the timed regions' output sizes before the first of them runs, as it does in any loop
+    #  that has been running for a while: two sets, a region's outputs are alive while the next one's are allocated)
+    prime = [torch.empty(K, c["B"], c["dz"], device=dev) for _ in range(4)] + [torch.empty(K, 4, device=dev) for _ in range(2)]
+    del prime
+    # the state the timed region starts from, kept on the device (the oracle's copies -- the checker of the ELBO and the CPU
+    # baseline; nothing of the timed path goes through them -- are made from it AFTER the timed regions: no host work, and no idle
+    # device, between the warm-up steps and the timed ones)
     checker = rank == 0 and world == 1 and not (a.no_elbo_check and a.no_cpu_baseline)
-    s64 = s32 = None
-    q0 = None if q is None else (q.mean.cpu().numpy().astype(np.float64), q.logvar.cpu().numpy().astype(np.float64))
-    if checker:
-        from tests.helpers import load_oracle_state
-        s64, s32 = load_oracle_state(model, np.float64), load_oracle_state(model, np.float32)
+    snap = model._blob.clone() if checker else None
+    q0d = None if q is None else (q.mean.clone(), q.logvar.clone())
+    barrier()
     walls, devs, enqs, elbos, first_losses = [], [], [], [], None
     stream = torch.cuda.current_stream()                         # the stream vjf_filter_seq launches on (vjf_set_stream)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(R)]
+    for e0, e1 in evs:                                           # (the events exist before the first timed region)
+        e0.record(stream); e1.record(stream)
     for r in range(R):
         lo = W + r * K
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1 = evs[r]
         barrier()
         t0 = time.perf_counter()
         ev0.record(stream)
@@ -230,6 +256,17 @@ def main():
         q = vjf_amd.Gaussian(mu[-1], lv[-1])
     status = model.status()
     wall_max, dev_s, enq = walls[0], devs[0], enqs[0]           # `value`: the first region = exactly K steps after W warm-up steps
+    s64 = s32 = q0 = None
+    if checker:
+        from tests.helpers import load_oracle_state
+        torch.manual_seed(0)
+        twin = vjf_amd.VJF.make_model(c["dy"], c["dz"], c["du"], c["n"], c["hidden"], likelihood=c["lik"], noise="device")
+        for g_t, g_m in zip(twin.optimizer.param_groups, model.optimizer.param_groups):
+            g_t["lr"] = g_m["lr"]
+        twin._blob.copy_(snap)
+        s64, s32 = load_oracle_state(twin, np.float64), load_oracle_state(twin, np.float32)
+        q0 = None if q0d is None else (q0d[0].cpu().numpy().astype(np.float64), q0d[1].cpu().numpy().astype(np.float64))
+        del twin
 
     # ELBO of the first timed steps against the oracle on identical state / inputs / noise
     elbo_check = None

@@ -309,7 +309,68 @@ def test_nonfinite_loss_is_flagged(vjf):
     st = model.status()
     assert st & 1, st                      # VJF_STATUS_NONFINITE_RECON
     assert float(recon) == 0.0             # replaced by the constant 0 (model.py:138-139)
-    assert np.isfinite(float(loss))
+
+
+@pytest.mark.parametrize("which", ["recon", "dynamics"])
+def test_nonfinite_component_is_dropped_like_the_reference(vjf, which):
+    """vjf/model.py:138-149: a loss component whose batch mean is not finite becomes the constant 0 -- the step's gradient is that
+    of the OTHER components, clipped and applied as usual.  Overflow in fp32 (the reference's dtype): the oracle runs in fp32 too.
+      recon:    Poisson, one decoder bias at -3e38 and counts of 2 there: -y * eta overflows, everything else stays finite;
+      dynamics: w_chol scaled by 1e25: the predictive variance and with it the 'trace' term exp(logvar sums) overflow.
+    The flagged step is replayed inside the launch (the middle of a sequence) and behind the last step of a call (filter())."""
+    import warnings
+    lik = "poisson" if which == "recon" else "gaussian"
+    B, dz, dy, n, T = 40, 3, 10, 16, 4
+    g = torch.Generator().manual_seed(31)
+    y = torch.poisson(torch.exp(0.3 * torch.randn(T, B, dy, generator=g)), generator=g) if lik == "poisson" else torch.randn(T, B, dy, generator=g)
+    eps = torch.randn(T, 2, B, dz, generator=g)
+
+    def fresh():
+        torch.manual_seed(30)
+        m = vjf.VJF.make_model(dy, dz, 0, n, [8], likelihood=lik, lr=1e-2)
+        return m
+
+    def poison(m):
+        with torch.no_grad():
+            if which == "recon":
+                m.decoder.decode.bias[0] = -3e38
+            else:
+                m.transition.velocity.w_chol.mul_(1e25)
+    if which == "recon":
+        y[:, :, 0] = 2.0
+    bit = 1 if which == "recon" else 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                     # (numpy's overflow warnings in the fp32 oracle)
+        # (1) the second step of a sequence
+        m = fresh()
+        mu0, lv0, _ = m.filter_sequence(y[:1], eps=eps[:1])
+        poison(m)
+        s = load_oracle_state(m, np.float32)
+        mu, lv, loss = m.filter_sequence(y[1:], qs=vjf.Gaussian(mu0[-1], lv0[-1]), eps=eps[1:])
+        st = m.status()
+        assert st & bit and not (st & ~0x7 & ~8), hex(st)
+        om, ol = mu0[-1].cpu().numpy(), lv0[-1].cpu().numpy()
+        for t in range(1, T):
+            o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
+            om, ol = o.mu_t, o.lv_t
+            close(mu[t - 1], o.mu_t, rtol=2e-4, atol=2e-4)
+            close(loss[t - 1], [o.loss, o.recon, o.dyn, o.entropy], rtol=2e-4, atol=2e-4)
+            if t == 1:
+                assert (o.recon if which == "recon" else o.dyn) == 0.0
+        state_close(m, s, rtol=2e-3, atol=2e-4, rls_rtol=2e-2, rls_atol=2e-3)
+        # (2) the only step of a call: the replay runs behind the last step
+        m = fresh()
+        poison(m)
+        s = load_oracle_state(m, np.float32)
+        w_before = m.recognition.mean.weight.clone()
+        q, l1, *comp = m.filter(y[0], eps=(eps[0, 0], eps[0, 1]), verbose=True)
+        assert m.status() & bit
+        o = orc.filter_step(s, y[0].numpy(), None, None, None, eps[0, 0].numpy(), eps[0, 1].numpy())
+        close(q.mean, o.mu_t, rtol=2e-4, atol=2e-4)
+        close(torch.stack([l1, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=2e-4, atol=2e-4)
+        state_close(m, s, rtol=2e-3, atol=2e-4, rls_rtol=2e-2, rls_atol=2e-3)
+    # the other components' gradient was applied (a skipped step would leave the recognition weights where they were)
+    assert (m.recognition.mean.weight - w_before).abs().max() > 1e-4
 
 
 def test_rls_failure_is_flagged_and_leaves_rls_state(vjf):

@@ -196,7 +196,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
 }
 
 struct Carve {
-    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_meta, mg_img, mg_imgidx; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_meta, mg_img, mg_imgidx, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -231,6 +231,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
         c.mg_meta = take((size_t)P.train_len * 8);
         c.mg_img = take((size_t)vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).th_len * 4 + 64);   // the parameters in the trial role's LDS layout
         c.mg_imgidx = take((size_t)P.train_len * 4);
+        c.mg_pmsave = take((size_t)max_batch * (P.dz + 1) * 4);
     }
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
@@ -781,6 +782,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     A.y = y; A.u = u; A.eps = eps; A.mu0 = mu0; A.lv0 = lv0; A.mu = mu; A.lv = lv; A.loss = loss;
     A.state = c->state; A.aux = (float*)(c->ws + c->cv.aux);
     A.img = (const float*)(c->ws + c->cv.mg_img); A.imgidx = (const int*)(c->ws + c->cv.mg_imgidx);
+    A.pmsave = (float*)(c->ws + c->cv.mg_pmsave);
     A.slab_early = (float*)(c->ws + c->cv.mg_early); A.slab_late = (float*)(c->ws + c->cv.mg_late); A.gslab = (float*)(c->ws + c->cv.mg_gslab);
     A.red0 = rede[0]; A.red1 = rede[1];
     A.gbuf = (float*)(c->ws + c->cv.work);
@@ -810,6 +812,12 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     VjfPlan Pk = P;
     void* args[] = {(void*)&Pk, (void*)&A, (void*)&C, (void*)&Q};
     const int grid = m.n_rls + m.n_trial + m.n_gram + m.n_prep + m.n_sgd;
+    static const bool plain = getenv("VJF_DEBUG_PLAIN_LAUNCH") && atoi(getenv("VJF_DEBUG_PLAIN_LAUNCH")) != 0;   // (measurements only)
+    if (plain) {
+        hipLaunchKernelGGL(vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), kMegaLds, c->stream, Pk, A, C, Q);
+        VJF_HIP(hipGetLastError());
+        return 0;
+    }
     VJF_HIP(hipLaunchCooperativeKernel((const void*)vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), args, (unsigned)kMegaLds, c->stream));
     return 0;
 }

@@ -38,10 +38,6 @@
 
 // counters: one per 64-byte line of the block that the host zeroes before every launch
 enum {
-    MG_C_PHI = 0,        // trial workgroups whose Phi rows of an EVEN event e are in memory    target (e / 2 + 1) n_trial
-    MG_C_PHI1 = 176,     // ... of an odd event.  (Two counters: a workgroup signals event e + 1 at the end of step e without waiting for
-                         // anybody's event e -- at step 0 both are its own -- so one count could reach an event's target with a
-                         // workgroup missing.  It cannot run two events ahead: step e + 1 starts behind everybody's late slab of step e.)
     MG_C_FWD = 16,       // trial workgroups whose early slab of step t is in memory           target (t + 1) n_trial
     MG_C_K1 = 32,        // trial workgroups that have read W, w_chol, sigma of step t - 1      target (t + 1) n_trial
     MG_C_BWD = 48,       // trial workgroups whose late slab of step t is in memory            target (t + 1) n_trial
@@ -51,6 +47,9 @@ enum {
     MG_C_SGD = 112,      // SGD workgroups done with step t                                    target (t + 1) n_sgd
     MG_C_PDONE = 128,    // RLS workgroups (y / W loop + inverse loops) done with step t       target (t + 1) (2 nbl + 1)
     MG_C_STARTED = 144,
+    MG_C_REDO_B = 0,     // trial workgroups whose REPLAYED late slab is in memory             target (replays so far) n_trial
+    MG_C_REDO_S = 176,   // SGD workgroups done with a replayed step                         target (replays so far) n_sgd
+    MG_C_MASK = 192,     // (step + 1) << 8 | non-finite loss components (1 recon, 2 dynamics, 4 entropy) of the last step that had one
     MG_C_COLFLAGS = 160, // [0 .. VJF_CHOL_MAXBLK]: column flags of the Cholesky loop; [VJF_CHOL_MAXBLK + 2]: its "operands loaded" word
     MG_C_WORDS = 256
 };
@@ -63,6 +62,7 @@ struct VjfMegaArgs {
     float* state; float* aux;
     const float* img;                                 // the optimised parameters as the trial role's LDS holds them (vjf_mega_trial_lds: theta region)
     const int* imgidx;                                // per trainable element: its index in `img` (-1: alignment padding)
+    float* pmsave;                                    // (B, dz + 1): pt.mean | pt.logvar of every trial at its last step (for a replayed backward pass)
     float* slab_early; float* slab_late; float* gslab;
     float* red0; float* red1;                         // reduce buffers of even / odd steps ([G | FDX | sums], as the RLS loops read them)
     float* gbuf;                                      // g (n, dz)
@@ -325,30 +325,57 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     }
     __syncthreads();
 
-    for (int t = 0; t < A.T; ++t) {
+    // A step whose loss has a non-finite component (model.py:138-145) is REPLAYED: the SGD role sees the sums only when every
+    // workgroup's backward pass is done, publishes which components to drop and leaves the parameters alone; the trial role finds
+    // that word when it fetches the parameters for the next step, runs the flagged step's forward and backward pass again --
+    // same parameters, same inputs, the predictive mean / variance it saved, the dropped components' seeds exactly zero --, hands
+    // over a second late slab, waits for the SGD role's (unconditional) step on it and only then starts over with the next step.
+    // Nothing of this costs the usual step anything but one more word read beside rho.  Step index T is the gate alone.
+    float sig_prev = 0.f, rho_prev = 0.f;
+    unsigned nredo = 0;
+    for (int t = 0; t <= A.T; ++t) {
+      bool replay = false, replayed = false;
+      unsigned rbits = 0;
+      for (;;) {
+        const int ts = replay ? t - 1 : t;             // the step whose inputs this pass stages
+        bool want_replay = false;
         // (the thread index is made opaque at every phase boundary: what the compiler derives from it -- dozens of per-thread LDS and
         //  memory offsets, one set per loop of the step -- is then formed in the phase that uses it instead of at the top of the step,
         //  where it was kept, and spilled to scratch memory, across the whole step)
         int tid = tid0, lane, wave;
         MG_PHASE();
-        const float* y_t = A.y + (size_t)t * sy;
-        const float* u_t = A.u ? A.u + (size_t)t * su : nullptr;
-        const float* mu_s = t ? A.mu + (size_t)(t - 1) * sz : A.mu0;
-        const float* lv_s = t ? A.lv + (size_t)(t - 1) * sz : A.lv0;
-        const float* eps_s = A.eps + (size_t)t * 2 * sz;
+        const int tc = min(ts, A.T - 1);               // (the gate pass of step T stages nothing)
+        const float* y_t = A.y + (size_t)tc * sy;
+        const float* u_t = A.u ? A.u + (size_t)tc * su : nullptr;
+        const float* mu_s = tc ? A.mu + (size_t)(tc - 1) * sz : A.mu0;
+        const float* lv_s = tc ? A.lv + (size_t)(tc - 1) * sz : A.lv0;
+        const float* eps_s = A.eps + (size_t)tc * 2 * sz;
         const float* eps_t = eps_s + sz;
-        float* mu_t = A.mu + (size_t)t * sz;
-        float* lv_t = A.lv + (size_t)t * sz;
+        float* mu_t = A.mu + (size_t)tc * sz;
+        float* lv_t = A.lv + (size_t)tc * sz;
         const bool prior = (mu_s == nullptr);
+        const bool m_r = !(rbits & 1u), m_d = !(rbits & 2u), m_h = !(rbits & 4u);   // components kept (all of them unless replaying)
         // early slabs alternate between two sets: the operand role may read step t's long after this workgroup has started
         // step t + 1 (it also waits for the Gram of step t); step t + 2 starts behind the RLS update of step t, which consumed them
-        float* early = A.slab_early + ((size_t)(t & 1) * A.n_trial + wg) * A.early_len;
+        float* early = A.slab_early + ((size_t)(tc & 1) * A.n_trial + wg) * A.early_len;
         VJF_MG_STAMP(0);
         if (tid < 16) s_wg[tid] = 0.f;
-        float sig = 0.f, rho = 0.f;
-        bool tri = false, rls_in = false;
+        float sig = sig_prev, rho = rho_prev;          // (a replayed pass: the values its step ran with)
+        bool tri = false, rls_in = replay;
+        // the parameters of step t - 1 (the SGD role's write-through stores) and its verdict on that step's loss
+        auto gate = [&]() {
+            if (t > 0) {
+                if (!vjf_wg_wait(cnt + MG_C_SGD, (unsigned)t * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS))
+                    vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
+                if (!replayed) {
+                    const unsigned mw = __hip_atomic_load(cnt + MG_C_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((mw >> 8) == (unsigned)t) { rbits = mw & 7u; want_replay = true; }
+                }
+            }
+        };
+        if (ts >= A.T) gate();                         // (behind the last step: only that)
         int it = 0;
-        for (int tile = wg; tile < A.ntiles; tile += A.n_trial, ++it) {
+        for (int tile = wg; tile < A.ntiles && ts < A.T; tile += A.n_trial, ++it) {
             const bool first = it == 0, last = it == ntl - 1;
             const int b0 = tile * TR;
             const int nb = min(TR, A.B - b0);
@@ -405,7 +432,8 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
                 __syncthreads(); MG_PHASE();
                 if (first) VJF_MG_STAMP(21);
-                // ---- stage 1: RBF features (functional.py:11-22)
+                // ---- stage 1: RBF features (functional.py:11-22); a replayed pass needs none (its predictive mean / variance are saved)
+                if (!replay)
                 for (int e = tid; e < TR * n; e += NT) {
                     const int k = e >> 5, b = e & 31;
                     float d2 = 0.f;
@@ -418,7 +446,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             // ---- the RLS update of the previous step (W, w_chol, sigma: write-through stores of the RLS roles), if it is complete
             //      already: its acquire and the L2 warm-up then cost nothing on the path parameters -> forward -> backward.  If not,
             //      the same happens behind the forward pass (below): the values read are the same either way.
-            if (first) {
+            if (first && !replay) {
                 rls_in = t == 0;
                 if (t > 0) {
                     if (tid == 0) {
@@ -435,19 +463,19 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;               // w_chol known upper triangular
                 }
             }
-            // ---- theta of the previous step (the SGD role's write-through stores).  Nothing above depends on it: the inputs and the
-            //      features of a step are ready before the parameters are
-            if (first && t > 0) {
-                if (!vjf_wg_wait(cnt + MG_C_SGD, (unsigned)t * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS))
-                    vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
+            // ---- theta of the previous step.  Nothing above depends on it: the inputs and the features of a step are ready before the
+            //      parameters are
+            if (first && !replay) {
+                gate();
                 if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
-                if (!tl) {
+                if (want_replay) break;                                        // (uniform: every thread read the same word)
+                if (t > 0 && !tl) {
                     mg_warm(A.aux, P.aux_len, wg, tid);                        // (see mg_warm)
                     mg_warm(S + P.train_off, P.train_len, wg, tid);
                 }
             }
-            if (first) rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);            // (the SGD role's)
-            if (first && tl) {
+            if (first && !replay) rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);  // (the SGD role's)
+            if (first && tl && !replay) {                                      // (a replayed pass: they are in LDS, untouched since its step)
                 // the parameters of this step into LDS: the image the SGD role keeps has the layout of the region, so this is a flat
                 // 16-byte copy with all of a thread's loads in flight -- one round trip
                 const float4* src = reinterpret_cast<const float4*>(A.img);
@@ -524,6 +552,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 s_xt[j * LD + b] = xt;
                 s_dx[j * LD + b] = b < nb ? xt - s_xu[j * LD + b] : 0.f;
             }
+            if (!replay)
             for (int e = tid; e < nb * dz; e += NT) {                          // coalesced posterior stores
                 const int b = mg_div(e, m_dz), j = e - b * dz;
                 mg_st(mu_t + (size_t)(b0 + b) * dz + j, s_mu[j * LD + b]);         // (write-through: the Gram role forms the next step's
@@ -556,7 +585,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             }
             if (first) VJF_MG_STAMP(25);
             // early slab: Phi^T dx of this tile (module.py:94), 16 features x 16 columns per MFMA tile, K = 32 trials
-            {
+            if (!replay) {
                 const int mt = (n + 15) >> 4;
                 for (int tt = NW - 1 - wave; tt < mt; tt += NW) {
                     const int m0 = tt * 16, i = lane & 15, kk = lane >> 4;
@@ -580,14 +609,14 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
             }
             __syncthreads(); MG_PHASE();
-            if (tid == 0) {
+            if (tid == 0 && !replay) {
                 float v = 0.f;
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + RS_SDX2];
                 s_wg[RS_SDX2] += v;
                 if (last) mg_st(early + (size_t)n * 16 + RS_SDX2, s_wg[RS_SDX2]);
             }
             if (first) VJF_MG_STAMP(26);
-            if (last) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
+            if (last && !replay) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
             if (first) VJF_MG_STAMP(4);
             if (last) VJF_MG_STAMPX(28, -1);
             // ---- the RLS update of the previous step, if it had not landed before the forward pass
@@ -601,7 +630,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             }
             if (first) VJF_MG_STAMP(5);
             // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
-            {
+            if (!replay) {
                 const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
                 const int ntile = (n + 15) >> 4;
                 float v2a = 0.f, v2b = 0.f;
@@ -635,19 +664,32 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 mean_nsl = nsl;
             }
             __syncthreads(); MG_PHASE();
-            if (last && tid == 0) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
-            if (tid < TR) {
-                float v = 0.f;
-                for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
-                s_plv[tid] = logf(v);
-            }
-            for (int e = tid; e < TR * dz; e += NT) {
-                const int j = e >> 5, b = e & 31;
-                float v = 0.f;
-                for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
-                s_pm[j * LD + b] = s_xu[j * LD + b] + v;
+            if (last && tid == 0 && !replay) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
+            if (!replay) {
+                if (tid < TR) {
+                    float v = 0.f;
+                    for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
+                    s_plv[tid] = logf(v);
+                }
+                for (int e = tid; e < TR * dz; e += NT) {
+                    const int j = e >> 5, b = e & 31;
+                    float v = 0.f;
+                    for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
+                    s_pm[j * LD + b] = s_xu[j * LD + b] + v;
+                }
             }
             __syncthreads(); MG_PHASE();
+            // pt.mean | pt.logvar of the tile's trials: kept for a replay of this step (by then W and w_chol have moved on)
+            for (int e = tid; e < TR * (dz + 1); e += NT) {
+                const int j = e >> 5, b = e & 31;
+                if (b < nb) {
+                    float* sv = A.pmsave + (size_t)(b0 + b) * (dz + 1) + j;
+                    if (!replay) *sv = j < dz ? s_pm[j * LD + b] : s_plv[b];
+                    else if (j < dz) s_pm[j * LD + b] = *sv;
+                    else s_plv[b] = *sv;
+                }
+            }
+            if (replay) { __syncthreads(); MG_PHASE(); }
             if (first) VJF_MG_STAMP(6);
             // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
             {
@@ -662,7 +704,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                         const float r = pv - yv, dsc = yv * p - pv * p;
                         lrec += 0.5f * (dsc * dsc + rho);
                         ssey = fmaf(r, r, ssey);
-                        s_dpy[i * LD + b] = ok ? e * r : 0.f;
+                        s_dpy[i * LD + b] = (ok && m_r) ? e * r : 0.f;
                     }
                 } else {                                                       // likelihood.py:51-62
                     for (int i = s; i < dy; i += LPT) {
@@ -671,7 +713,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                         lrec += ex - yv * eta;
                         const float r = pv - yv;
                         ssey = fmaf(r, r, ssey);
-                        s_dpy[i * LD + b] = (ok && pv <= 10.f) ? (ex - yv) : 0.f;
+                        s_dpy[i * LD + b] = (ok && m_r && pv <= 10.f) ? (ex - yv) : 0.f;
                     }
                 }
                 lrec = group_sum<LPT>(lrec);
@@ -685,8 +727,8 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                         const float tr = expf(plv + lv - sig);
                         ldyn += 0.5f * (dsc * dsc + sig) + 0.5f * tr;
                         ent += 0.5f * lv;                                      // functional.py:25-29
-                        float dmu = 0.f, dlv = -0.5f;
-                        if (!warm) { dmu = -e * (mp - mu); dlv += 0.5f * tr; }
+                        float dmu = 0.f, dlv = m_h ? -0.5f : 0.f;
+                        if (!warm && m_d) { dmu = -e * (mp - mu); dlv += 0.5f * tr; }
                         s_dmu[j * LD + b] = ok ? dmu : 0.f;
                         s_dlv[j * LD + b] = ok ? dlv : 0.f;
                     }
@@ -701,7 +743,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
             }
             __syncthreads(); MG_PHASE();
-            if (tid < RS_SDX2) {                                               // (RS_LRECON, RS_LDYN, RS_ENT, RS_SSEY)
+            if (tid < RS_SDX2 && !replay) {                                    // (RS_LRECON, RS_LDYN, RS_ENT, RS_SSEY)
                 float v = 0.f;
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + tid];
                 s_wg[tid] += v;
@@ -810,13 +852,26 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (last) {
                 // the workgroup's late slab is complete: loss sums, then the signal the SGD role waits for
                 __syncthreads(); MG_PHASE();
-                if (tid < RS_SDX2) mg_st(late + P.train_len + tid, s_wg[tid]);
-                vjf_wg_signal_wt(cnt + MG_C_BWD, tid);
+                if (tid < RS_SDX2 && !replay) mg_st(late + P.train_len + tid, s_wg[tid]);
+                vjf_wg_signal_wt(cnt + (replay ? MG_C_REDO_B : MG_C_BWD), tid);
                 VJF_MG_STAMP(9);
                 VJF_MG_STAMPX(29, 30);
             }
         }
         VJF_MG_STAMP(18);
+        if (want_replay) { replay = true; continue; }
+        if (replay) {
+            // the SGD role's step on the replayed late slabs; then this step starts over (inputs, features, parameters)
+            ++nredo;
+            if (!vjf_wg_wait(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS))
+                vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
+            if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+            replay = false; replayed = true; rbits = 0;
+            continue;
+        }
+        sig_prev = sig; rho_prev = rho;
+        break;
+      }
     }
 }
 
@@ -1130,13 +1185,25 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     const int npq = (A.n_trial + 7) >> 3, part = tid & 7;
     const int nquad = P.train_len >> 2, qstride = (A.n_sgd * NT) >> 3;
     const int w1 = min(A.n_trial, (part + 1) * npq);
+    unsigned nredo = 0;
     for (int t = 0; t < A.T; ++t) {
-        if (!vjf_wg_wait(A.cnt + MG_C_BWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
-            vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
+      float l_recon = 0.f, l_dyn = 0.f, ent = 0.f;
+      bool ok_r = true, ok_d = true, ok_h = true, grad_ok = true;
+      // pass 0: the step.  A loss with a non-finite component (not all three: then the gradient is zero, model.py:206-214) leaves
+      // the parameters alone and publishes which components the trial role is to drop; pass 1 steps on its replayed late slabs
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 0) {
+            if (!vjf_wg_wait(A.cnt + MG_C_BWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
+                vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
+        } else {
+            ++nredo;
+            if (!vjf_wg_wait(A.cnt + MG_C_REDO_B, nredo * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
+                vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
+            grad_ok = true;
+        }
         if (vjf_abort_seen(SC + VJF_SC_STATUS)) return;
         { const int wg = sw; VJF_MG_STAMP(16); }
-        float l_recon = 0.f, l_dyn = 0.f, ent = 0.f;
-        bool ok_r = true, ok_d = true, ok_h = true, grad_ok = true, have_sums = false;
+        bool have_sums = pass == 1;
         for (int q0 = (sw * NT) >> 3; q0 < nquad || !have_sums; q0 += qstride) {     // (uniform over the workgroup: it holds a barrier)
             const int quad = q0 + (tid >> 3);
             const bool act = quad < nquad;
@@ -1198,7 +1265,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
                 else if (ax[r] >= 0) mg_st(A.aux + ax[r], wn);
             }
         }
-        if (t == 0 && mg_ld(SC + VJF_SC_TRI_CLEAN) == 0.f) {
+        if (pass == 0 && t == 0 && mg_ld(SC + VJF_SC_TRI_CLEAN) == 0.f) {
             // one-time clearing of the halves the inverse loops never write (block-lower part of w_chol, block-upper part of
             // w_pchol): every reader of the dense w_chol of step 0 has signalled its late slab
             float* Wc = S + P.off[VJF_SLOT_W_CHOL];
@@ -1210,7 +1277,10 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
                 if ((i >> 5) > (j >> 5)) mg_st(Wc + e, 0.f);
             }
         }
-        if (sw == 0 && tid == 0) {                                             // ---- scalars: loss, likelihood log-variance
+        const unsigned bad = (ok_r ? 0u : 1u) | (ok_d ? 0u : 2u) | (ok_h ? 0u : 4u);
+        const bool redo = pass == 0 && bad != 0u && bad != 7u;
+        if (pass == 0 && sw == 0 && tid == 0) {                                // ---- scalars: loss, likelihood log-variance
+            if (redo) __hip_atomic_store(A.cnt + MG_C_MASK, ((unsigned)(t + 1) << 8) | bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!ok_r) l_recon = 0.f;
             if (!ok_d) l_dyn = 0.f;
             if (!ok_h) ent = 0.f;
@@ -1222,7 +1292,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
             if (P.lik == VJF_LIK_GAUSSIAN) {
                 const float sse_y = s_sc[RS_SSEY];
                 float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
-                if (grad_ok) {
+                if (ok_r) {                                                    // (its gradient comes from the reconstruction term alone)
                     float g = 0.5f * ((float)P.dy - expf(-rho) * sse_y * invB);
                     g = fminf(fmaxf(g, -1.f), 1.f);
                     rho -= SC[VJF_SC_LR_LIK] * g;
@@ -1235,8 +1305,10 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
             }
         }
         __syncthreads();
-        vjf_wg_signal_wt(A.cnt + MG_C_SGD, tid);
+        vjf_wg_signal_wt(A.cnt + (pass == 0 ? MG_C_SGD : MG_C_REDO_S), tid);
         { const int wg = sw; VJF_MG_STAMP(17); }
+        if (!redo) break;
+      }
     }
     // (the launch's last act on the triangle flag: set once every SGD workgroup has cleared its share -- they all have signalled
     //  step 0 by then; the kernel boundary makes it visible to the next launch)
