@@ -373,6 +373,24 @@ def test_nonfinite_component_is_dropped_like_the_reference(vjf, which):
     assert (m.recognition.mean.weight - w_before).abs().max() > 1e-4
 
 
+def test_timed_out_handoff_ends_the_launch_and_raises(vjf, monkeypatch):
+    """A hand-off inside the one-launch route that runs out of its bound (injected: the Cholesky loop reports its statistics wait
+    of step 3 as timed out): every role leaves its loop at its next wait (nothing hangs, the grid drains), the sticky status
+    carries a WAIT bit and `check_status` -- what fit() calls after every sequence -- raises."""
+    torch.manual_seed(8)
+    model = vjf.VJF.make_model(10, 3, 0, 40, [8], likelihood="gaussian")
+    g = torch.Generator().manual_seed(9)
+    y, eps = torch.randn(12, 64, 10, generator=g), torch.randn(12, 2, 64, 3, generator=g)
+    model.filter_sequence(y[:2], eps=eps[:2])
+    assert model.route() == "one-launch" and model.check_status() == 0
+    monkeypatch.setenv("VJF_DEBUG_INJECT", "4")
+    model.filter_sequence(y, eps=eps)
+    monkeypatch.delenv("VJF_DEBUG_INJECT")
+    with pytest.raises(RuntimeError, match="timed out"):
+        model.check_status()
+    assert model.status() == 0                                   # (cleared by the read)
+
+
 def test_rls_failure_is_flagged_and_leaves_rls_state(vjf):
     """A precision matrix that is not positive definite: the reference's fallback raises (module.py:104-112); here the RLS
     tensors stay as they were, the status bit is raised and nothing hangs -- through the single-step path and through the

@@ -629,7 +629,6 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     g.E = (const float*)(c->ws + (gen ? c->cv.E2 : c->cv.E)); g.ACT = (const float*)(c->ws + c->cv.ACT); g.DEL = (const float*)(c->ws + c->cv.DEL);
     g.slabs = (float*)(c->ws + c->cv.slabs);
     g.B = B; g.nsplit = nsplit; g.job0 = job0;
-    g.status = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
     hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(VJF_GRAM_THREADS), 0, st, P, g);
     VJF_HIP(hipGetLastError());
@@ -802,6 +801,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     C.wait_count = cnt + MG_C_PDONE; C.wait_target = 0; C.wait_stride = npost;
     C.stat_count = cnt + MG_C_STAT; C.stat_target = (unsigned)m.n_gram; C.stat_stride = (unsigned)m.n_gram;
     C.nsteps = T; C.step0 = 0;
+    { const char* ie = getenv("VJF_DEBUG_INJECT"); C.inject_epoch = ie ? (unsigned)atoi(ie) : 0u; }   // (test hook: a hand-off of step k - 1 reports a time-out)
     VjfPostArgs Q{};
     Q.state = c->state; Q.dinv = dinv; Q.gbuf = A.gbuf; Q.lscr = C.lscr; Q.flags = cnt + MG_C_COLFLAGS; Q.epoch = 1; Q.status = stw;
     Q.k1_done = cnt + MG_C_K1; Q.k1_target = (unsigned)m.n_trial; Q.k1_stride = (unsigned)m.n_trial;

@@ -147,128 +147,6 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Slab reduce of the gradient Gram tiles + clip + SGD + scalars in one launch (single rank: nobody else needs the reduced
-// gradient).  Workgroup j < njobs owns gradient tile job0 + j: it sums the tile's split-K slabs in split order (the same
-// order as vjf_gram_reduce_kernel, so both routes give the same bits), clips, steps the parameters the tile covers
-// (model.py:210-211) and keeps their transposed copies in step.  Every workgroup first reduces the trial kernel's loss
-// partials itself (fp64, the reduce kernel's fixed order) for the finite guards (model.py:138-154); the last workgroup
-// does what vjf_prep_kernel's scalar workgroup does.  grid = njobs + 1.
-struct VjfSgdArgs {
-    const VjfJob* jobs;
-    const float* slabs;
-    const float* partial;     // (nblocks_k1, RS_N)
-    float* state;
-    float* aux;
-    float* loss4;
-    int job0, njobs, nsplit, nblocks_k1, B_total;
-    unsigned flags;
-};
-__global__ __launch_bounds__(1024) void vjf_sgd_kernel(VjfPlan P, VjfSgdArgs A) {
-    __shared__ float s_sc[RS_N];
-    const int tid = threadIdx.x;
-    float* S = A.state;
-    float* SC = S + P.off[VJF_SLOT_SCALARS];
-    // one tile element per thread: its slab values are requested first (all in flight under the loss reduction below)
-    float sv[16];
-    const bool tile = (int)blockIdx.x < A.njobs;
-    const float* slab = A.slabs + (size_t)(A.job0 + (tile ? blockIdx.x : 0)) * A.nsplit * 1024;
-    if (tile && A.nsplit <= 16) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) sv[q] = q < A.nsplit ? slab[(size_t)q * 1024 + tid] : 0.f;
-    }
-    // ... and so is everything else the update needs: the job, the learning rates, the parameter itself
-    bool valid = false, dec = false;
-    int tens = 0, pidx = 0;
-    float w_old = 0.f, lr = 0.f;
-    if (tile) {
-        const VjfJob job = A.jobs[A.job0 + blockIdx.x];
-        const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
-        const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
-        const int i = tid >> 5, j = tid & 31;
-        if (i < job.xn && j < job.yn) {
-            if (j < job.ncol_w) { tens = job.tw; pidx = job.dst + i * job.ld + j; valid = true; }
-            else if (j == job.ncol_w && job.dst_b >= 0) { tens = job.tb; pidx = job.dst_b + i; valid = true; }
-        }
-        if (valid) {
-            dec = P.tr_dec[tens] != 0;
-            if (dec && freeze) valid = false;
-            lr = dec ? lr_dec : lr_rec;
-        }
-        if (valid) w_old = S[P.train_off + pidx];
-    }
-    if (tid < 256) {
-        const int sc = tid >> 5, l = tid & 31;
-        double v = 0.0;
-        int b = l;
-        for (; b + 7 * 32 < A.nblocks_k1; b += 8 * 32) {           // 8 loads in flight, summed in the same order
-            float t[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = A.partial[(size_t)(b + 32 * q) * RS_N + sc];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v += (double)t[q];
-        }
-        for (; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
-        v = vjf_sum32(v);
-        if (l == 0) s_sc[sc] = (float)v;
-    }
-    __syncthreads();
-    const bool do_sgd = A.flags & VJF_FLAG_SGD, do_upd = A.flags & VJF_FLAG_UPDATE, warm = A.flags & VJF_FLAG_WARM_UP;
-    const float Bf = (float)A.B_total, invB = 1.0f / Bf;
-    float l_recon = s_sc[RS_LRECON] * invB, l_dyn = s_sc[RS_LDYN] * invB, ent = s_sc[RS_ENT] * invB;
-    const bool ok_r = isfinite(l_recon), ok_d = isfinite(l_dyn), ok_h = isfinite(ent);
-    const bool grad_ok = ok_r && ok_h && (warm || ok_d);
-    if ((int)blockIdx.x < A.njobs) {
-        if (!(do_sgd && grad_ok)) return;
-        {
-            const int e = tid;
-            float v = 0.f;
-            if (A.nsplit <= 16) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) if (q < A.nsplit) v += sv[q];       // split order, as vjf_gram_reduce_kernel sums
-            } else {
-                for (int s2 = 0; s2 < A.nsplit; ++s2) v += slab[(size_t)s2 * 1024 + e];
-            }
-            if (!valid) return;
-            const int cols = P.tr_cols[tens], rel = pidx - (P.tr_off[tens] - P.train_off);
-            const int r = rel / cols, c = rel - r * cols;
-            float g = v * invB;
-            g = fminf(fmaxf(g, -1.f), 1.f);
-            const float w = w_old - lr * g;
-            S[P.train_off + pidx] = w;
-            if (P.tr_aux[tens] >= 0) A.aux[P.tr_aux[tens] + (size_t)c * P.tr_auxld[tens] + P.tr_auxcol[tens] + r] = w;
-        }
-        return;
-    }
-    if (tid == 0) {                                            // ---- scalars: loss, likelihood log-variance
-        if (!ok_r) l_recon = 0.f;
-        if (!ok_d) l_dyn = 0.f;
-        if (!ok_h) ent = 0.f;
-        float loss = l_recon - ent;
-        if (!warm) loss += l_dyn;
-        if (A.loss4) { A.loss4[0] = loss; A.loss4[1] = -l_recon; A.loss4[2] = -l_dyn; A.loss4[3] = ent; }
-        const unsigned st = (ok_r ? 0u : VJF_STATUS_NONFINITE_RECON) | (ok_d ? 0u : VJF_STATUS_NONFINITE_DYN) |
-                            (ok_h ? 0u : VJF_STATUS_NONFINITE_ENT);
-        if (st) vjf_status_or(SC + VJF_SC_STATUS, st);
-        if (P.lik == VJF_LIK_GAUSSIAN) {
-            const float sse_y = s_sc[RS_SSEY];
-            float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
-            if (do_sgd && grad_ok) {
-                float g = 0.5f * ((float)P.dy - expf(-rho) * sse_y * invB);
-                g = fminf(fmaxf(g, -1.f), 1.f);
-                rho -= SC[VJF_SC_LR_LIK] * g;
-            }
-            if (do_upd) {
-                const float mse = sse_y / (Bf * (float)P.dy);
-                const float acc = fminf(SC[VJF_SC_N_LIK], 1000.f), tot = acc + Bf;
-                rho = logf((acc / tot) * expf(rho) + (Bf / tot) * mse);
-                SC[VJF_SC_N_LIK] = tot;
-            }
-            S[P.off[VJF_SLOT_LIK_LOGVAR]] = rho;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // RLS operands, 16 rows of P per workgroup (replaces the row part of vjf_prep_kernel on the fast path):
 //   g[i][:] = sum_k P[i][k] W[k][:] + (Phi^T dx)[i][:] / v     (module.py:94)   on v_mfma_f32_16x16x4_f32, K split over 4 wavefronts
 //   P[i][:] += (Phi^T Phi)[i][:] / v                            (module.py:96)   on the rows just read

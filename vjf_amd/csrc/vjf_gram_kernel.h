@@ -22,9 +22,6 @@ struct VjfGramArgs {
     int B, nsplit, rows_per_split;
     int job0;                // first job of this launch (the grid covers a contiguous job range)
     int high_prio;           // raise the wavefronts' issue priority (the statistics Gram that runs beside the trial kernel)
-    const unsigned* wait_count;   // non-null: the rows come from a kernel on another stream; every workgroup first waits
-    unsigned wait_target;         //   (bounded) until *wait_count has reached wait_target, then acquires at agent scope
-    float* status;
 };
 
 #define VJF_GRAM_WAVES 4            // wavefronts per workgroup (8 was tried: 1.4 us/step slower at config B)
@@ -35,19 +32,6 @@ __global__ __launch_bounds__(VJF_GRAM_THREADS) void vjf_gram_kernel(VjfPlan P, V
     if (A.high_prio) __builtin_amdgcn_s_setprio(3);     // beside the trial kernel's older wavefronts: do not starve
     // linear id = job * nsplit + split: workgroups are dealt round-robin over the 8 XCDs, so with nsplit a
     // multiple of 8 every job of one trial range lands on the same XCD and re-reads its rows from that L2
-    if (A.wait_count) {
-        if (threadIdx.x == 0) {
-            bool there = false;
-            for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
-                if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.wait_target) >= 0) { there = true; break; }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if (!there) vjf_status_or(A.status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-    }
     const int split = blockIdx.x % A.nsplit, jobid = A.job0 + blockIdx.x / A.nsplit;
     const VjfJob job = A.jobs[jobid];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -110,11 +94,6 @@ struct VjfReduceArgs {
     int njobs, nsplit, nblocks_k1;
     int job0;                 // first job of this launch; njobs = jobs in this launch
     unsigned sc_mask;         // which of K1's loss sums the extra workgroup reduces (bit per RS_* index)
-    unsigned kind0_mask;      // E^T E tiles: bit 0 -> write the Phi^T Phi entries, bit 1 -> the Phi^T dx entries (0 = both).  The one-launch-
-                              //   per-step sequence reduces Phi^T Phi early (all tiles, from rows whose dx columns are not there yet)
-                              //   and Phi^T dx late (the tile rows that hold dx, again)
-    unsigned* done_count;     // non-null: += 1 per workgroup once its sums are in memory (consumers that are already running wait
-                              //   for njobs + 1 of them: the persistent RLS kernels of vjf_filter_seq)
 };
 
 // grid = njobs + 1 workgroups of 1024 threads (one tile element each: all of a thread's slab loads are in flight at once);
@@ -122,7 +101,6 @@ struct VjfReduceArgs {
 #define VJF_REDUCE_THREADS 1024
 __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(VjfPlan P, VjfReduceArgs A) {
     const int tid = threadIdx.x;
-    const bool wt = A.done_count != nullptr;      // a kernel that is already running takes the sums: write-through stores
     if ((int)blockIdx.x == A.njobs) {
         // RS_N scalars; 32 threads per scalar accumulate strided partials in double, then a fixed xor tree over the 32
         const int sc = (tid >> 5) & 7, l = tid & 31;
@@ -138,9 +116,8 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
             }
             for (; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
             v = vjf_sum32(v);
-            if (l == 0 && ((A.sc_mask >> sc) & 1u)) { if (wt) vjf_store_wt(A.red + P.red_SC + sc, (float)v); else A.red[P.red_SC + sc] = (float)v; }
+            if (l == 0 && ((A.sc_mask >> sc) & 1u)) A.red[P.red_SC + sc] = (float)v;
         }
-        if (A.done_count) vjf_wg_signal_wt(A.done_count, tid);
         return;
     }
     const VjfJob job = A.jobs[A.job0 + blockIdx.x];
@@ -167,19 +144,14 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
         if (i >= job.xn || j >= job.yn) continue;
         if (job.kind == 0) {
             const int gr = job.ti * VJF_TILE + i, gc = job.tj * VJF_TILE + j;   // gr: X column, gc: Y column of E
-            const unsigned km = A.kind0_mask ? A.kind0_mask : 3u;
             if (gr < P.n) {
-                if ((km & 1u) && gc < P.n && gc <= gr) {
-                    if (wt) { vjf_store_wt(A.red + P.red_G + (size_t)gr * P.n + gc, v); vjf_store_wt(A.red + P.red_G + (size_t)gc * P.n + gr, v); }
-                    else { A.red[P.red_G + (size_t)gr * P.n + gc] = v; A.red[P.red_G + (size_t)gc * P.n + gr] = v; }
-                }
-            } else if ((km & 2u) && gr < P.n + P.dz && gc < P.n) {
-                if (wt) vjf_store_wt(A.red + P.red_FDX + (size_t)gc * P.dz + (gr - P.n), v); else A.red[P.red_FDX + (size_t)gc * P.dz + (gr - P.n)] = v;
+                if (gc < P.n && gc <= gr) { A.red[P.red_G + (size_t)gr * P.n + gc] = v; A.red[P.red_G + (size_t)gc * P.n + gr] = v; }
+            } else if (gr < P.n + P.dz && gc < P.n) {
+                A.red[P.red_FDX + (size_t)gc * P.dz + (gr - P.n)] = v;
             }
         } else {
             if (j < job.ncol_w) A.red[job.dst + (size_t)i * job.ld + j] = v;
             else if (j == job.ncol_w && job.dst_b >= 0) A.red[job.dst_b + i] = v;
         }
     }
-    if (A.done_count) vjf_wg_signal_wt(A.done_count, tid);
 }

@@ -38,40 +38,7 @@ __global__ void vjf_linear_kernel(const float* __restrict__ X, int ldx, const fl
     out[i] = act ? tanhf(acc) : acc;
 }
 
-// logvar(B,dout) = log sum_j (feat @ w_chol)[b][j]^2, tiled over dout   (vjf/module.py:75-76, row-sum form)
-__global__ void vjf_blr_logvar_kernel(const float* __restrict__ feat, const float* __restrict__ w_chol, float* __restrict__ logvar,
-                                      int B, int n, int dout) {
-    const int b = blockIdx.x;
-    __shared__ float s_w[4];
-    float v = 0.f;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-        float acc = 0.f;
-        for (int k = 0; k < n; ++k) acc = fmaf(feat[(size_t)b * n + k], w_chol[(size_t)k * n + j], acc);
-        v = fmaf(acc, acc, v);
-    }
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_w[w];
-    const float lv = logf(t);
-    for (int j = threadIdx.x; j < dout; j += blockDim.x) logvar[(size_t)b * dout + j] = lv;
-}
 
-// concat rows: out(B, d1+d2+d3+d4) = [a|b|c|d] (null parts have width 0)
-__global__ void vjf_concat4_kernel(const float* a, int d1, const float* b, int d2, const float* c, int d3, const float* d, int d4,
-                                   float* out, int B) {
-    const int D = d1 + d2 + d3 + d4;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * D) return;
-    const int r = (int)(i / D), col = (int)(i - (size_t)r * D);
-    float v;
-    if (col < d1) v = a[(size_t)r * d1 + col];
-    else if (col < d1 + d2) v = b[(size_t)r * d2 + col - d1];
-    else if (col < d1 + d2 + d3) v = c[(size_t)r * d3 + col - d1 - d2];
-    else v = d[(size_t)r * d4 + col - d1 - d2 - d3];
-    out[i] = v;
-}
 
 // Scalar losses: one workgroup, fp64 accumulation, fixed order.
 //   mode 0: gaussian_loss (functional.py:32-75)  mode 1: gaussian_entropy (:25-29)  mode 2: poisson (likelihood.py:51-62)

@@ -463,25 +463,7 @@ __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_rls_pair_kernel(VjfPlan 
     else vjf_rls_post_loop(P, Q, lds, &s_dead, 1, (int)blockIdx.x - 2);
 }
 
-// Queue probe (vjf_filter_seq, once per context): a kernel that waits (bounded, ~1 ms) for *flag to become `want` and reports
-// a time-out, and one that sets it.  Kernels that spin on kernels of other streams need those streams on hardware queues of
-// their own; the runtime multiplexes streams onto a few queues, so that is checked, not assumed.
-__global__ void vjf_probe_wait_kernel(const unsigned* flag, unsigned want, unsigned* timed_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (unsigned spins = 0; spins < (1u << 12); ++spins) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    __hip_atomic_fetch_add(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void vjf_probe_set_kernel(unsigned* flag, unsigned value) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
-// += add, behind whatever precedes it in its stream (a collective that the consumers of *count wait for)
-__global__ void vjf_count_kernel(unsigned* count, unsigned add) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_fetch_add(count, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // One wavefront that ends when `*count` has reached `target` (bounded): the next kernel of its stream then starts behind the
 // producers on another stream without a cross-stream event (6-13 us on this stack).  It holds no LDS and one wave slot, so
@@ -497,19 +479,6 @@ __global__ __launch_bounds__(64) void vjf_gate_kernel(const unsigned* count, uns
     vjf_status_or(status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
 }
 
-// The same with two counts (both must have reached their targets).
-__global__ __launch_bounds__(64) void vjf_gate2_kernel(const unsigned* count, unsigned target, const unsigned* count2, unsigned target2,
-                                                       float* status) {
-    if (threadIdx.x != 0) return;
-    for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
-        const unsigned v = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned w = __hip_atomic_load(count2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)(v - target) >= 0 && (int)(w - target2) >= 0) return;
-        if ((spins & 255u) == 255u && vjf_abort_seen(status)) return;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    vjf_status_or(status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
-}
 
 struct VjfResidArgs {
     float* state;

@@ -7,7 +7,8 @@
 //   per block column k:     vjf_rlsb_diag_kernel   L_kk, L_kk^-1      (one wavefront: the rank-2 column chain)
 //                           vjf_rlsb_panel_kernel  L_ik = A_ik L_kk^-T (one wavefront per block)
 //                           vjf_rlsb_trail_kernel  A_ij -= L_ik L_jk^T (one wavefront per lower block)
-//   per block row i:        vjf_rlsb_inv_kernel    X_ij = -L_ii^-1 sum_k L_ik X_kj   (X = L^-1, module.py:102)
+//   inverse X = L^-1 (module.py:102): vjf_rlsb_inv_diag_kernel (diagonal blocks), then per level of a binary recursion over the
+//                           block rows vjf_rlsb_inv_t_kernel / vjf_rlsb_inv_x_kernel (T = L_21 X_11, X_21 = -X_22 T)
 //   two GEMMs (vjf_wide_gemm_kernel)        y = X g,  W = X^T y                      (module.py:101)
 //   vjf_rlsb_final_kernel   w_chol = X^T, w_pchol = L, P += Phi^T Phi / v -- or, after a failed pivot, nothing but the status
 // All block products on v_mfma_f32_32x32x2_f32 through the helpers of vjf_chol_kernel.h.  Matrices are padded to a
@@ -125,46 +126,6 @@ __global__ __launch_bounds__(64) void vjf_rlsb_trail_kernel(VjfPlan P, VjfRlsbAr
     rlsb_acc_out(acc, Lm, n, bi, bj, lane, false);
 }
 
-// block row i of X = L^-1; workgroup j (one wavefront): X_ij.  Launched for i = 0, 1, ..: rows < i are complete.
-__global__ __launch_bounds__(64) void vjf_rlsb_inv_kernel(VjfPlan P, VjfRlsbArgs A) {
-    __shared__ __attribute__((aligned(16))) float s_l[1024], s_x[1024];
-    if (A.ok[0] == 0) return;
-    const int n = P.n, i = A.k, j = blockIdx.x, lane = threadIdx.x;
-    const float* Lm = A.Lw;
-    vjf_f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (j == i) {                                               // X_ii = L_ii^-1
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = lane + 64 * q, r = e >> 5, c = e & 31;
-            const int gi = i * 32 + r, gj = i * 32 + c;
-            if (gi < n && gj < n) A.X[(size_t)gi * n + gj] = A.Dinv[(size_t)i * 1024 + e];
-        }
-        return;
-    }
-    for (int k = j; k < i; ++k) {                               // T = sum_k L_ik X_kj
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = lane + 64 * q, r = e >> 5, c = e & 31;
-            const int li = i * 32 + r, lj = k * 32 + c, xi = k * 32 + r, xj = j * 32 + c;
-            s_l[vsw(r, c)] = (li < n && lj < n) ? Lm[(size_t)li * n + lj] : 0.f;
-            s_x[vsw(r, c)] = (xi < n && xj < n) ? A.X[(size_t)xi * n + xj] : 0.f;
-        }
-        blk_mma<false>(acc, s_l, s_x, 1.f, lane);
-    }
-    blk_store(acc, s_x, lane);                                  // T as the B operand of  X_ij = -L_ii^-1 T
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = lane + 64 * q, r = e >> 5, c = e & 31;
-        s_l[vsw(r, c)] = A.Dinv[(size_t)i * 1024 + e];
-    }
-    vjf_f32x16 x;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = 0.f;
-    blk_mma<false>(x, s_l, s_x, -1.f, lane);
-    rlsb_acc_out(x, A.X, n, i, j, lane, false);
-}
 
 // X = L^-1 by recursive doubling instead of block row after block row (nbl dependent launches with up to nbl - 1 chained
 // block products each): with the diagonal blocks inverted, level l joins pairs of 2^l-tile diagonal blocks,
@@ -233,29 +194,6 @@ __global__ __launch_bounds__(256) void vjf_rlsb_inv_diag_kernel(VjfPlan P, VjfRl
     }
 }
 
-// y = X g  (X block-lower: columns of row r up to the end of its diagonal block)
-__global__ __launch_bounds__(256) void vjf_rlsb_y_kernel(VjfPlan P, VjfRlsbArgs A) {
-    if (A.ok[0] == 0) return;
-    const int n = P.n, dz = P.dz;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < n * dz; e += gridDim.x * 256) {
-        const int r = e / dz, c = e - r * dz, kend = min(n, ((r >> 5) + 1) * 32);
-        float acc = 0.f;
-        for (int k = 0; k < kend; ++k) acc = fmaf(A.X[(size_t)r * n + k], A.gbuf[(size_t)k * dz + c], acc);
-        A.ybuf[e] = acc;
-    }
-}
-// W = X^T y  (cholesky_solve, module.py:101)
-__global__ __launch_bounds__(256) void vjf_rlsb_w_kernel(VjfPlan P, VjfRlsbArgs A) {
-    if (A.ok[0] == 0) return;
-    const int n = P.n, dz = P.dz;
-    float* Wm = A.state + P.off[VJF_SLOT_W_MEAN];
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < n * dz; e += gridDim.x * 256) {
-        const int k = e / dz, c = e - k * dz;
-        float acc = 0.f;
-        for (int r = (k >> 5) * 32; r < n; ++r) acc = fmaf(A.X[(size_t)r * n + k], A.ybuf[(size_t)r * dz + c], acc);
-        Wm[e] = acc;
-    }
-}
 // w_chol = X^T (module.py:102), zero halves of w_chol / w_pchol, P += Phi^T Phi / v; after a failed pivot only the status bit
 // (the reference's fallback calls the removed torch.eig and raises, module.py:104-112: the RLS state stays as it was)
 __global__ __launch_bounds__(256) void vjf_rlsb_final_kernel(VjfPlan P, VjfRlsbArgs A) {

@@ -83,20 +83,10 @@ struct VjfTrialMfmaArgs {
                            //   (release at agent scope): the statistics Gram on another stream starts behind vjf_gate_kernel on it
     const unsigned* rls_done;  // backward half: workgroups of the previous step's post kernel that have their W, w_chol, sigma in
     unsigned rls_target;       //   memory; non-null -> the workgroup waits (bounded) for the count before stage 2, its reloads done
-    // part 3, statistics one step ahead: Phi of the NEXT step depends only on this step's posterior, xs' = mu_t + eps_s' e^{lv_t/2}.
-    // With next_E set the kernel writes those Phi columns (the rows of the next step's parity) right after the posterior and
-    // counts them in phi_done; own_phi = 0 then says that this step's Phi columns were written by the previous launch.
-    float* next_E; const float* next_eps_s; const float* next_u; int own_phi;
-    unsigned* phi_done;    // part 3: += 1 per workgroup once the Phi columns of its E rows are in memory (the Gram of Phi^T Phi starts
-                           //   behind it, before the recognition network has run)
-    int late_prio;         // > 0: the last late_prio workgroups of the grid raise their wavefronts' priority (see the kernel)
     int part;              // 0: whole step; 1: forward half (features, recognition, E / ACT rows, posterior);
                            // 2: backward half (predictive mean / variance, losses, backward, DEL rows) -- reloads the
                            //    forward half's rows, so that it can run after the RLS update of the previous step while
                            //    the forward half of this step ran beside it (vjf_filter_seq, two streams)
-                           // 3: whole step in the order  features -> [Phi rows out, phi_done] -> recognition -> [dx / ACT rows and
-                           //    posterior out, fwd_done] -> [wait: RLS update of the previous step] -> predictive mean / variance,
-                           //    decoder, losses, backward: one launch per step, the statistics leave as early as they exist
 };
 
 #define VJF_K1_STAMP(i)                                                                     \
@@ -119,10 +109,6 @@ static inline size_t vjf_trial_mfma_lds_floats(const VjfPlan& P) {
 
 __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void vjf_trial_mfma_kernel(VjfPlan P, VjfTrialMfmaArgs AA) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // The last workgroups of the grid are the ones that find no CU of their own (16 CUs are taken by the RLS kernels): they run
-    // beside an older workgroup whose wavefronts win the issue arbitration, and finish 10 us after everybody else.  A raised
-    // priority lets the two share the CU evenly: the pair ends earlier than its slower half did.
-    if (AA.late_prio > 0 && (int)blockIdx.x >= (int)gridDim.x - AA.late_prio) __builtin_amdgcn_s_setprio(3);
     const VjfTrialArgs& A = AA.t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * 16;
@@ -132,7 +118,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     const bool prior = (A.mu_s == nullptr);
     const bool warm = (A.flags & VJF_FLAG_WARM_UP) != 0;
     const bool tri = S[P.off[VJF_SLOT_SCALARS] + VJF_SC_TRI_CLEAN] != 0.f;   // w_chol known upper triangular
-    const bool fwd = AA.part != 2, bwd = AA.part != 1, fused3 = AA.part == 3;
+    const bool fwd = AA.part != 2, bwd = AA.part != 1;
     const bool handoff = AA.fwd_done != nullptr && !bwd;        // part 1 inside vjf_filter_seq
     constexpr int LD = VJF_LDT;
     constexpr int NW = VJF_K1M_WAVES;
@@ -225,23 +211,6 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     __syncthreads();
 
-    auto signal_rows = [&](unsigned* count) {                  // producer side of a hand-off to a kernel on another stream
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    if (fused3 && AA.own_phi) {
-        for (int b = wave; b < nb; b += NW) {
-            float* erow = A.E + (size_t)(b0 + b) * P.ldE;
-            for (int c = lane; c < n; c += 64) erow[c] = s_phi[c * LD + b];
-        }
-        if (AA.phi_done) signal_rows(AA.phi_done);
-    }
-
     VJF_K1_STAMP(25);
     // ---- stage 3: recognition forward (recognition.py:31-42)
     if (!fwd) {                                   // backward half: hidden activations from the ACT rows, posterior from the outputs
@@ -300,61 +269,11 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     if (fwd) for (int e = tid; e < nb * dz; e += VJF_K1M_THREADS) {                 // coalesced posterior stores
         const int b = e / dz, j = e - b * dz;
-        if (fused3) {                                                  // (taken by a kernel on another stream behind "rows written")
-            __hip_atomic_store(A.mu_t + (size_t)(b0 + b) * dz + j, s_mu[j * LD + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(A.lv_t + (size_t)(b0 + b) * dz + j, s_lv[j * LD + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            A.mu_t[(size_t)(b0 + b) * dz + j] = s_mu[j * LD + b];
-            A.lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
-        }
+        A.mu_t[(size_t)(b0 + b) * dz + j] = s_mu[j * LD + b];
+        A.lv_t[(size_t)(b0 + b) * dz + j] = s_lv[j * LD + b];
     }
     __syncthreads();
-    if (fused3) {
-        // sum |dx|^2 of this workgroup (as the forward half forms it), needed behind the signal below
-        constexpr int LPT = VJF_K1M_THREADS / 16;
-        const int b = tid / LPT, sl = tid % LPT;
-        float sdx2 = 0.f;
-        for (int j = sl; j < dz; j += LPT) {
-            const float dx = s_xt[j * LD + b] - s_xu[j * LD + b];
-            sdx2 = fmaf(dx, dx, sdx2);
-        }
-        sdx2 = group_sum<LPT>(sdx2);
-        if (sl == 0) s_sc[b * RS_N + RS_SDX2] = b < nb ? sdx2 : 0.f;
-        __syncthreads();
-        if (tid == RS_SDX2) {
-            float v = 0.f;
-            for (int bb = 0; bb < 16; ++bb) v += s_sc[bb * RS_N + tid];
-            __hip_atomic_store(A.partial + (size_t)blockIdx.x * RS_N + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (fused3) {
-        // the rest of the forward half's rows (dx and zero padding of E, all of ACT; the posterior went out in stage 4), the
-        // signal for the kernels that take them, and only then what needs the previous step's RLS update
-        for (int b = wave; b < nb; b += NW) {
-            float* erow = A.E + (size_t)(b0 + b) * P.ldE;
-            for (int c = n + lane; c < P.ldE; c += 64)
-                __hip_atomic_store(erow + c, c < n + dz ? s_xt[(c - n) * LD + b] - s_xu[(c - n) * LD + b] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float* arow = A.ACT + (size_t)(b0 + b) * P.ldA;
-            for (int c = lane; c <= din; c += 64) arow[c] = c < din ? s_in[c * LD + b] : 1.f;
-            int aoff = 0;
-            for (int l = 0; l < P.L; ++l) {
-                const int hl = P.h[l], c0 = P.colA_act[l + 1];
-                for (int k = lane; k <= hl; k += 64) arow[c0 + k] = k < hl ? s_act[(aoff + k) * LD + b] : 1.f;
-                aoff += hl;
-            }
-            for (int j = lane; P.colA_xt + j < P.ldA; j += 64) arow[P.colA_xt + j] = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f);
-        }
-        // What this launch hands to kernels on other streams (the dx columns of E, Phi of the next step, sum |dx|^2) went out as
-        // write-through stores: in memory once vmcnt has drained -- no L2 write-back by 256 workgroups (the ACT rows and the
-        // posterior are for kernels behind this one in its own stream)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            if (AA.fwd_done) __hip_atomic_fetch_add(AA.fwd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    const bool late_dec = fused3 && compact && AA.next_E != nullptr;   // (see the next-step Phi block: it needs the staged centroids)
-    if (bwd && !late_dec) {
+    if (bwd) {
         const float* CT = AA.aux + P.aux_decT;                         // (dz, dy)
         const float* d = S + P.off[VJF_SLOT_DEC_B];
         const int mt = (dy + 15) >> 4;
@@ -408,58 +327,6 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         __syncthreads();
         }
-    if (fused3 && AA.next_E) {
-        // Phi of the next step, exactly as stage 0 / 1 of the next launch will form it (same operations in the same order: the
-        // same bits), written BEHIND the wait above: the rows it overwrites are those of step t-1, whose Phi^T dx Gram is only
-        // known to be finished once the RLS update of step t-1 is (operand kernel -> y / W loop -> sigma).  xs' goes to the
-        // backward seeds' rows (free until stage 5); the centroids are still staged (compact layout: the decoder, whose output
-        // takes their place, runs behind this block).
-        float* s_xn = s_dmu;                                           // dxu <= 3 dz rows (host checks)
-        for (int e = tid; e < 16 * dxu; e += VJF_K1M_THREADS) {
-            const int c = e >> 4, b = e & 15;
-            const size_t g = (size_t)(b0 + (b < nb ? b : 0));
-            float v;
-            if (c < dz) v = fmaf(AA.next_eps_s[g * dz + c], expf(0.5f * s_lv[c * LD + b]), s_mu[c * LD + b]);
-            else v = AA.next_u[g * du + (c - dz)];
-            s_xn[c * LD + b] = v;
-        }
-        __syncthreads();
-        const float* cen_g = S + P.off[VJF_SLOT_CENTROID];
-        const float* lw_g = S + P.off[VJF_SLOT_LOGWIDTH];
-        for (int b = wave; b < nb; b += NW) {
-            float* erow = AA.next_E + (size_t)(b0 + b) * P.ldE;
-            for (int k = lane; k < n; k += 64) {
-                float d2 = 0.f, iw;
-                if (stage_c) {
-                    for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
-                    iw = s_iw[k];
-                } else {
-                    for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - cen_g[k * dxu + c]; d2 = fmaf(d, d, d2); }
-                    const float w = expf(lw_g[k]);
-                    iw = -0.5f / (w * w);
-                }
-                __hip_atomic_store(erow + k, expf(d2 * iw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through)
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0 && AA.phi_done) __hip_atomic_fetch_add(AA.phi_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (bwd && late_dec) {                                         // compact layout: the decoder mean overwrites the staged centroids
-        const float* CT = AA.aux + P.aux_decT;                         // (dz, dy)
-        const float* d = S + P.off[VJF_SLOT_DEC_B];
-        const int mt = (dy + 15) >> 4;
-        for (int t = wave; t < mt; t += NW) {
-            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            mma_tile(acc, CT, dy, dy, t * 16, s_xt, dz, lane);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = t * 16 + 4 * (lane >> 4) + r;
-                if (f < dy) s_py[f * LD + (lane & 15)] = acc[r] + d[f];
-            }
-        }
-    }
-    if (late_dec) __syncthreads();
     VJF_K1_STAMP(24);
     // ---- stage 2 (runs in front of stage 5): predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and
     //      pt.mean = xs + Phi W (module.py:77)
@@ -559,7 +426,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         }
     }
     __syncthreads();
-    if (bwd && tid < RS_N && ((fwd && !fused3) || tid != RS_SDX2)) {   // (the forward half / part owns sum |dx|^2)
+    if (bwd && tid < RS_N && (fwd || tid != RS_SDX2)) {   // (the forward half / part owns sum |dx|^2)
         float v = 0.f;
         if (tid <= RS_SDX2) for (int b = 0; b < 16; ++b) v += s_sc[b * RS_N + tid];
         A.partial[(size_t)blockIdx.x * RS_N + tid] = v;
@@ -633,7 +500,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     // ---- stage 7: rows of E = [Phi | dx | 0], ACT = [in|1|h_1|1|..|h_L|1|xt|1|0], DEL = [.. | dmu | dlv | dpy].
     //      wavefront w writes the rows of trials w, w+4, ...; the lane walks the columns (coalesced, no divisions)
     for (int b = wave; b < nb; b += NW) {
-        if (fwd && !fused3) {
+        if (fwd) {
             float* erow = A.E + (size_t)(b0 + b) * P.ldE;
             for (int c = lane; c < P.ldE; c += 64) {
                 float v = 0.f;
@@ -679,45 +546,6 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(AA.fwd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// Phi of the next step from this step's posterior, for the statistics stream (vjf_filter_seq, one-launch schedule): the Phi^T Phi
-// Gram of step t+1 then runs a step early.  xs' = mu_t + eps_s' e^{lv_t/2}, Phi = exp(-|xu' - c_k|^2 / (2 w_k^2)) with exactly the
-// operations, in the order, of stages 0 / 1 of the trial kernel (which forms the same Phi for itself in the next launch): the
-// same bits.  16 trials per workgroup; writes the Phi columns of the next parity's E rows.
-struct VjfPhiNextArgs {
-    const float* state; const float* mu_t; const float* lv_t; const float* eps_s; const float* u; float* E; int B;
-};
-__global__ __launch_bounds__(256) void vjf_phi_next_kernel(VjfPlan P, VjfPhiNextArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = P.n, dz = P.dz, du = P.du, dxu = P.dxu, b0 = blockIdx.x * 16, nb = min(16, A.B - b0);
-    constexpr int LD = VJF_LDT;
-    float* s_cen = smem;                           // n * dxu
-    float* s_iw = s_cen + n * dxu;                 // n
-    float* s_xn = s_iw + n;                        // dxu x 17
-    const float* S = A.state;
-    const float* cen = S + P.off[VJF_SLOT_CENTROID];
-    const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
-    for (int e = tid; e < n * dxu; e += 256) s_cen[e] = cen[e];
-    for (int e = tid; e < n; e += 256) { const float w = expf(lw[e]); s_iw[e] = -0.5f / (w * w); }
-    for (int e = tid; e < 16 * dxu; e += 256) {
-        const int c = e >> 4, b = e & 15;
-        const size_t g = (size_t)(b0 + (b < nb ? b : 0));
-        float v;
-        if (c < dz) v = fmaf(A.eps_s[g * dz + c], expf(0.5f * A.lv_t[g * dz + c]), A.mu_t[g * dz + c]);
-        else v = A.u[g * du + (c - dz)];
-        s_xn[c * LD + b] = v;
-    }
-    __syncthreads();
-    for (int b = wave; b < nb; b += 4) {
-        float* erow = A.E + (size_t)(b0 + b) * P.ldE;
-        for (int k = lane; k < n; k += 64) {
-            float d2 = 0.f;
-            for (int c = 0; c < dxu; ++c) { const float d = s_xn[c * LD + b] - s_cen[k * dxu + c]; d2 = fmaf(d, d, d2); }
-            erow[k] = expf(d2 * s_iw[k]);
-        }
     }
 }
 

@@ -412,6 +412,18 @@ class VJF(Module):
             return (w, True) if (w > 1 or os.environ.get("VJF_FORCE_DIST") == "1") else (1, False)
         return 1, False
 
+    @staticmethod
+    def _all_reduce_sum(t: Tensor):
+        """Sum over ranks, in place.  A gloo group (several ranks sharing one GPU in tests, or a CPU control plane) gets the
+        buffer through the host; RCCL takes the device tensor as it is."""
+        import torch.distributed as dist
+        if dist.get_backend() == "gloo" and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
     def _native_comm(self, world) -> bool:
         """RCCL communicators inside the context (collective over the ranks; once per context).  False -> the caller keeps
         the all-reduce on its side (vjf_filter_local / torch.distributed.all_reduce / vjf_filter_global)."""
@@ -551,7 +563,7 @@ class VJF(Module):
             import torch.distributed as dist
             N.check(L.vjf_filter_local(self._ctx, B, N.ptr(y), N.ptr(u), N.ptr(mu_s), N.ptr(lv_s), N.ptr(eps_s), N.ptr(eps_t),
                                        N.ptr(mu_t), N.ptr(lv_t), flags), "vjf_filter_local")
-            dist.all_reduce(self._reduce, op=dist.ReduceOp.SUM)      # the ONE collective of a step
+            self._all_reduce_sum(self._reduce)                        # the ONE collective of a step
             N.check(L.vjf_filter_global(self._ctx, B * world, N.ptr(loss4), flags), "vjf_filter_global")
         if update and not warm_up:
             self.transition.velocity._w_colmajor = True      # see LinearRegression._draw_weight_noise
@@ -604,7 +616,7 @@ class VJF(Module):
             for t in range(T):
                 N.check(L.vjf_filter_local(self._ctx, B, N.ptr(y[t]), N.ptr(None if u is None else u[t]), N.ptr(ms), N.ptr(ls),
                                            N.ptr(eps[t, 0]), N.ptr(eps[t, 1]), N.ptr(mu[t]), N.ptr(lv[t]), flags), "vjf_filter_local")
-                dist.all_reduce(self._reduce, op=dist.ReduceOp.SUM)
+                self._all_reduce_sum(self._reduce)
                 N.check(L.vjf_filter_global(self._ctx, B * world, N.ptr(loss[t]), flags), "vjf_filter_global")
                 ms, ls = mu[t], lv[t]
         if update and not warm_up:
