@@ -188,6 +188,7 @@ def main():
     K, W, R = a.steps, a.warmup, max(1, a.repeats)
     if a.config == "E" and a.steps == 200:
         K, W, R = 40, 5, 3                                      # ms-scale steps: keep the default run short
+        a.elbo_steps = min(a.elbo_steps, 2)                     # (an fp64 oracle step takes seconds at this size)
     if a.config == "A" and a.steps == 200:
         K = 2000                                                # T_meas = 2000 for the single-trial configuration
     T = W + K * R

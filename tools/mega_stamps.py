@@ -16,14 +16,14 @@ m.filter_sequence(y[8:])
 torch.cuda.synchronize()
 ev = []
 TR = ["step start", "theta staged", "features done", "recognition done", "early slab out", "RLS(t-1) there", "var+mean done", "seeds+dxt done",
-      "backward+grads done", "late slab out", "", "gram: may start", "gram: partials out", "gram: reduced",
+      "backward+grads done", "late slab out", "moments saved", "gram: may start", "gram: partials out", "gram: reduced",
       "operand: inputs there", "operand: done", "sgd: late slabs there", "sgd: done", "trial: step end", "trial: deltas done", "trial: inputs in LDS", "trial: xs done",
       "trial: wave0 variance tiles done", "trial: rec layers done", "trial: heads partials done", "trial: xt/post/decoder done", "trial: early slab stored"]
 for t in range(max(0, T - 6), T):
     o = (ctypes.c_uint64 * 32)()
     N.check(m._backend().vjf_debug_stamps(m._ctx, 128 + (t & 31), o))
     R = list(o)
-    for i, nm in ((27, "trial: LAST workgroup has theta"), (28, "trial: LAST early slab out"), (29, "trial: LAST late slab out")):
+    for i, nm in ((31, "trial: loss terms + seeds done"), (27, "trial: LAST workgroup has theta"), (28, "trial: LAST early slab out"), (29, "trial: LAST late slab out")):
         if R[i]:
             ev.append((R[i], t, nm))
     if R[30] and t >= 32:        # (kept complemented; a slot holds steps t and t - 32: only the later one's minimum is meaningful)

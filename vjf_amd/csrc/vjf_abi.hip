@@ -170,8 +170,8 @@ bool mega_plan_ok(const VjfPlan& P) {
 bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
     // one workgroup per compute unit: the RLS loops and the operand role have fixed sizes; the trial role gets 128 / 227 of the
     // rest (one 32-trial tile per workgroup at 256 CUs and 4096 trials), the SGD role one 8-lane group per quad of parameters when
-    // half of what is left allows it (a single round of slab loads per step), the Gram role whatever remains (<= 96 rows each in
-    // one pass)
+    // what is left allows it beside a Gram role that takes its rows in one pass of 96 (a single round of slab loads per step), the
+    // Gram role whatever remains
     const int nbl = (P.n + 31) / 32;
     m->n_rls = 2 + 2 * nbl;
     m->n_prep = (P.n + 15) / 16;
@@ -183,8 +183,11 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
     if (cap_t > kMegaMaxTrialWg) cap_t = kMegaMaxTrialWg;
     m->n_trial = m->ntiles < cap_t ? m->ntiles : cap_t;
     const int left = rest - m->n_trial;                                               // >= 2
-    m->n_sgd = ((P.train_len / 4) * 8 + VJF_MG_THREADS - 1) / VJF_MG_THREADS;          // 8 lanes per quad of parameters
-    if (m->n_sgd > left / 2) m->n_sgd = left / 2;
+    int gram_min = (B + VJF_MG_GROWS - 1) / VJF_MG_GROWS;                              // (one pass of rows per Gram workgroup)
+    if (gram_min > left / 2) gram_min = left / 2;
+    if (gram_min < 1) gram_min = 1;
+    m->n_sgd = ((vjf_mega_slab_layout(P).len / 4) * 8 + VJF_MG_THREADS - 1) / VJF_MG_THREADS;   // 8 lanes per quad of the late slab
+    if (m->n_sgd > left - gram_min) m->n_sgd = left - gram_min;
     if (m->n_sgd > 64) m->n_sgd = 64;
     if (m->n_sgd < 1) m->n_sgd = 1;
     m->n_gram = (B + 63) / 64;
@@ -196,7 +199,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
 }
 
 struct Carve {
-    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_meta, mg_img, mg_imgidx, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_imgidx, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -223,14 +226,15 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.pscr = take((size_t)(VJF_CHOL_MAXBLK * (VJF_CHOL_MAXBLK + 1) / 2) * 1024 * 4);   // lower blocks of P, from one Cholesky kernel to the next
     if (mega_plan_ok(P)) {                                 // slabs of the one-launch route, sized for the largest role counts
         const int nbl = (P.n + 31) / 32;
-        c.mg_early = take((size_t)2 * kMegaMaxTrialWg * ((size_t)P.n * 16 + 8) * 4);   // (two sets: even / odd steps)
-        c.mg_late = take((size_t)kMegaMaxTrialWg * ((size_t)P.train_len + 8) * 4);
+        const size_t slab_len = (size_t)vjf_mega_slab_layout(P).len;
+        c.mg_early = take((size_t)2 * kMegaMaxTrialWg * ((size_t)((P.n + 3) & ~3) * 16 + 8) * 4);   // (two sets: even / odd steps)
+        c.mg_late = take((size_t)kMegaMaxTrialWg * (slab_len + 8) * 4);
         c.mg_gslab = take((size_t)kMegaMaxGramWg * (nbl * (nbl + 1) / 2) * 1024 * 4);
         c.mg_cnt = take((size_t)MG_C_WORDS * 4);
         c.mg_stamps = take(32 * 32 * 8);
-        c.mg_meta = take((size_t)P.train_len * 8);
-        c.mg_img = take((size_t)vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).th_len * 4 + 64);   // the parameters in the trial role's LDS layout
+        c.mg_pidx = take(slab_len * 4); c.mg_cidx = take(slab_len * 4); c.mg_grp = take(slab_len);
         c.mg_imgidx = take((size_t)P.train_len * 4);
+        c.mg_img = take((size_t)vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).th_len * 4 + 64);   // the parameters in the trial role's LDS layout
         c.mg_pmsave = take((size_t)max_batch * (P.dz + 1) * 4);
     }
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
@@ -373,25 +377,19 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red2, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red3, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.flags, 0, 256, c->stream);
-    std::vector<int> meta, imgidx;
-    if (c->mega_ok) {                                          // per trainable element: group | index of its transposed copy
-        meta.assign((size_t)P.train_len * 2, -1);
-        for (int t = 0; t < P.n_train; ++t) {
-            const int o = P.tr_off[t] - P.train_off, rows = P.tr_rows[t], cols = P.tr_cols[t];
-            for (int el = 0; el < rows * cols; ++el) {
-                const int r = el / cols, cc = el - r * cols;
-                meta[(size_t)(o + el) * 2] = P.tr_dec[t] ? 1 : 0;
-                meta[(size_t)(o + el) * 2 + 1] = P.tr_aux[t] >= 0 ? P.tr_aux[t] + cc * P.tr_auxld[t] + P.tr_auxcol[t] + r : -1;
-            }
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, c->stream);
-        // ... and its place in the image of the trial role's LDS region (vjf_mega_trial_lds)
+    std::vector<int> pidx, cidx, grpv;
+    if (c->mega_ok) {
+        // the late slab's tables (vjf_mega_slab_layout): per float the parameter it is the gradient of and that parameter's copy
+        // for the trial role -- its place in the image of the LDS region (vjf_mega_trial_lds) when the parameters fit there, else
+        // in the transposed aux copies; per quad the optimizer group
         const VjfMegaTrialLds Lo = vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8);
-        imgidx.assign((size_t)P.train_len, -1);
+        const VjfMegaSlab SL = vjf_mega_slab_layout(P);
+        pidx.assign((size_t)SL.len, -1); cidx.assign((size_t)SL.len, -1); grpv.assign((size_t)SL.len / 4, 0);
+        std::vector<int> img_of((size_t)P.train_len, -1), aux_of((size_t)P.train_len, -1), dec_of((size_t)P.train_len, 0);
         auto place = [&](int slot, int rows, int cols, int at, int ld) {
             const int o = P.off[slot] - P.train_off;
             for (int r = 0; r < rows; ++r)
-                for (int cc = 0; cc < cols; ++cc) imgidx[(size_t)o + (size_t)r * cols + cc] = at - Lo.th0 + r * ld + cc;
+                for (int cc = 0; cc < cols; ++cc) img_of[(size_t)o + (size_t)r * cols + cc] = at - Lo.th0 + r * ld + cc;
         };
         int prev = P.din;
         for (int l = 0; l < P.L; ++l) {
@@ -404,7 +402,38 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
         place(VJF_SLOT_LV_B, 1, P.dz, Lo.th_bl, P.dz);
         place(VJF_SLOT_DEC_W, P.dy, P.dz, Lo.th_dec, Lo.th_ldd);
         place(VJF_SLOT_DEC_B, 1, P.dy, Lo.th_bd, P.dy);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_imgidx, imgidx.data(), imgidx.size() * 4, hipMemcpyHostToDevice, c->stream);
+        for (int t = 0; t < P.n_train; ++t) {
+            const int o = P.tr_off[t] - P.train_off, rows = P.tr_rows[t], cols = P.tr_cols[t];
+            for (int el = 0; el < rows * cols; ++el) {
+                const int r = el / cols, cc = el - r * cols;
+                dec_of[(size_t)o + el] = P.tr_dec[t] ? 1 : 0;
+                aux_of[(size_t)o + el] = P.tr_aux[t] >= 0 ? P.tr_aux[t] + cc * P.tr_auxld[t] + P.tr_auxcol[t] + r : -1;
+            }
+        }
+        // block b of the slab: weight (M, Kin) [+ bias (M)] stored as rows j = 0 .. Kin - 1 [, Kin] of ldm columns m
+        auto block = [&](int b, int slotW, int slotB, int M, int Kin) {
+            const int ow = P.off[slotW] - P.train_off, ob = slotB >= 0 ? P.off[slotB] - P.train_off : -1;
+            for (int j = 0; j < SL.rows[b]; ++j)
+                for (int m2 = 0; m2 < SL.ldm[b]; ++m2) {
+                    const size_t at = (size_t)SL.off[b] + (size_t)j * SL.ldm[b] + m2;
+                    int pe = -1;
+                    if (m2 < M) pe = j < Kin ? ow + m2 * Kin + j : (ob >= 0 ? ob + m2 : -1);
+                    pidx[at] = pe;
+                    if (pe >= 0) {
+                        cidx[at] = Lo.theta ? img_of[(size_t)pe] : aux_of[(size_t)pe];
+                        grpv[at / 4] = dec_of[(size_t)pe];
+                    }
+                }
+        };
+        const int hL = P.h[P.L - 1];
+        block(0, VJF_SLOT_DEC_W, VJF_SLOT_DEC_B, P.dy, P.dz);
+        block(1, VJF_SLOT_MEAN_W, -1, P.dz, hL);
+        block(2, VJF_SLOT_LV_W, VJF_SLOT_LV_B, P.dz, hL);
+        for (int l = P.L - 1; l >= 0; --l) block(3 + (P.L - 1 - l), VJF_SLOT_REC_W0 + 2 * l, VJF_SLOT_REC_B0 + 2 * l, P.h[l], l > 0 ? P.h[l - 1] : P.din);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_imgidx, img_of.data(), img_of.size() * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_pidx, pidx.data(), pidx.size() * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_cidx, cidx.data(), cidx.size() * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_grp, grpv.data(), grpv.size() * 4, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.mg_img, 0, (size_t)Lo.th_len * 4, c->stream);   // (its padding stays 0)
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs`, `meta` (host) must outlive the copies
@@ -780,16 +809,17 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     A.n_rls = m.n_rls; A.n_trial = m.n_trial; A.n_gram = m.n_gram; A.n_prep = m.n_prep; A.n_sgd = m.n_sgd;
     A.y = y; A.u = u; A.eps = eps; A.mu0 = mu0; A.lv0 = lv0; A.mu = mu; A.lv = lv; A.loss = loss;
     A.state = c->state; A.aux = (float*)(c->ws + c->cv.aux);
-    A.img = (const float*)(c->ws + c->cv.mg_img); A.imgidx = (const int*)(c->ws + c->cv.mg_imgidx);
+    A.img = (const float*)(c->ws + c->cv.mg_img);
     A.pmsave = (float*)(c->ws + c->cv.mg_pmsave);
     A.slab_early = (float*)(c->ws + c->cv.mg_early); A.slab_late = (float*)(c->ws + c->cv.mg_late); A.gslab = (float*)(c->ws + c->cv.mg_gslab);
     A.red0 = rede[0]; A.red1 = rede[1];
     A.gbuf = (float*)(c->ws + c->cv.work);
     A.cnt = cnt; A.flags = flags;
-    A.early_len = P.n * 16 + 8; A.late_len = P.train_len + 8;
+    A.slab_len = vjf_mega_slab_layout(P).len;
+    A.early_len = ((P.n + 3) & ~3) * 16 + 8; A.late_len = A.slab_len + 8;
     A.gram_rows = m.gram_rows;
     A.lds_floats = (int)(kMegaLds / 4) - 8;               // (a few static words beside the dynamic region)
-    A.meta = (const int*)(c->ws + c->cv.mg_meta);
+    A.sl_pidx = (const int*)(c->ws + c->cv.mg_pidx); A.sl_cidx = (const int*)(c->ws + c->cv.mg_cidx); A.sl_grp = (const int*)(c->ws + c->cv.mg_grp);
     A.stamps = c->stamps ? (unsigned long long*)(c->ws + c->cv.mg_stamps) : nullptr;
     VjfCholArgs C{};
     C.state = c->state; C.red = rede[0]; C.red2 = rede[1]; C.gbuf = A.gbuf; C.B_total = B; C.flags = flags;

@@ -61,7 +61,6 @@ struct VjfMegaArgs {
     float* mu; float* lv; float* loss;
     float* state; float* aux;
     const float* img;                                 // the optimised parameters as the trial role's LDS holds them (vjf_mega_trial_lds: theta region)
-    const int* imgidx;                                // per trainable element: its index in `img` (-1: alignment padding)
     float* pmsave;                                    // (B, dz + 1): pt.mean | pt.logvar of every trial at its last step (for a replayed backward pass)
     float* slab_early; float* slab_late; float* gslab;
     float* red0; float* red1;                         // reduce buffers of even / odd steps ([G | FDX | sums], as the RLS loops read them)
@@ -71,7 +70,10 @@ struct VjfMegaArgs {
     int early_len, late_len;                          // floats per trial workgroup
     int lds_floats;                                   // dynamic LDS of the launch (floats): decides whether the parameters are staged in it
     int gram_rows;                                    // rows of Phi per Gram workgroup (a multiple of 2)
-    const int* meta;                                  // per trainable element (2 ints): group (-1 padding, 0 recognition, 1 decoder) | index of its transposed copy in aux (-1: none)
+    int slab_len;                                     // floats of gradient per late slab (vjf_mega_slab_layout)
+    const int* sl_pidx;                               // per slab float: the parameter it is the gradient of (index in the train region; -1: padding)
+    const int* sl_cidx;                               // per slab float: that parameter's copy the trial role reads (LDS image, or the transposed aux copy; -1: none)
+    const int* sl_grp;                                // per slab QUAD: 0 recognition, 1 decoder group (learning rate, freeze flag)
     unsigned long long* stamps;                       // diagnostic (null in normal runs): s_memrealtime of workgroup 0 of each role, 32 per step
 };
 
@@ -122,6 +124,25 @@ __host__ __device__ inline VjfMegaTrialLds vjf_mega_trial_lds(const VjfPlan& P, 
 // features park xs' in the 3 dz rows at dmu): take() pads to 4 floats, so dz * LD must be a multiple of 4 or the code below
 // addresses through the struct's offsets only -- it does (no pointer arithmetic across fields except mu -> lv and dmu -> dlv,
 // which are handled explicitly).
+
+// Late slab of a trial workgroup: its tiles' gradients, one block per weight tensor, each block TRANSPOSED -- row j = the input
+// (activation) index, then the bias row; columns = the output units, padded to a multiple of 4 -- so that the four accumulator
+// registers of a lane (four consecutive output units of one input) leave as ONE 16-byte write-through store.  Blocks in the order
+// the backward pass produces them: decoder, mean head, log-variance head, recognition layers L-1 .. 0.
+struct VjfMegaSlab { int off[VJF_MAX_HIDDEN + 3], ldm[VJF_MAX_HIDDEN + 3], rows[VJF_MAX_HIDDEN + 3], len; };
+__host__ __device__ inline VjfMegaSlab vjf_mega_slab_layout(const VjfPlan& P) {
+    VjfMegaSlab L;
+    int o = 0, k = 0;
+    auto blk = [&](int M, int rows) { L.off[k] = o; L.ldm[k] = (M + 3) & ~3; L.rows[k] = rows; o += rows * L.ldm[k]; ++k; };
+    const int hL = P.h[P.L - 1];
+    blk(P.dy, P.dz + 1);                               // 0: decoder  (dy, dz) + bias
+    blk(P.dz, hL);                                     // 1: mean head (dz, hL), no bias
+    blk(P.dz, hL + 1);                                 // 2: log-variance head + bias
+    for (int l = P.L - 1; l >= 0; --l) blk(P.h[l], (l > 0 ? P.h[l - 1] : P.din) + 1);   // 3 + (L-1-l): layer l + bias
+    for (; k < VJF_MAX_HIDDEN + 3; ++k) { L.off[k] = o; L.ldm[k] = 4; L.rows[k] = 0; }
+    L.len = o;
+    return L;
+}
 
 static inline size_t vjf_mega_gram_lds_floats(const VjfPlan& P) {      // rows of Phi | tile table | centroids^T | -1/(2 w^2) | xs rows
     const size_t npad = (size_t)((P.n + 3) & ~3);
@@ -209,8 +230,6 @@ __device__ __forceinline__ int mg_div(int e, unsigned m) { return m ? (int)__umu
 
 __device__ __forceinline__ float mg_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mg_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// slab entry: the first tile of a workgroup in a step stores, later tiles add (the workgroup's own bytes, all through sc1)
-__device__ __forceinline__ void mg_slab(float* p, float v, bool first) { mg_st(p, first ? v : mg_ld(p) + v); }
 
 // L2 warm-up.  Parameters that another role has just rewritten (write-through) sit in memory, and the trial workgroups of an
 // XCD all walk them in the same order at the same time: every batch of operand loads would be a miss that all of them wait
@@ -223,6 +242,22 @@ __device__ __forceinline__ void mg_warm(const float* base, int nfloats, int wg, 
         const float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * 4);
         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
     }
+}
+
+// the same with the loads left in flight (two per thread; a longer range finishes the blocking way): the caller goes on issuing
+// its own loads and retires these behind them
+__device__ __forceinline__ void mg_warm_issue(const float* base, int nfloats, int wg, int tid, float4 (&r)[2]) {
+    const int nq = nfloats >> 2, per = (nq + 15) >> 4, q0 = ((wg >> 3) & 15) * per, q1 = min(nq, q0 + per);
+    r[0] = r[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + tid < q1) r[0] = *reinterpret_cast<const float4*>(base + (size_t)(q0 + tid) * 4);
+    if (q0 + tid + VJF_MG_THREADS < q1) r[1] = *reinterpret_cast<const float4*>(base + (size_t)(q0 + tid + VJF_MG_THREADS) * 4);
+    for (int q = q0 + tid + 2 * VJF_MG_THREADS; q < q1; q += VJF_MG_THREADS) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * 4);
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    }
+}
+__device__ __forceinline__ void mg_warm_retire(const float4 (&r)[2]) {
+    asm volatile("" ::"v"(r[0].x), "v"(r[0].y), "v"(r[0].z), "v"(r[0].w), "v"(r[1].x), "v"(r[1].y), "v"(r[1].z), "v"(r[1].w));
 }
 
 #define VJF_MG_STAMP(i)                                                                     \
@@ -245,9 +280,10 @@ __device__ __forceinline__ void mg_warm(const float* base, int nfloats, int wg, 
         }                                                                                   \
     } while (0)
 
-// one 16x16 tile of  G[m][j] = sum_{b<32} D[m0+m][b] * Bop[j0+j][b],  Bop = [Bact (Kin rows) | ones | 0..]  -> slab
+// one 16x16 tile of  G[m][j] = sum_{b<32} D[m0+m][b] * Bop[j0+j][b],  Bop = [Bact (Kin rows) | ones | 0..]  -> block `blk` of the
+// late slab ([j][ldm], see vjf_mega_slab_layout): a lane's four registers are G[m .. m+3][j], one 16-byte store
 __device__ __forceinline__ void mg_grad_tile(const float* D, int M, int m0, const float* Bact, int Kin, int j0, const float* s_one,
-                                             const float* s_zero, float* slab, int dstW, int ld, int dstB, bool first, int lane) {
+                                             const float* s_zero, float* blk, int ldm, int rows, bool first, int lane) {
     constexpr int LD = VJF_MG_LD;
     const int i = lane & 15, kk = lane >> 4;
     const float* arow = ((m0 + i) < M ? D + (size_t)(m0 + i) * LD : s_zero) + kk;
@@ -263,12 +299,11 @@ __device__ __forceinline__ void mg_grad_tile(const float* D, int M, int m0, cons
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
     }
     acc += acc1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 4 * (lane >> 4) + r, j = j0 + (lane & 15);
-        if (m >= M) continue;
-        if (j < Kin) mg_slab(slab + dstW + (size_t)m * ld + j, acc[r], first);
-        else if (j == Kin && dstB >= 0) mg_slab(slab + dstB + m, acc[r], first);
+    const int mq = m0 + 4 * (lane >> 4), j = j0 + (lane & 15);      // (rows m >= M of D are the zero row: the padding columns get 0)
+    if (j < rows && mq < ldm) {
+        float* p = blk + (size_t)j * ldm + mq;
+        if (!first) { acc[0] += mg_ld(p); acc[1] += mg_ld(p + 1); acc[2] += mg_ld(p + 2); acc[3] += mg_ld(p + 3); }   // (a later tile of the workgroup)
+        mg_st4(p, acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -305,10 +340,12 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     float* s_part = smem + Lo.part;                    // partial tiles of the K-split products (heads, pt.mean)
     constexpr int part_rows = VJF_MG_WAVES * 16;
     int mean_nsl = 1;
-    __shared__ int s_try;
+    __shared__ unsigned s_try[2];
     unsigned* cnt = A.cnt;
     const unsigned npost = (unsigned)(A.n_rls - 1);
     float* late = A.slab_late + (size_t)wg * A.late_len;
+    const VjfMegaSlab SL = vjf_mega_slab_layout(P);
+    const int ldn = (n + 3) & ~3;                      // early slab: [16 columns][ldn] Phi^T dx (transposed), then the scalars
     const size_t sy = (size_t)A.B * dy, su = (size_t)A.B * du, sz = (size_t)A.B * dz;
     int ntl = 0;
     for (int tile = wg; tile < A.ntiles; tile += A.n_trial) ++ntl;
@@ -363,14 +400,30 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         float sig = sig_prev, rho = rho_prev;          // (a replayed pass: the values its step ran with)
         bool tri = false, rls_in = replay;
         // the parameters of step t - 1 (the SGD role's write-through stores) and its verdict on that step's loss
+        // One lane polls the SGD role's count; once it is there it looks -- once -- at the RLS roles' count of the same step, and
+        // at the verdict word; ONE acquire covers whatever it saw complete.
+        bool rls_now = false;
         auto gate = [&]() {
             if (t > 0) {
-                if (!vjf_wg_wait(cnt + MG_C_SGD, (unsigned)t * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS))
-                    vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
-                if (!replayed) {
+                if (tid == 0) {
+                    bool there = false;
+                    for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
+                        if ((int)(__hip_atomic_load(cnt + MG_C_SGD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * (unsigned)A.n_sgd) >= 0) { there = true; break; }
+                        if ((spins & 255u) == 255u && vjf_abort_seen(SCW + VJF_SC_STATUS)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    const bool rls = !rls_in && (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
                     const unsigned mw = __hip_atomic_load(cnt + MG_C_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((mw >> 8) == (unsigned)t) { rbits = mw & 7u; want_replay = true; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    s_try[0] = (there ? 1u : 0u) | (rls ? 2u : 0u);
+                    s_try[1] = mw;
+                    if (!there) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
                 }
+                __syncthreads(); MG_PHASE();
+                rls_now = (s_try[0] & 2u) != 0u;
+                const unsigned mw = s_try[1];
+                if (!replayed && (mw >> 8) == (unsigned)t) { rbits = mw & 7u; want_replay = true; }
             }
         };
         if (ts >= A.T) gate();                         // (behind the last step: only that)
@@ -452,10 +505,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     if (tid == 0) {
                         const bool there = (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
                         if (there) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                        s_try = there ? 1 : 0;
+                        s_try[0] = there ? 1u : 0u;
                     }
                     __syncthreads(); MG_PHASE();
-                    rls_in = s_try != 0;
+                    rls_in = s_try[0] != 0u;
                     if (rls_in) mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
                 }
                 if (rls_in) {
@@ -474,7 +527,15 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     mg_warm(S + P.train_off, P.train_len, wg, tid);
                 }
             }
+            float4 wv[2];
+            const bool warm_now = first && !replay && rls_now && !rls_in;      // the RLS update landed while this workgroup waited for the parameters
             if (first && !replay) rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);  // (the SGD role's)
+            if (warm_now) {
+                mg_warm_issue(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid, wv);
+                sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
+                tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
+                rls_in = true;
+            }
             if (first && tl && !replay) {                                      // (a replayed pass: they are in LDS, untouched since its step)
                 // the parameters of this step into LDS: the image the SGD role keeps has the layout of the region, so this is a flat
                 // 16-byte copy with all of a thread's loads in flight -- one round trip
@@ -490,6 +551,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
                 __syncthreads(); MG_PHASE();
             }
+            if (warm_now) mg_warm_retire(wv);
             if (first) { VJF_MG_STAMP(1); VJF_MG_STAMPX(27, -1); }
             // ---- stage 3: recognition forward (recognition.py:31-42)
             {
@@ -601,10 +663,13 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
                     }
                     acc += acc1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int f = m0 + 4 * (lane >> 4) + r;
-                        if (f < n) mg_slab(early + (size_t)f * 16 + (lane & 15), acc[r], first);
+                    // [dz column][feature]: a lane's four registers are four consecutive features of one column (features >= n: the
+                    // zero row of the A operand)
+                    const int fq = m0 + 4 * (lane >> 4), col = lane & 15;
+                    if (col < dz && fq < ldn) {
+                        float* p = early + (size_t)col * ldn + fq;
+                        if (!first) { acc[0] += mg_ld(p); acc[1] += mg_ld(p + 1); acc[2] += mg_ld(p + 2); acc[3] += mg_ld(p + 3); }
+                        mg_st4(p, acc[0], acc[1], acc[2], acc[3]);
                     }
                 }
             }
@@ -613,7 +678,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 float v = 0.f;
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + RS_SDX2];
                 s_wg[RS_SDX2] += v;
-                if (last) mg_st(early + (size_t)n * 16 + RS_SDX2, s_wg[RS_SDX2]);
+                if (last) mg_st(early + (size_t)16 * ldn + RS_SDX2, s_wg[RS_SDX2]);
             }
             if (first) VJF_MG_STAMP(26);
             if (last && !replay) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
@@ -690,6 +755,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
             }
             if (replay) { __syncthreads(); MG_PHASE(); }
+            if (first) VJF_MG_STAMP(10);
             if (first) VJF_MG_STAMP(6);
             // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
             {
@@ -743,6 +809,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
             }
             __syncthreads(); MG_PHASE();
+            if (first) VJF_MG_STAMP(31);
             if (tid < RS_SDX2 && !replay) {                                    // (RS_LRECON, RS_LDYN, RS_ENT, RS_SSEY)
                 float v = 0.f;
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + tid];
@@ -752,13 +819,12 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             //      operand comes from memory runs BEFORE the first gradient tile goes out: a load issued behind write-through stores
             //      waits for them to reach memory (vmcnt counts in order).
             int gbase = 0;                                                     // running tile count: gradient tiles go round the wavefronts
-            auto grad_tensor = [&](const float* D, int M, const float* Bact, int Kin, int slotW, int slotB) {
-                const int dstW = P.off[slotW] - P.train_off, dstB = slotB >= 0 ? P.off[slotB] - P.train_off : -1;
+            auto grad_tensor = [&](const float* D, int M, const float* Bact, int Kin, int blkid) {
                 const int ntm = (M + 15) >> 4, ntj = (Kin + 1 + 15) >> 4;
                 const unsigned mj = mg_magic(ntj);
                 for (int q = (wave - gbase) & (NW - 1); q < ntm * ntj; q += NW) {                   // this wavefront's tiles of the tensor
                     const int tm = mg_div(q, mj), tj = q - tm * ntj;
-                    mg_grad_tile(D, M, tm * 16, Bact, Kin, tj * 16, s_one, s_zero, late, dstW, Kin, dstB, first, lane);
+                    mg_grad_tile(D, M, tm * 16, Bact, Kin, tj * 16, s_one, s_zero, late + SL.off[blkid], SL.ldm[blkid], SL.rows[blkid], first, lane);
                 }
                 gbase += ntm * ntj;
             };
@@ -827,16 +893,16 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 auto layer_grads = [&](int l, const float* da) {               // weights / bias of recognition layer l from da_l and its input
                     int aoff = 0;
                     for (int q = 0; q < l - 1; ++q) aoff += P.h[q];
-                    grad_tensor(da, P.h[l], l > 0 ? s_act + aoff * LD : s_in, l > 0 ? P.h[l - 1] : din, VJF_SLOT_REC_W0 + 2 * l, VJF_SLOT_REC_B0 + 2 * l);
+                    grad_tensor(da, P.h[l], l > 0 ? s_act + aoff * LD : s_in, l > 0 ? P.h[l - 1] : din, 3 + (P.L - 1 - l));
                 };
                 delta(P.L, nullptr, s_d0);                                     // da_{L-1}
                 __syncthreads(); MG_PHASE();
                 if (P.L >= 2) { delta(P.L - 1, s_d0, s_d1); __syncthreads(); MG_PHASE(); } // da_{L-2}
                 if (first) VJF_MG_STAMP(19);
                 // gradient tiles (write-through stores into the workgroup's late slab)
-                grad_tensor(s_dpy, dy, s_xt, dz, VJF_SLOT_DEC_W, VJF_SLOT_DEC_B);
-                grad_tensor(s_dmu, dz, hact, hL, VJF_SLOT_MEAN_W, -1);
-                grad_tensor(s_dlv, dz, hact, hL, VJF_SLOT_LV_W, VJF_SLOT_LV_B);
+                grad_tensor(s_dpy, dy, s_xt, dz, 0);
+                grad_tensor(s_dmu, dz, hact, hL, 1);
+                grad_tensor(s_dlv, dz, hact, hL, 2);
                 layer_grads(P.L - 1, s_d0);
                 if (P.L >= 2) layer_grads(P.L - 2, s_d1);
                 float* cur = s_d1; float* nxt = s_d0;                          // deeper networks: the two delta buffers alternate
@@ -852,7 +918,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (last) {
                 // the workgroup's late slab is complete: loss sums, then the signal the SGD role waits for
                 __syncthreads(); MG_PHASE();
-                if (tid < RS_SDX2 && !replay) mg_st(late + P.train_len + tid, s_wg[tid]);
+                if (tid < RS_SDX2 && !replay) mg_st(late + A.slab_len + tid, s_wg[tid]);
                 vjf_wg_signal_wt(cnt + (replay ? MG_C_REDO_B : MG_C_BWD), tid);
                 VJF_MG_STAMP(9);
                 VJF_MG_STAMPX(29, 30);
@@ -1068,15 +1134,16 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
         if (!ok) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_OPERAND);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
         { const int wg = pw; VJF_MG_STAMP(14); }
-        // Phi^T dx rows i0 .. i0 + 15 (16 x 16 entries = 64 quads): 8 lanes per quad, lane p sums the early slabs [p npq, (p+1) npq)
-        // (all in flight), then a fixed xor tree
+        // Phi^T dx rows i0 .. i0 + 15 (16 columns x 4 quads of features: the early slabs hold it transposed): 8 lanes per quad, lane p
+        // sums the early slabs [p npq, (p+1) npq) (all in flight), then a fixed xor tree
         {
+            const int ldn = (n + 3) & ~3;
             const float* base = A.slab_early + (size_t)(t & 1) * A.n_trial * A.early_len;
-            const int npq = (A.n_trial + 7) >> 3, part = tid & 7, quad = tid >> 3;      // quad = row * 4 + column quad
-            const int r = quad >> 2, c4 = (quad & 3) * 4;
+            const int npq = (A.n_trial + 7) >> 3, part = tid & 7, quad = tid >> 3;      // quad = column * 4 + feature quad
+            const int c = quad >> 2, r4 = (quad & 3) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 + r < n) {
-                const float* src = base + (size_t)(i0 + r) * 16 + c4;
+            if (c < dz && i0 + r4 < ldn) {
+                const float* src = base + (size_t)c * ldn + i0 + r4;
                 const int w1 = min(A.n_trial, (part + 1) * npq);
                 for (int w0 = part * npq; w0 < w1; w0 += 16) {
                     float4 tq[16];
@@ -1097,13 +1164,13 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
             if (part == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    s_f[r * 17 + c4 + q] = vv[q];
-                    if (i0 + r < n && c4 + q < dz) mg_st(red + P.red_FDX + (size_t)(i0 + r) * dz + c4 + q, vv[q]);
+                    s_f[(r4 + q) * 17 + c] = vv[q];
+                    if (i0 + r4 + q < n && c < dz) mg_st(red + P.red_FDX + (size_t)(i0 + r4 + q) * dz + c, vv[q]);
                 }
             }
             if (pw == 0 && tid < 64) {                                             // sum |dx|^2: one wavefront, strided partial sums, xor tree
                 float q2 = 0.f;
-                for (int w = tid; w < A.n_trial; w += 64) q2 += base[(size_t)w * A.early_len + (size_t)n * 16 + RS_SDX2];
+                for (int w = tid; w < A.n_trial; w += 64) q2 += base[(size_t)w * A.early_len + (size_t)16 * ldn + RS_SDX2];
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
                 if (tid == 0) mg_st(red + P.red_SC + RS_SDX2, q2);
@@ -1179,12 +1246,33 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
     const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
     const bool tl = vjf_mega_trial_lds(P, A.lds_floats).theta != 0;   // the trial role reads the LDS image (else: the state and its transposed copies)
-    // a quad of parameters per 8 lanes: lane p sums the late slabs [p npq, (p+1) npq) (16-byte loads, all in flight together with
+    // a quad of the slab (four consecutive output units of one input: vjf_mega_slab_layout) per 8 lanes: lane p sums the late slabs [p npq, (p+1) npq) (16-byte loads, all in flight together with
     // the quad's old values, its table entries and the step's loss sums), then a fixed xor tree; lane 0 of the group clips and
     // steps its four parameters (model.py:210-211)
     const int npq = (A.n_trial + 7) >> 3, part = tid & 7;
-    const int nquad = P.train_len >> 2, qstride = (A.n_sgd * NT) >> 3;
+    const int nquad = A.slab_len >> 2, qstride = (A.n_sgd * NT) >> 3;
     const int w1 = min(A.n_trial, (part + 1) * npq);
+    // A lane group serves the same quads in every step: the table entries and the parameters of its first round stay in
+    // registers for the whole launch (a longer parameter vector reads the later rounds' from memory each step)
+    const int q00 = (sw * NT) >> 3;
+    int4 k_pi, k_ci;
+    int k_grp;
+    float k_w[4];
+    auto fetch = [&](int quad, int4& pi, int4& ci, int& grp, float (&w)[4]) {
+        pi = make_int4(-1, -1, -1, -1); ci = pi; grp = 0;
+        w[0] = w[1] = w[2] = w[3] = 0.f;
+        if (quad < nquad && part == 0) {
+            pi = *reinterpret_cast<const int4*>(A.sl_pidx + (size_t)quad * 4);
+            ci = *reinterpret_cast<const int4*>(A.sl_cidx + (size_t)quad * 4);
+            grp = A.sl_grp[quad];
+            const float* th = S + P.train_off;
+            if (pi.x >= 0) w[0] = th[pi.x];
+            if (pi.y >= 0) w[1] = th[pi.y];
+            if (pi.z >= 0) w[2] = th[pi.z];
+            if (pi.w >= 0) w[3] = th[pi.w];
+        }
+    };
+    fetch(q00 + (tid >> 3), k_pi, k_ci, k_grp, k_w);
     unsigned nredo = 0;
     for (int t = 0; t < A.T; ++t) {
       float l_recon = 0.f, l_dyn = 0.f, ent = 0.f;
@@ -1204,28 +1292,22 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
         if (vjf_abort_seen(SC + VJF_SC_STATUS)) return;
         { const int wg = sw; VJF_MG_STAMP(16); }
         bool have_sums = pass == 1;
-        for (int q0 = (sw * NT) >> 3; q0 < nquad || !have_sums; q0 += qstride) {     // (uniform over the workgroup: it holds a barrier)
+        // one round: the quads q0 + (tid >> 3).  (Uniform over the workgroup: the first round of a pass holds a barrier.)
+        auto round = [&](int q0, const int4& pi, const int4& ci, int grp, float (&wold)[4]) {
             const int quad = q0 + (tid >> 3);
             const bool act = quad < nquad;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), wo = v;
-            int4 m0 = make_int4(-1, -1, -1, -1), m1 = m0, ix = m0;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 tq[16];
             const float* src = A.slab_late + (size_t)(act ? quad : 0) * 4;
 #pragma unroll
             for (int q = 0; q < 16; ++q)
                 tq[q] = (act && part * npq + q < w1) ? *reinterpret_cast<const float4*>(src + (size_t)(part * npq + q) * A.late_len) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act && part == 0) {
-                wo = *reinterpret_cast<const float4*>(S + P.train_off + (size_t)quad * 4);
-                m0 = *reinterpret_cast<const int4*>(A.meta + (size_t)quad * 8);
-                m1 = *reinterpret_cast<const int4*>(A.meta + (size_t)quad * 8 + 4);
-                ix = *reinterpret_cast<const int4*>(A.imgidx + (size_t)quad * 4);
-            }
             if (!have_sums) {
                 // loss sums of the step: fp64, 32 strided partial sums per scalar, then a fixed xor tree (every SGD workgroup, for the guards)
                 if (tid < 32 * RS_SDX2) {
                     const int sc = tid >> 5, l = tid & 31;
                     double d = 0.0;
-                    for (int w = l; w < A.n_trial; w += 32) d += (double)A.slab_late[(size_t)w * A.late_len + P.train_len + sc];
+                    for (int w = l; w < A.n_trial; w += 32) d += (double)A.slab_late[(size_t)w * A.late_len + A.slab_len + sc];
                     d = vjf_sum32(d);
                     if (l == 0) s_sc[sc] = (float)d;
                 }
@@ -1251,19 +1333,26 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
                 vv[r] += __shfl_xor(vv[r], 2, 64);
                 vv[r] += __shfl_xor(vv[r], 4, 64);
             }
-            if (!act || part != 0 || !grad_ok) continue;
-            const float wold[4] = {wo.x, wo.y, wo.z, wo.w};
-            const int grp[4] = {m0.x, m0.z, m1.x, m1.z}, ax[4] = {m0.y, m0.w, m1.y, m1.w}, im[4] = {ix.x, ix.y, ix.z, ix.w};
+            if (!act || part != 0 || !grad_ok || (grp == 1 && freeze)) return;     // (frozen decoder)
+            const int pidx[4] = {pi.x, pi.y, pi.z, pi.w}, cidx[4] = {ci.x, ci.y, ci.z, ci.w};
+            float* cdst = tl ? const_cast<float*>(A.img) : A.aux;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (grp[r] < 0 || (grp[r] == 1 && freeze)) continue;            // (alignment padding between tensors; frozen decoder)
+                if (pidx[r] < 0) continue;                                     // (padding of the slab's rows)
                 float g = vv[r] * invB;
                 g = fminf(fmaxf(g, -1.f), 1.f);                                // clip_grad_value_ (model.py:210)
-                const float wn = wold[r] - (grp[r] == 1 ? lr_dec : lr_rec) * g;
-                mg_st(S + P.train_off + quad * 4 + r, wn);
-                if (tl) { if (im[r] >= 0) mg_st(const_cast<float*>(A.img) + im[r], wn); }
-                else if (ax[r] >= 0) mg_st(A.aux + ax[r], wn);
+                const float wn = wold[r] - (grp == 1 ? lr_dec : lr_rec) * g;
+                wold[r] = wn;
+                mg_st(S + P.train_off + pidx[r], wn);
+                if (cidx[r] >= 0) mg_st(cdst + cidx[r], wn);
             }
+        };
+        for (int q0 = q00; q0 < nquad || q0 == q00; q0 += qstride) {
+            int4 pi = k_pi, ci = k_ci; int grp = k_grp;
+            float w[4] = {k_w[0], k_w[1], k_w[2], k_w[3]};
+            if (q0 != q00) fetch(q0 + (tid >> 3), pi, ci, grp, w);
+            round(q0, pi, ci, grp, w);
+            if (q0 == q00) { k_w[0] = w[0]; k_w[1] = w[1]; k_w[2] = w[2]; k_w[3] = w[3]; }
         }
         if (pass == 0 && t == 0 && mg_ld(SC + VJF_SC_TRI_CLEAN) == 0.f) {
             // one-time clearing of the halves the inverse loops never write (block-lower part of w_chol, block-upper part of
