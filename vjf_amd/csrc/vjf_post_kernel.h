@@ -113,6 +113,43 @@ __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned 
     return st;
 }
 
+// The y / W workgroup, whose LDS holds all of L, takes in every column that has been published so far in one go -- one acquire,
+// the columns' loads in flight together: a look at the flags from..kmax without waiting (and at the operand role's count for g),
+// s_ctl[0] = 1 if a column reports a failed pivot, s_ctl[1] = the last column found published (from - 1: none new), s_ctl[2] =
+// g is there.  With wait_first the first flag is waited for as post_wait_column does (returns its codes in s_ctl[0]).
+__device__ __forceinline__ void post_peek_columns(const unsigned* flags, unsigned epoch, int from, int kmax, bool wait_first,
+                                                  const unsigned* prep_count, unsigned prep_target, int* s_ctl, int tid, const float* status) {
+    if (tid == 0) {
+        int st = 0, kr = from - 1;
+        if (wait_first) {
+            st = 2;
+            for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
+                const unsigned v = __hip_atomic_load(flags + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 1) == epoch) { st = (int)(v & 1u); break; }
+                if ((spins & 255u) == 255u && vjf_abort_seen(status)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (st == 0) kr = from;
+        }
+        if (st == 0)
+            for (int j = kr + 1; j <= kmax; ++j) {
+                const unsigned v = __hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 1) != epoch) break;
+                if (v & 1u) { st = 1; break; }
+                kr = j;
+            }
+        const int g = prep_count ? ((int)(__hip_atomic_load(prep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - prep_target) >= 0 ? 1 : 0) : 1;
+        if (kr >= from || g) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            __builtin_amdgcn_s_sleep(8);
+        }
+        s_ctl[0] = st; s_ctl[1] = kr; s_ctl[2] = g;
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPostArgs& A, float* lds, int* s_dead, const unsigned it_epoch,
                                                   const float* it_red, const unsigned it_k1_target, const unsigned it_prep_target,
                                                   const bool it_first, const int role, const int bix) {
@@ -204,39 +241,71 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
         if (!vjf_wg_wait(A.prep_count, it_prep_target, tid, A.status)) { vjf_status_or(A.status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_G); *s_dead = 1; }
     };
     // ---- forward  Y_k = Dinv_k R_k ;  R_i -= L_ik Y_k  (i > k),   k = j0 .. nbl-1, column k of L staged when it appears
-    for (int k = j0; k < nbl; ++k) {
-        bad = post_wait_column(A.flags, it_epoch, k, s_ctl, tid, A.status);
-        if (bad) break;
-        if (solve && k == 0) {
-            wait_g();
-            // Everything this workgroup takes from the kernels that precede the Cholesky kernel in its stream (g, the RLS
-            // statistics) is read behind the first column flag of this epoch: the flag says those kernels are complete.
-            for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
-                const int r = e >> 4, c = e & 15;
-                s_x[r * LX + c] = (r < n && c < dz) ? A.gbuf[(size_t)r * dz + c] : 0.f;
-            }
-            if (A.fold_sigma) prefetch_tail();
+    auto stage_column = [&](int k) {   // blocks (i, k), i > k, and Dinv_k; (nbl - k) x 256 float4 chunks, all of a thread's in flight
+        const int nb = nbl - k;
+        float4 v[4];                                                       // nb * 256 <= 7 * 256 <= 4 * 512
+        const int r = (tid >> 3) & 31, c4 = (tid & 7) * 4, bh = tid >> 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int it = 2 * q + bh;                                     // 0: Dinv_k; i = k + it: L block (i, k)
+            const int gi = (k + it) * 32 + r, gj = k * 32 + c4;
+            const bool real = it < nb && (it == 0 || (gi < n && gj < n));  // (padding rows / columns of L are zero)
+            const float* src = it == 0 ? A.dinv + (size_t)k * 1024 + r * 32 + c4 : Lm + (size_t)gi * n + gj;
+            v[q] = *reinterpret_cast<const float4*>(real ? src : A.dinv);
+            if (!real) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        {   // stage column k: blocks (i, k), i > k, and Dinv_k; (nbl - k) x 256 float4 chunks, all of a thread's in flight
-            const int nb = nbl - k;
-            float4 v[4];                                                       // nb * 256 <= 7 * 256 <= 4 * 512
-            const int r = (tid >> 3) & 31, c4 = (tid & 7) * 4, bh = tid >> 8;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int it = 2 * q + bh;                                     // 0: Dinv_k; i = k + it: L block (i, k)
-                const int gi = (k + it) * 32 + r, gj = k * 32 + c4;
-                const bool real = it < nb && (it == 0 || (gi < n && gj < n));  // (padding rows / columns of L are zero)
-                const float* src = it == 0 ? A.dinv + (size_t)k * 1024 + r * 32 + c4 : Lm + (size_t)gi * n + gj;
-                v[q] = *reinterpret_cast<const float4*>(real ? src : A.dinv);
-                if (!real) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) {
+            const int it = 2 * q + bh;
+            if (it < nb) {
+                float* dst = (it == 0 ? dblk(k) : lblk(k + it, k)) + (size_t)r * LB + c4;
+                dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int it = 2 * q + bh;
-                if (it < nb) {
-                    float* dst = (it == 0 ? dblk(k) : lblk(k + it, k)) + (size_t)r * LB + c4;
-                    dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
+        }
+    };
+    int staged = j0;                                           // (y / W workgroup) columns < staged are in LDS
+    for (int k = j0; k < nbl; ++k) {
+        if (!solve) {
+            bad = post_wait_column(A.flags, it_epoch, k, s_ctl, tid, A.status);
+            if (bad) break;
+            stage_column(k);
+        } else {
+            if (k >= staged) {                                 // wait for column k, take whatever else is there with it
+                post_peek_columns(A.flags, it_epoch, k, nbl - 1, true, nullptr, 0u, s_ctl, tid, A.status);
+                bad = s_ctl[0];
+                const int kr = s_ctl[1];
+                __syncthreads();                               // (s_ctl is reused)
+                if (bad) break;
+                for (int k2 = k; k2 <= kr; ++k2) stage_column(k2);
+                staged = kr + 1;
+            }
+            if (k == 0) {
+                // g (and with it the RLS statistics) comes from the operand role, usually after the first columns of L: they are
+                // taken in as they appear while this workgroup waits for it
+                if (!g_there) {
+                    for (unsigned spins = 0;; ++spins) {
+                        post_peek_columns(A.flags, it_epoch, staged, nbl - 1, false, A.prep_count, it_prep_target, s_ctl, tid, A.status);
+                        const int st = s_ctl[0], kr = s_ctl[1], g = s_ctl[2];
+                        __syncthreads();
+                        if (st) { bad = st; break; }
+                        for (int k2 = staged; k2 <= kr; ++k2) stage_column(k2);
+                        if (kr >= staged) staged = kr + 1;
+                        if (g) break;
+                        if (spins >= VJF_SPIN_LIMIT / 8 || ((spins & 63u) == 63u && vjf_abort_seen(A.status))) {
+                            if (tid == 0) { vjf_status_or(A.status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_G); *s_dead = 1; }
+                            break;
+                        }
+                    }
+                    g_there = true;
+                    if (bad) break;
                 }
+                // Everything this workgroup takes from the kernels that precede the Cholesky kernel in its stream (g, the RLS
+                // statistics) is read behind the first column flag of this epoch: the flag says those kernels are complete.
+                for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
+                    const int r = e >> 4, c = e & 15;
+                    s_x[r * LX + c] = (r < n && c < dz) ? A.gbuf[(size_t)r * dz + c] : 0.f;
+                }
+                if (A.fold_sigma) prefetch_tail();
             }
         }
         __syncthreads();
