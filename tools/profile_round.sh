@@ -23,7 +23,8 @@ cp "$f" $O/${TAG}_kernel_stats.csv
 python - <<PY
 import json
 json.dump({"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps $K --warmup $W --repeats 1 --no-cpu-baseline --no-elbo-check",
-           "steps_per_launch": $K, "note": "vjf_mega_kernel: one launch of $W warm-up steps and one of $K timed steps; AverageNs is over both",
+           "steps_per_launch": $K, "steps_in_all_launches": $K + $W,
+           "note": "vjf_mega_kernel: the warm-up steps ($W, in two launches) and ONE launch of the $K timed steps (= MaxNs); AverageNs is over all three launches, TotalDurationNs / ($K + $W) is the time per step",
            "bench_line": json.load(open("$O/${TAG}_stats.json"))}, open("$O/${TAG}_kernel_stats_meta.json", "w"), indent=1)
 PY
 for set in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
@@ -51,7 +52,7 @@ if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     json.dump({"bytes_per_step_corrected": fe + wr, "fetch_bytes_per_step_corrected": fe, "write_bytes_per_step": wr, "steps_per_launch": K,
                "raw": {k: out[k] for k in ("FETCH_SIZE", "WRITE_SIZE")},
                "note": f"rocprofv3 --pmc, separate passes, of the {K}-step vjf_mega_kernel launch of bench.py: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, KB = 1024 B, / {K} steps; "
-                       "`traffic` in the bench line = this x steps_per_launch"}, open(f"{O}/{TAG}_pmc_traffic.json", "w"), indent=1)
+                       "traffic in the bench line = this x steps_per_launch"}, open(f"{O}/{TAG}_pmc_traffic.json", "w"), indent=1)
 json.dump(out, open(f"{O}/{TAG}_pmc_sq.json", "w"), indent=1)
 PY
 find $O -path "*${TAG}_pmc_*" -name "*.csv" -size +5M -delete
