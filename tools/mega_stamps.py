@@ -36,7 +36,7 @@ for t in range(max(0, T - 6), T):
     R = list(o)
     for nm, i in (("chol: step start (stat wait)", 0), ("chol: operands + sigma there, chain starts", 1), ("chol: factor done", 2),
                   ("y/W: first column staged", 17), ("y/W: forward done, factor good, trial readers done", 18), ("y/W: backward done", 19),
-                  ("y/W: W stored", 20), ("y/W: sigma stored", 21)):
+                  ("y/W: W stored", 20), ("y/W: sigma stored", 21), ("inverse loops: LAST one done", 22)):
         if R[i]:
             ev.append((R[i], t, nm))
     for k in range(7):
@@ -46,4 +46,19 @@ ev.sort()
 t0 = ev[0][0]
 for tt, t, nm in ev:
     print(f"{(tt - t0) / 100.0:9.2f} us  [{t}] {nm}")
+# the last step, every trial workgroup: times relative to the earliest "theta staged"
+rows = []
+for j in range(32):
+    o = (ctypes.c_uint64 * 32)()
+    N.check(m._backend().vjf_debug_stamps(m._ctx, 256 + j, o))
+    R = list(o)
+    for k in range(4):
+        w = R[8 * k:8 * k + 8]
+        if w[0]:
+            rows.append((4 * j + k, w))
+if rows:
+    t00 = min(w[0] for _, w in rows)
+    print("last step, per trial workgroup (us after the first one had theta): wg xcc rls-at-gate | theta staged, early slab out, RLS there, var+mean done, grads done, late slab out")
+    for wgi, w in rows:
+        print(f"  {wgi:3d} {w[6]:2d} {w[7]} | " + " ".join(f"{(x - t00) / 100.0:7.2f}" for x in w[:6]))
 print("status", m.status())

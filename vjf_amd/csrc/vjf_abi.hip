@@ -231,7 +231,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
         c.mg_late = take((size_t)kMegaMaxTrialWg * (slab_len + 8) * 4);
         c.mg_gslab = take((size_t)kMegaMaxGramWg * (nbl * (nbl + 1) / 2) * 1024 * 4);
         c.mg_cnt = take((size_t)MG_C_WORDS * 4);
-        c.mg_stamps = take(32 * 32 * 8);
+        c.mg_stamps = take((32 * 32 + kMegaMaxTrialWg * 8) * 8);   // ring of role stamps | 8 words per trial workgroup (last step)
         c.mg_pidx = take(slab_len * 4); c.mg_cidx = take(slab_len * 4); c.mg_grp = take(slab_len);
         c.mg_imgidx = take((size_t)P.train_len * 4);
         c.mg_img = take((size_t)vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).th_len * 4 + 64);   // the parameters in the trial role's LDS layout
@@ -523,9 +523,10 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status) {
 int vjf_debug_stamps(vjf_ctx* ctx, int enable, uint64_t* out32) {
     if (!ctx) return fail(-1, "vjf_debug_stamps: null context");
     int ring = 0;
-    if (enable >= 128) {                                     // 128 + k: the one-launch route's role stamps of step k % 32 (32 words)
-        if (out32 && ctx->mega_ok) {
-            VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.mg_stamps + (size_t)((enable - 128) & 31) * 256, 256, hipMemcpyDeviceToHost, ctx->stream));
+    if (enable >= 128) {                                     // 128 + k: the one-launch route's role stamps of step k % 32 (32 words);
+        if (out32 && ctx->mega_ok) {                         // 256 + j: the last step's 8 words of trial workgroups 4 j .. 4 j + 3
+            const size_t at = enable >= 256 ? (size_t)32 * 256 + (size_t)((enable - 256) % (kMegaMaxTrialWg / 4)) * 256 : (size_t)((enable - 128) & 31) * 256;
+            VJF_HIP(hipMemcpyAsync(out32, ctx->ws + ctx->cv.mg_stamps + at, 256, hipMemcpyDeviceToHost, ctx->stream));
             VJF_HIP(hipStreamSynchronize(ctx->stream));
         }
         return 0;

@@ -626,7 +626,8 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // operands in registers: the state's P may now be overwritten
             __syncthreads();
             if (tid == 0) __hip_atomic_store(A.flags_out + VJF_CHOL_MAXBLK + 2, it_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!vjf_wg_wait(A.wait_count, it_wait_target, tid, SC + VJF_SC_STATUS)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
+            // (no acquire: the one thing read behind this wait is sigma, with an sc1 load)
+            if (!vjf_wg_wait_sc1(A.wait_count, it_wait_target, tid, SC + VJF_SC_STATUS)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
             sig = __hip_atomic_load(S + P.off[VJF_SLOT_TR_LOGVAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto g4 = [&](int gi, int gj) {                                 // 4 entries of G, zero outside the matrix

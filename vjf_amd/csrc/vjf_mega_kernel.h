@@ -152,10 +152,24 @@ static inline size_t vjf_mega_prep_lds_floats(const VjfPlan& P) {
     return (size_t)16 * VJF_PREPG_LDP(P.n) + (size_t)P.n * 17 + (size_t)VJF_MG_WAVES * 16 * 17 + 16 * 17 + 64;
 }
 
+__device__ __forceinline__ float mg_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mg_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte sc1 loads (buffer_load_dwordx4 ... sc1): what another workgroup stored write-through, read past this CU's vector L1.
+// The descriptor's base must be workgroup-uniform (it lives in scalar registers); the per-lane part is the 32-bit float index.
+typedef unsigned mg_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mg_rsrc(const float* uniform_base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 mg_ld4(__amdgpu_buffer_rsrc_t r, int float_index) {
+    const mg_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, float_index * 4, 0, 16);               // aux 16 = sc1
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
 // acc_g(row = 4*(lane>>4)+r, col = lane&15) += sum_{kb <= k < ke} Ag[k*lda + m0 + row] * Xs[k*LD + 16 g + col]   (g = 0, 1)
 // Rows m0 + i >= M contribute 0 (their A operand is read from a clamped address and masked).  kb is a multiple of 4.  The A operands come straight from L2 (k-major matrices: row k contiguous over the output features), 16 k-steps per batch,
 // two batches in flight: while one batch's 32 MFMAs issue the next one's loads are on their way (and the SIMD's other wavefront
-// fills what latency is left).
+// fills what latency is left).  The loads are sc1 (they bypass this CU's vector L1): these matrices are rewritten every step by
+// other roles, and the waits in front of them do not acquire.
 __device__ __forceinline__ void mg_mma2(vjf_f32x4& acc0, vjf_f32x4& acc1, const float* __restrict__ Ag, int lda, int M, int m0,
                                         const float* Xs, int kb, int ke, int lane) {
     constexpr int LD = VJF_MG_LD;
@@ -168,7 +182,7 @@ __device__ __forceinline__ void mg_mma2(vjf_f32x4& acc0, vjf_f32x4& acc1, const 
     const int klast = ke - 1;
     auto ld16 = [&](float (&a)[16], int s0) {          // steps s0 .. s0 + 15: clamped rows, masked at use
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { const int k = min(kb + 4 * (s0 + q) + kk, klast); const float v = Ag[row + (unsigned)k * ulda]; a[q] = rv ? v : 0.f; }
+        for (int q = 0; q < 16; ++q) { const int k = min(kb + 4 * (s0 + q) + kk, klast); const float v = mg_ld(Ag + row + (unsigned)k * ulda); a[q] = rv ? v : 0.f; }
     };
     auto mm16 = [&](const float (&a)[16], int s0) {
 #pragma unroll
@@ -228,9 +242,6 @@ __device__ __forceinline__ void mg_st4(float* p, float x, float y, float z, floa
 __device__ __forceinline__ unsigned mg_magic(unsigned d) { return d < 2 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
 __device__ __forceinline__ int mg_div(int e, unsigned m) { return m ? (int)__umulhi((unsigned)e, m) : e; }
 
-__device__ __forceinline__ float mg_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void mg_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // L2 warm-up.  Parameters that another role has just rewritten (write-through) sit in memory, and the trial workgroups of an
 // XCD all walk them in the same order at the same time: every batch of operand loads would be a miss that all of them wait
 // for together.  Instead each workgroup first touches one sixteenth of the range (16-byte loads, all in flight, nothing kept):
@@ -238,8 +249,9 @@ __device__ __forceinline__ void mg_st(float* p, float v) { __hip_atomic_store(p,
 // Which workgroups share an XCD is a placement guess (blockIdx round-robin); a wrong guess costs speed, never correctness.
 __device__ __forceinline__ void mg_warm(const float* base, int nfloats, int wg, int tid) {
     const int nq = nfloats >> 2, per = (nq + 15) >> 4, q0 = ((wg >> 3) & 15) * per;
+    const __amdgpu_buffer_rsrc_t rb = mg_rsrc(base);
     for (int q = q0 + tid; q < min(nq, q0 + per); q += VJF_MG_THREADS) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * 4);
+        const float4 v = mg_ld4(rb, q * 4);
         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
     }
 }
@@ -248,11 +260,12 @@ __device__ __forceinline__ void mg_warm(const float* base, int nfloats, int wg, 
 // its own loads and retires these behind them
 __device__ __forceinline__ void mg_warm_issue(const float* base, int nfloats, int wg, int tid, float4 (&r)[2]) {
     const int nq = nfloats >> 2, per = (nq + 15) >> 4, q0 = ((wg >> 3) & 15) * per, q1 = min(nq, q0 + per);
+    const __amdgpu_buffer_rsrc_t rb = mg_rsrc(base);
     r[0] = r[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q0 + tid < q1) r[0] = *reinterpret_cast<const float4*>(base + (size_t)(q0 + tid) * 4);
-    if (q0 + tid + VJF_MG_THREADS < q1) r[1] = *reinterpret_cast<const float4*>(base + (size_t)(q0 + tid + VJF_MG_THREADS) * 4);
+    if (q0 + tid < q1) r[0] = mg_ld4(rb, (q0 + tid) * 4);
+    if (q0 + tid + VJF_MG_THREADS < q1) r[1] = mg_ld4(rb, (q0 + tid + VJF_MG_THREADS) * 4);
     for (int q = q0 + tid + 2 * VJF_MG_THREADS; q < q1; q += VJF_MG_THREADS) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * 4);
+        const float4 v = mg_ld4(rb, q * 4);
         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
     }
 }
@@ -277,6 +290,16 @@ __device__ __forceinline__ void mg_warm_retire(const float4 (&r)[2]) {
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
             atomicMax(A.stamps + (size_t)(t & 31) * 32 + (i), t_);                          \
             if ((j) >= 0) atomicMax(A.stamps + (size_t)(t & 31) * 32 + (j), ~t_);           \
+        }                                                                                   \
+    } while (0)
+
+// per-workgroup times of the LAST step of a launch (8 words per trial workgroup behind the 32 x 32 ring)
+#define VJF_MG_STAMPW(i)                                                                    \
+    do {                                                                                    \
+        if (A.stamps && tid == 0 && t == A.T - 1 && !replay) {                              \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+            A.stamps[1024 + (size_t)wg * 8 + (i)] = t_;                                     \
         }                                                                                   \
     } while (0)
 
@@ -401,7 +424,8 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         bool tri = false, rls_in = replay;
         // the parameters of step t - 1 (the SGD role's write-through stores) and its verdict on that step's loss
         // One lane polls the SGD role's count; once it is there it looks -- once -- at the RLS roles' count of the same step, and
-        // at the verdict word; ONE acquire covers whatever it saw complete.
+        // at the verdict word.  No acquire: what the trial role takes from other roles (the parameter image, W, w_chol, sigma, rho)
+        // it reads with sc1 loads behind this poll and the workgroup barrier (MI355X guide, "sc1 loads in place of the acquire").
         bool rls_now = false;
         auto gate = [&]() {
             if (t > 0) {
@@ -414,8 +438,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     }
                     const bool rls = !rls_in && (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
                     const unsigned mw = __hip_atomic_load(cnt + MG_C_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!tl) {                                                 // (parameters read from the state with plain loads)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
                     s_try[0] = (there ? 1u : 0u) | (rls ? 2u : 0u);
                     s_try[1] = mw;
                     if (!there) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
@@ -504,7 +530,6 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 if (t > 0) {
                     if (tid == 0) {
                         const bool there = (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
-                        if (there) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                         s_try[0] = there ? 1u : 0u;
                     }
                     __syncthreads(); MG_PHASE();
@@ -539,20 +564,26 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (first && tl && !replay) {                                      // (a replayed pass: they are in LDS, untouched since its step)
                 // the parameters of this step into LDS: the image the SGD role keeps has the layout of the region, so this is a flat
                 // 16-byte copy with all of a thread's loads in flight -- one round trip
-                const float4* src = reinterpret_cast<const float4*>(A.img);
+                const __amdgpu_buffer_rsrc_t r_img = mg_rsrc(A.img);
                 float4* dst = reinterpret_cast<float4*>(smem + Lo.th0);
                 const int n4 = Lo.th_len >> 2;
                 for (int q0 = tid; q0 < n4; q0 += 8 * NT) {
                     float4 v[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) if (q0 + q * NT < n4) v[q] = src[q0 + q * NT];
+                    for (int q = 0; q < 8; ++q) if (q0 + q * NT < n4) v[q] = mg_ld4(r_img, (q0 + q * NT) * 4);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) if (q0 + q * NT < n4) dst[q0 + q * NT] = v[q];
                 }
                 __syncthreads(); MG_PHASE();
             }
             if (warm_now) mg_warm_retire(wv);
-            if (first) { VJF_MG_STAMP(1); VJF_MG_STAMPX(27, -1); }
+            if (first) { VJF_MG_STAMP(1); VJF_MG_STAMPX(27, -1); VJF_MG_STAMPW(0); }
+            if (first && A.stamps && tid == 0 && t == A.T - 1 && !replay) {
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                A.stamps[1024 + (size_t)wg * 8 + 6] = xcc & 15u;
+                A.stamps[1024 + (size_t)wg * 8 + 7] = rls_in ? 1u : 0u;
+            }
             // ---- stage 3: recognition forward (recognition.py:31-42)
             {
                 const float* xin = s_in;
@@ -683,17 +714,17 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (first) VJF_MG_STAMP(26);
             if (last && !replay) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
             if (first) VJF_MG_STAMP(4);
-            if (last) VJF_MG_STAMPX(28, -1);
+            if (last) { VJF_MG_STAMPX(28, -1); VJF_MG_STAMPW(1); }
             // ---- the RLS update of the previous step, if it had not landed before the forward pass
             if (first && !rls_in) {
-                if (!vjf_wg_wait(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS))
+                if (!vjf_wg_wait_sc1(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
                 if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
                 mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
                 sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
                 tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
             }
-            if (first) VJF_MG_STAMP(5);
+            if (first) { VJF_MG_STAMP(5); VJF_MG_STAMPW(2); }
             // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
             if (!replay) {
                 const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
@@ -756,7 +787,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             }
             if (replay) { __syncthreads(); MG_PHASE(); }
             if (first) VJF_MG_STAMP(10);
-            if (first) VJF_MG_STAMP(6);
+            if (first) { VJF_MG_STAMP(6); VJF_MG_STAMPW(3); }
             // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
             {
                 constexpr int LPT = NT / TR;
@@ -914,7 +945,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     float* tmp = cur; cur = nxt; nxt = tmp;
                 }
             }
-            if (first) VJF_MG_STAMP(8);
+            if (first) { VJF_MG_STAMP(8); VJF_MG_STAMPW(4); }
             if (last) {
                 // the workgroup's late slab is complete: loss sums, then the signal the SGD role waits for
                 __syncthreads(); MG_PHASE();
@@ -922,6 +953,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 vjf_wg_signal_wt(cnt + (replay ? MG_C_REDO_B : MG_C_BWD), tid);
                 VJF_MG_STAMP(9);
                 VJF_MG_STAMPX(29, 30);
+                VJF_MG_STAMPW(5);
             }
         }
         VJF_MG_STAMP(18);
@@ -929,7 +961,8 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         if (replay) {
             // the SGD role's step on the replayed late slabs; then this step starts over (inputs, features, parameters)
             ++nredo;
-            if (!vjf_wg_wait(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS))
+            if (!(tl ? vjf_wg_wait_sc1(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS)
+                     : vjf_wg_wait(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS)))
                 vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
             if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
             replay = false; replayed = true; rbits = 0;
@@ -975,6 +1008,7 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
     __syncthreads();
     const int r0 = hg * A.gram_rows, r1 = min(A.B, r0 + A.gram_rows);
     float* myslab = A.gslab + (size_t)hg * ntri * 1024;
+    const __amdgpu_buffer_rsrc_t r_gslab = mg_rsrc(A.gslab);
     const int c = lane & 31, kh = lane >> 5;
     for (int e = 0; e < A.T; ++e) {
         float* red = (e & 1) ? A.red1 : A.red0;
@@ -983,10 +1017,10 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         const float* eps_s = A.eps + (size_t)e * 2 * sz;
         const float* u_e = A.u ? A.u + (size_t)e * su : nullptr;
         // (the posterior of step e - 1: write-through stores of the trial role, in memory before its early slab's signal)
-        if (e > 0 && !vjf_wg_wait(A.cnt + MG_C_FWD, (unsigned)e * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS))
+        if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)e * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         // (the slab of the previous event: every Gram workgroup has summed its share)
-        if (e > 0 && !vjf_wg_wait(A.cnt + MG_C_STAT, (unsigned)e * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS))
+        if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)e * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
         { const int wg = hg, t = e; VJF_MG_STAMP(11); }
@@ -1004,8 +1038,8 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
                 float v = 0.f;
                 if (b < r1) {
                     if (c2 < dz) {
-                        const float m = mu_s ? mu_s[(size_t)b * dz + c2] : S[P.off[VJF_SLOT_PRIOR_MEAN] + c2];
-                        const float l = mu_s ? lv_s[(size_t)b * dz + c2] : S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c2];
+                        const float m = mu_s ? mg_ld(mu_s + (size_t)b * dz + c2) : S[P.off[VJF_SLOT_PRIOR_MEAN] + c2];   // (sc1: no acquire
+                        const float l = mu_s ? mg_ld(lv_s + (size_t)b * dz + c2) : S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c2]; //  behind the waits)
                         v = fmaf(eps_s[(size_t)b * dz + c2], expf(0.5f * l), m);
                     } else {
                         v = u_e[(size_t)b * du + c2 - dz];
@@ -1065,7 +1099,7 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         }
         vjf_wg_signal_wt(A.cnt + MG_C_GRAM, tid);
         { const int wg = hg, t = e; VJF_MG_STAMP(12); }
-        if (!vjf_wg_wait(A.cnt + MG_C_GRAM, (unsigned)(e + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS))
+        if (!vjf_wg_wait_sc1(A.cnt + MG_C_GRAM, (unsigned)(e + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
         // this workgroup's share of the sum over the slabs: a quad of elements per 4 lanes, lane p sums the slabs [p npq, (p+1) npq)
@@ -1075,12 +1109,12 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
             const int part = tid & 3;
             for (int quad = (hg * NT + tid) >> 2; quad < ntri * 256; quad += (A.n_gram * NT) >> 2) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float* src = A.gslab + (size_t)quad * 4;
+                const int src = quad * 4;
                 for (int h0 = part * npq; h0 < min(A.n_gram, (part + 1) * npq); h0 += 16) {
                     float4 tq[16];
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        tq[q] = (h0 + q < min(A.n_gram, (part + 1) * npq)) ? *reinterpret_cast<const float4*>(src + (size_t)(h0 + q) * ntri * 1024)
+                        tq[q] = (h0 + q < min(A.n_gram, (part + 1) * npq)) ? mg_ld4(r_gslab, src + (h0 + q) * ntri * 1024)
                                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
@@ -1125,12 +1159,14 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
     float* SCW = S + P.off[VJF_SLOT_SCALARS];
     const unsigned npost = (unsigned)(A.n_rls - 1);
     const unsigned* runw = A.cnt + MG_C_COLFLAGS + VJF_CHOL_MAXBLK + 2;
+    // (every byte taken from other roles is read with sc1 loads behind the counts' polls and the workgroup barrier: no acquires)
+    const __amdgpu_buffer_rsrc_t r_early = mg_rsrc(A.slab_early);
     for (int t = 0; t < A.T; ++t) {
         float* red = (t & 1) ? A.red1 : A.red0;
-        bool ok = vjf_wg_wait(A.cnt + MG_C_FWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS);
-        ok = vjf_wg_wait(A.cnt + MG_C_STAT, (unsigned)(t + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS) && ok;
-        if (t > 0) ok = vjf_wg_wait(A.cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS) && ok;
-        ok = vjf_wg_wait(runw, (unsigned)(t + 1), tid, SCW + VJF_SC_STATUS) && ok;      // the Cholesky loop holds its operands (it reads the state's P at step 0)
+        bool ok = vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS);
+        ok = vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)(t + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS) && ok;
+        if (t > 0) ok = vjf_wg_wait_sc1(A.cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS) && ok;
+        ok = vjf_wg_wait_sc1(runw, (unsigned)(t + 1), tid, SCW + VJF_SC_STATUS) && ok;      // the Cholesky loop holds its operands (it reads the state's P at step 0)
         if (!ok) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_OPERAND);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
         { const int wg = pw; VJF_MG_STAMP(14); }
@@ -1143,13 +1179,13 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
             const int c = quad >> 2, r4 = (quad & 3) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c < dz && i0 + r4 < ldn) {
-                const float* src = base + (size_t)c * ldn + i0 + r4;
+                const int src = (int)(base - A.slab_early) + c * ldn + i0 + r4;
                 const int w1 = min(A.n_trial, (part + 1) * npq);
                 for (int w0 = part * npq; w0 < w1; w0 += 16) {
                     float4 tq[16];
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        tq[q] = (w0 + q < w1) ? *reinterpret_cast<const float4*>(src + (size_t)(w0 + q) * A.early_len) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        tq[q] = (w0 + q < w1) ? mg_ld4(r_early, src + (w0 + q) * A.early_len) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
                 }
@@ -1170,7 +1206,7 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
             }
             if (pw == 0 && tid < 64) {                                             // sum |dx|^2: one wavefront, strided partial sums, xor tree
                 float q2 = 0.f;
-                for (int w = tid; w < A.n_trial; w += 64) q2 += base[(size_t)w * A.early_len + (size_t)16 * ldn + RS_SDX2];
+                for (int w = tid; w < A.n_trial; w += 64) q2 += mg_ld(base + (size_t)w * A.early_len + (size_t)16 * ldn + RS_SDX2);
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
                 if (tid == 0) mg_st(red + P.red_SC + RS_SDX2, q2);
@@ -1180,6 +1216,7 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
         float* Pm = S + P.off[VJF_SLOT_W_PREC];
         const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
         const float* G = red + P.red_G;
+        const __amdgpu_buffer_rsrc_t r_P = mg_rsrc(Pm), r_G = mg_rsrc(G);
         const int n4 = n >> 2;
         const unsigned m_n4 = mg_magic(n4);
         for (int e0 = tid; e0 < 16 * n4; e0 += 4 * NT) {
@@ -1189,8 +1226,8 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
                 const int e = e0 + q * NT, row = mg_div(e, m_n4), c4 = (e - row * n4) * 4;
                 const bool in = e < 16 * n4 && i0 + row < n;
                 const size_t off = in ? (size_t)(i0 + row) * n + c4 : 0;
-                p[q] = *reinterpret_cast<const float4*>(Pm + off);
-                g[q] = *reinterpret_cast<const float4*>(G + off);
+                p[q] = mg_ld4(r_P, (int)off);                                  // (P: this workgroup's own rows -- and the y / W loop's after a failed factorisation)
+                g[q] = mg_ld4(r_G, (int)off);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1205,7 +1242,7 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
         }
         for (int e = tid; e < n * 16; e += NT) {
             const int k = e >> 4, cc = e & 15;
-            s_w[k * 17 + cc] = cc < dz ? Wm[(size_t)k * dz + cc] : 0.f;
+            s_w[k * 17 + cc] = cc < dz ? mg_ld(Wm + (size_t)k * dz + cc) : 0.f;
         }
         __syncthreads();
         {
@@ -1252,6 +1289,9 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     const int npq = (A.n_trial + 7) >> 3, part = tid & 7;
     const int nquad = A.slab_len >> 2, qstride = (A.n_sgd * NT) >> 3;
     const int w1 = min(A.n_trial, (part + 1) * npq);
+    // Every byte this role takes from the trial role (late slabs, loss sums) is read with sc1 loads behind the count's poll and the
+    // workgroup barrier: no agent-scope acquire (vjf_wg_wait_sc1)
+    const __amdgpu_buffer_rsrc_t r_late = mg_rsrc(A.slab_late);
     // A lane group serves the same quads in every step: the table entries and the parameters of its first round stay in
     // registers for the whole launch (a longer parameter vector reads the later rounds' from memory each step)
     const int q00 = (sw * NT) >> 3;
@@ -1266,10 +1306,10 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
             ci = *reinterpret_cast<const int4*>(A.sl_cidx + (size_t)quad * 4);
             grp = A.sl_grp[quad];
             const float* th = S + P.train_off;
-            if (pi.x >= 0) w[0] = th[pi.x];
-            if (pi.y >= 0) w[1] = th[pi.y];
-            if (pi.z >= 0) w[2] = th[pi.z];
-            if (pi.w >= 0) w[3] = th[pi.w];
+            if (pi.x >= 0) w[0] = mg_ld(th + pi.x);                                // (this lane's own stores of the step before)
+            if (pi.y >= 0) w[1] = mg_ld(th + pi.y);
+            if (pi.z >= 0) w[2] = mg_ld(th + pi.z);
+            if (pi.w >= 0) w[3] = mg_ld(th + pi.w);
         }
     };
     fetch(q00 + (tid >> 3), k_pi, k_ci, k_grp, k_w);
@@ -1281,11 +1321,11 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
       // the parameters alone and publishes which components the trial role is to drop; pass 1 steps on its replayed late slabs
       for (int pass = 0; pass < 2; ++pass) {
         if (pass == 0) {
-            if (!vjf_wg_wait(A.cnt + MG_C_BWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
+            if (!vjf_wg_wait_sc1(A.cnt + MG_C_BWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
                 vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
         } else {
             ++nredo;
-            if (!vjf_wg_wait(A.cnt + MG_C_REDO_B, nredo * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
+            if (!vjf_wg_wait_sc1(A.cnt + MG_C_REDO_B, nredo * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
                 vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
             grad_ok = true;
         }
@@ -1298,16 +1338,16 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
             const bool act = quad < nquad;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 tq[16];
-            const float* src = A.slab_late + (size_t)(act ? quad : 0) * 4;
+            const int src = (act ? quad : 0) * 4;                                  // (float index into the late slabs)
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                tq[q] = (act && part * npq + q < w1) ? *reinterpret_cast<const float4*>(src + (size_t)(part * npq + q) * A.late_len) : make_float4(0.f, 0.f, 0.f, 0.f);
+                tq[q] = (act && part * npq + q < w1) ? mg_ld4(r_late, src + (part * npq + q) * A.late_len) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (!have_sums) {
                 // loss sums of the step: fp64, 32 strided partial sums per scalar, then a fixed xor tree (every SGD workgroup, for the guards)
                 if (tid < 32 * RS_SDX2) {
                     const int sc = tid >> 5, l = tid & 31;
                     double d = 0.0;
-                    for (int w = l; w < A.n_trial; w += 32) d += (double)A.slab_late[(size_t)w * A.late_len + A.slab_len + sc];
+                    for (int w = l; w < A.n_trial; w += 32) d += (double)mg_ld(A.slab_late + (size_t)w * A.late_len + A.slab_len + sc);
                     d = vjf_sum32(d);
                     if (l == 0) s_sc[sc] = (float)d;
                 }
@@ -1322,7 +1362,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
                 for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
-                    tq[q] = (act && wq + q < w1) ? *reinterpret_cast<const float4*>(src + (size_t)(wq + q) * A.late_len) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    tq[q] = (act && wq + q < w1) ? mg_ld4(r_late, src + (wq + q) * A.late_len) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
@@ -1380,14 +1420,14 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
             if (st) vjf_status_or(SC + VJF_SC_STATUS, st);
             if (P.lik == VJF_LIK_GAUSSIAN) {
                 const float sse_y = s_sc[RS_SSEY];
-                float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
+                float rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);
                 if (ok_r) {                                                    // (its gradient comes from the reconstruction term alone)
                     float g = 0.5f * ((float)P.dy - expf(-rho) * sse_y * invB);
                     g = fminf(fmaxf(g, -1.f), 1.f);
                     rho -= SC[VJF_SC_LR_LIK] * g;
                 }
                 const float mse = sse_y / (Bf * (float)P.dy);
-                const float acc = fminf(SC[VJF_SC_N_LIK], 1000.f), tot = acc + Bf;
+                const float acc = fminf(mg_ld(SC + VJF_SC_N_LIK), 1000.f), tot = acc + Bf;
                 rho = logf((acc / tot) * expf(rho) + (Bf / tot) * mse);
                 mg_st(SC + VJF_SC_N_LIK, tot);
                 mg_st(S + P.off[VJF_SLOT_LIK_LOGVAR], rho);

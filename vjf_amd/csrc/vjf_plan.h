@@ -197,6 +197,22 @@ __device__ __forceinline__ void vjf_wg_signal_wt(unsigned* count, int tid) {
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The wait without the acquire: for consumers that read EVERY handed-off byte with sc1 loads (which bypass this CU's vector L1;
+// the producer stored write-through and drained before it signalled) -- MI355X guide, "sc1 loads in place of the acquire".  One
+// lane polls, the workgroup barrier, then the sc1 loads.
+__device__ __forceinline__ bool vjf_wg_wait_sc1(const unsigned* count, unsigned target, int tid, const float* status = nullptr) {
+    bool there = true;
+    if (tid == 0) {
+        there = false;
+        for (unsigned spins = 0; spins < (1u << 21); ++spins) {
+            if ((int)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { there = true; break; }
+            if ((spins & 255u) == 255u && status && ((unsigned)__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x1ff00u)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    return there;
+}
 __device__ __forceinline__ void vjf_store_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // returns false (lane 0 only; the others get true) when the count did not arrive within the bound
 __device__ __forceinline__ bool vjf_wg_wait(const unsigned* count, unsigned target, int tid, const float* status = nullptr) {

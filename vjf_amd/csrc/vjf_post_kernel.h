@@ -91,9 +91,24 @@ __device__ __forceinline__ void post_mma32(vjf_f32x4& acc, const float* Bs, int 
     acc += acc1;
 }
 
-// Wait (one lane polls, relaxed, bounded) until the Cholesky kernel has published flag word `k` for this epoch, then make
-// its bytes visible to the whole workgroup: one agent-scope acquire, its vmcnt drained, the workgroup barrier, and only then
-// the plain loads (cdna guide, Guideline 16).  Returns 0 = there, 1 = the factorisation failed, 2 = timed out.
+// What these workgroups take from workgroups that run beside them (columns of L and the inverted diagonal blocks from the
+// Cholesky loop; g, Phi^T dx, the sums from the operand role; Phi^T Phi from the Gram role; sigma and the sample count, their own
+// stores of the step before) was stored write-through and drained before the flag / count that announces it, and is read with
+// sc1 loads -- 16-byte buffer loads or 4-byte agent-scope loads, which bypass this CU's vector L1 -- behind the poll that matched
+// and the workgroup barrier: no agent-scope acquire (an L1 invalidate the whole workgroup would wait ~1.7 us for) per column
+// (MI355X guide, "sc1 loads in place of the acquire").  The rare failure path, which reads more, does acquire.
+typedef unsigned post_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t post_rsrc(const float* base, size_t nfloats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(nfloats * 4), 0x00020000);
+}
+__device__ __forceinline__ float4 post_ld4(__amdgpu_buffer_rsrc_t r, size_t float_off) {
+    const post_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, 16);      // aux 16 = sc1
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+__device__ __forceinline__ float post_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Wait (one lane polls, relaxed, bounded) until the Cholesky kernel has published flag word `k` for this epoch; the workgroup
+// barrier; then the sc1 loads of the column (see above).  Returns 0 = there, 1 = the factorisation failed, 2 = timed out.
 __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned epoch, int k, int* s_ctl, int tid, const float* status) {
     if (tid == 0) {
         int st = 2;
@@ -103,8 +118,6 @@ __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned 
             if ((spins & 255u) == 255u && vjf_abort_seen(status)) break;
             __builtin_amdgcn_s_sleep(4);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         s_ctl[0] = st;
     }
     __syncthreads();
@@ -113,8 +126,8 @@ __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned 
     return st;
 }
 
-// The y / W workgroup, whose LDS holds all of L, takes in every column that has been published so far in one go -- one acquire,
-// the columns' loads in flight together: a look at the flags from..kmax without waiting (and at the operand role's count for g),
+// The y / W workgroup, whose LDS holds all of L, takes in every column that has been published so far in one go: a look at the
+// flags from..kmax without waiting (and at the operand role's count for g),
 // s_ctl[0] = 1 if a column reports a failed pivot, s_ctl[1] = the last column found published (from - 1: none new), s_ctl[2] =
 // g is there.  With wait_first the first flag is waited for as post_wait_column does (returns its codes in s_ctl[0]).
 __device__ __forceinline__ void post_peek_columns(const unsigned* flags, unsigned epoch, int from, int kmax, bool wait_first,
@@ -139,12 +152,7 @@ __device__ __forceinline__ void post_peek_columns(const unsigned* flags, unsigne
                 kr = j;
             }
         const int g = prep_count ? ((int)(__hip_atomic_load(prep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - prep_target) >= 0 ? 1 : 0) : 1;
-        if (kr >= from || g) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            __builtin_amdgcn_s_sleep(8);
-        }
+        if (kr < from && !g) __builtin_amdgcn_s_sleep(8);
         s_ctl[0] = st; s_ctl[1] = kr; s_ctl[2] = g;
     }
     __syncthreads();
@@ -169,10 +177,15 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
     auto leave = [&]() {                                       // every workgroup, on every path, exactly once
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (A.stamps && !solve && tid == 0) {                  // diagnostic: when the LAST inverse loop of the step is done
+            unsigned long long t_;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+            atomicMax(A.stamps + ((it_epoch & 7u) << 5) * (A.nsteps > 0 ? 1 : 0) + 22, t_);
+        }
         if (tid == 0 && A.done) __hip_atomic_fetch_add(A.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     const float* S = A.state;
-    const float* Lm = A.lscr;
+    const __amdgpu_buffer_rsrc_t r_L = post_rsrc(A.lscr, (size_t)n * n), r_dinv = post_rsrc(A.dinv, (size_t)nbl * 1024);
     const int j0 = solve ? 0 : bix >> 1;                       // first block row of the substitution
     const int c0 = solve ? 0 : 16 * (bix & 1);
     auto tri = [](int bi, int bj) { return bi * (bi - 1) / 2 + bj; };       // strictly lower: bi > bj
@@ -198,19 +211,12 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
     __syncthreads();
 
     float gpre[4][16], fpre[8];
-    auto prefetch_tail = [&]() {
-        // scalars of the state-noise update, fetched now so that the tail does not wait for them
-        pre_sdx2 = it_red[P.red_SC + RS_SDX2];
-        const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
-        const float Bf = (float)A.B_total;
-        const float acc = fminf(S[P.off[VJF_SLOT_SCALARS] + VJF_SC_N_TR], 500.f);   // running_var, size_cap=500 (model.py:375)
-        pre_tot = acc + Bf;
-        pre_old = (acc / pre_tot) * expf(sig);
-        pre_scale = 1.0 / ((double)Bf * (double)P.dz);
-        // wavefront w: the lower 32x32 tiles w, w + 8, .. of G in the matrix-core accumulator layout, and FDX
-        // (plain loads from clamped addresses: the tail masks what lies outside the matrix)
+    // the tail's operands, fetched early so that it does not wait for them: the tiles of G once the Cholesky loop has started on
+    // this step (its first column flag: the Gram role's sums were complete before it began) ...
+    auto prefetch_G = [&]() {
+        // wavefront w: the lower 32x32 tiles w, w + 8, .. of G in the matrix-core accumulator layout
+        // (loads from clamped addresses: the tail masks what lies outside the matrix)
         const float* G = it_red + P.red_G;
-        const float* FDX = it_red + P.red_FDX;
         const int c = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -219,15 +225,27 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gi = min(bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n - 1), gj = min(bj * 32 + c, n - 1);
-                gpre[q][r] = G[(size_t)gi * n + gj];
+                gpre[q][r] = post_ld(G + (size_t)gi * n + gj);
             }
         }
+    };
+    // ... and, with g, what the operand role leaves beside it (sum |dx|^2, Phi^T dx) and the scalars of the state-noise update
+    auto prefetch_rest = [&]() {
+        pre_sdx2 = post_ld(it_red + P.red_SC + RS_SDX2);
+        const float sig = post_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
+        const float Bf = (float)A.B_total;
+        const float acc = fminf(post_ld(S + P.off[VJF_SLOT_SCALARS] + VJF_SC_N_TR), 500.f);   // running_var, size_cap=500 (model.py:375)
+        pre_tot = acc + Bf;
+        pre_old = (acc / pre_tot) * expf(sig);
+        pre_scale = 1.0 / ((double)Bf * (double)P.dz);
+        const float* FDX = it_red + P.red_FDX;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {                                  // W's [row][16] grid: 224 * 16 <= 8 * 512
             const int e = tid + q * VJF_POST_THREADS, r = min(e >> 4, n - 1), cc = min(e & 15, dz - 1);
-            fpre[q] = FDX[r * dz + cc];
+            fpre[q] = post_ld(FDX + r * dz + cc);
         }
     };
+    auto prefetch_tail = [&]() { prefetch_G(); prefetch_rest(); };
 
     // Both substitutions run eagerly: as soon as block k of the solution exists (two wavefronts, one 16-row tile each),
     // every wavefront subtracts its contribution from the 16-row tiles of the later blocks it owns, in place in s_x.
@@ -250,8 +268,7 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
             const int it = 2 * q + bh;                                     // 0: Dinv_k; i = k + it: L block (i, k)
             const int gi = (k + it) * 32 + r, gj = k * 32 + c4;
             const bool real = it < nb && (it == 0 || (gi < n && gj < n));  // (padding rows / columns of L are zero)
-            const float* src = it == 0 ? A.dinv + (size_t)k * 1024 + r * 32 + c4 : Lm + (size_t)gi * n + gj;
-            v[q] = *reinterpret_cast<const float4*>(real ? src : A.dinv);
+            v[q] = it == 0 ? post_ld4(r_dinv, real ? (size_t)k * 1024 + r * 32 + c4 : 0) : post_ld4(r_L, real ? (size_t)gi * n + gj : 0);
             if (!real) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -279,9 +296,11 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
                 for (int k2 = k; k2 <= kr; ++k2) stage_column(k2);
                 staged = kr + 1;
             }
+            bool g_pre = false;
             if (k == 0) {
                 // g (and with it the RLS statistics) comes from the operand role, usually after the first columns of L: they are
                 // taken in as they appear while this workgroup waits for it
+                if (!g_there && A.fold_sigma) { prefetch_G(); g_pre = true; }
                 if (!g_there) {
                     for (unsigned spins = 0;; ++spins) {
                         post_peek_columns(A.flags, it_epoch, staged, nbl - 1, false, A.prep_count, it_prep_target, s_ctl, tid, A.status);
@@ -303,9 +322,9 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
                 // statistics) is read behind the first column flag of this epoch: the flag says those kernels are complete.
                 for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
                     const int r = e >> 4, c = e & 15;
-                    s_x[r * LX + c] = (r < n && c < dz) ? A.gbuf[(size_t)r * dz + c] : 0.f;
+                    s_x[r * LX + c] = (r < n && c < dz) ? post_ld(A.gbuf + (size_t)r * dz + c) : 0.f;
                 }
-                if (A.fold_sigma) prefetch_tail();
+                if (A.fold_sigma) { if (!g_pre) prefetch_G(); prefetch_rest(); }
             }
         }
         __syncthreads();
@@ -334,7 +353,8 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
         }
         __syncthreads();
     }
-    if (!bad) bad = post_wait_column(A.flags, it_epoch, VJF_CHOL_MAXBLK, s_ctl, tid, A.status);   // the factor as a whole
+    // (every column up to the last one reported good pivots: the factor as a whole is good -- its own flag, which the Cholesky
+    //  loop raises right behind the last column's, need not be waited for)
     if (A.k1_done) {                                           // readers of W, w_chol, sigma on another stream: all done?
         if (tid == 0) {
             int st = 2;
@@ -364,7 +384,7 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
                 const int q0 = bix * per, q1 = min(nq, q0 + per);
                 for (int q = q0 + tid; q < q1; q += VJF_POST_THREADS) {
                     const int e = 4 * q, i = e / n, j = e - i * n;
-                    if ((j >> 5) <= (i >> 5)) *reinterpret_cast<float4*>(Ls + e) = *reinterpret_cast<const float4*>(A.lscr + e);
+                    if ((j >> 5) <= (i >> 5)) *reinterpret_cast<float4*>(Ls + e) = post_ld4(r_L, (size_t)e);
                 }
             }
             // ---- w_chol[(j0*32 + c0 + c)][i] = X[i][c]: rows of w_chol, contiguous over i  (module.py:102)
@@ -420,6 +440,8 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
         double* s_p = reinterpret_cast<double*>(lds);          // one partial per wavefront (over s_L: the substitutions are done)
         if (failed) {                                          // sigma still moves, on the W that stays
             wait_g();
+            if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            __syncthreads();                                   // (this path reads the state with plain loads)
             const float* Wold = A.state + P.off[VJF_SLOT_W_MEAN];
             for (int e = tid; e < nbl * 32 * 16; e += VJF_POST_THREADS) {
                 const int r = e >> 4, c = e & 15;
