@@ -60,5 +60,6 @@ if rows:
     t00 = min(w[0] for _, w in rows)
     print("last step, per trial workgroup (us after the first one had theta): wg xcc rls-at-gate | theta staged, early slab out, RLS there, var+mean done, grads done, late slab out")
     for wgi, w in rows:
-        print(f"  {wgi:3d} {w[6]:2d} {w[7]} | " + " ".join(f"{(x - t00) / 100.0:7.2f}" for x in w[:6]))
+        hw = w[6] >> 8                                  # HW_ID: cu_id [11:8], sh_id [12], se_id [15:13] (gfx9 layout)
+        print(f"  {wgi:3d} {w[6] & 15:2d} {w[7]} | " + " ".join(f"{(x - t00) / 100.0:7.2f}" for x in w[:6]) + f" | se {(hw >> 13) & 7} sh {(hw >> 12) & 1} cu {(hw >> 8) & 15}")
 print("status", m.status())

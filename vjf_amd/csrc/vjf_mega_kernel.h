@@ -580,8 +580,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (first) { VJF_MG_STAMP(1); VJF_MG_STAMPX(27, -1); VJF_MG_STAMPW(0); }
             if (first && A.stamps && tid == 0 && t == A.T - 1 && !replay) {
                 unsigned xcc;
+                unsigned hwid;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                A.stamps[1024 + (size_t)wg * 8 + 6] = xcc & 15u;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                A.stamps[1024 + (size_t)wg * 8 + 6] = (xcc & 15u) | ((unsigned long long)hwid << 8);
                 A.stamps[1024 + (size_t)wg * 8 + 7] = rls_in ? 1u : 0u;
             }
             // ---- stage 3: recognition forward (recognition.py:31-42)
