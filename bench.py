@@ -295,6 +295,8 @@ def main():
         ach_gbs = (b_trial * c["B"] + b_shared) / step_s / 1e9
         traffic = traffic_note = None
         try:                                                    # HBM-side bytes per step from the committed PMC passes of this build
+            if a.config != "B" or world != 1 or a.no_overlap or a.streams_route or a.force_dist:
+                raise LookupError("the committed PMC passes are of the headline configuration on the one-launch route")
             tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
             traffic, traffic_note = float(tj["bytes_per_step_corrected"]), tj.get("note")
         except Exception:

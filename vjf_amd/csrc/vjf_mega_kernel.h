@@ -170,6 +170,7 @@ __device__ __forceinline__ float4 mg_ld4(__amdgpu_buffer_rsrc_t r, int float_ind
 // two batches in flight: while one batch's 32 MFMAs issue the next one's loads are on their way (and the SIMD's other wavefront
 // fills what latency is left).  The loads are sc1 (they bypass this CU's vector L1): these matrices are rewritten every step by
 // other roles, and the waits in front of them do not acquire.
+template <bool DEEP = false>
 __device__ __forceinline__ void mg_mma2(vjf_f32x4& acc0, vjf_f32x4& acc1, const float* __restrict__ Ag, int lda, int M, int m0,
                                         const float* Xs, int kb, int ke, int lane) {
     constexpr int LD = VJF_MG_LD;
@@ -197,6 +198,20 @@ __device__ __forceinline__ void mg_mma2(vjf_f32x4& acc0, vjf_f32x4& acc1, const 
         }
     };
     if (nst <= 0) return;
+    if (DEEP) {
+        // up to 64 k-steps (K <= 256): every load of the tile is issued before the first MFMA
+        float a0[16], a1[16], a2[16], a3[16];
+        ld16(a0, 0);
+        if (nst > 16) ld16(a1, 16);
+        if (nst > 32) ld16(a2, 32);
+        if (nst > 48) ld16(a3, 48);
+        mm16(a0, 0);
+        if (nst > 16) mm16(a1, 16);
+        if (nst > 32) mm16(a2, 32);
+        if (nst > 48) mm16(a3, 48);
+        for (int s0 = 64; s0 < nst; s0 += 16) { ld16(a0, s0); mm16(a0, s0); }
+        return;
+    }
     float a0[16], a1[16];
     ld16(a0, 0);
     if (nst > 16) ld16(a1, 16);
@@ -739,7 +754,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     const int tt = ntile - 1 - idx, j0 = tt * 16;
                     const int K = tri ? min(n, j0 + 16) : n;
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2(acc0, acc1, Wc, n, n, j0, s_phi, 0, K, lane);
+                    mg_mma2<true>(acc0, acc1, Wc, n, n, j0, s_phi, 0, K, lane);
                     v2a = fmaf(acc0[0], acc0[0], fmaf(acc0[1], acc0[1], fmaf(acc0[2], acc0[2], fmaf(acc0[3], acc0[3], v2a))));
                     v2b = fmaf(acc1[0], acc1[0], fmaf(acc1[1], acc1[1], fmaf(acc1[2], acc1[2], fmaf(acc1[3], acc1[3], v2b))));
                 }
