@@ -885,6 +885,16 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     };
     rc = check_step_args(c, B, y, u, mu0, lv0, eps, eps + sz, mu, lv);
     if (rc) return rc;
+    if (c->comm_a) {
+        // The ranks enter the sequence together: kernels of this route wait in-kernel (bounded, ~0.3 s) for kernels that sit behind
+        // an all-reduce, and an all-reduce waits for the slowest rank -- one that is late with this CALL by more than the bound
+        // (data loading, a first call) must not run its peers' waits out.  One tiny all-reduce and a host synchronisation per
+        // call; inside the sequence the per-step collectives keep the ranks in step.
+        float* tok = (float*)(c->ws + c->cv.flags) + 60;                    // (a word of the flag block no hand-off uses)
+        VJF_HIP(hipMemsetAsync(tok, 0, 4, sa));
+        VJF_NCCL(nccl().all_reduce(tok, tok, 1, kNcclFloat, kNcclSum, c->comm_a, sa));
+        VJF_HIP(hipStreamSynchronize(sa));
+    }
     rc = refresh_aux(c);
     if (rc) return rc;
     const int ne = c->n_ejobs, ng = c->njobs - ne;
