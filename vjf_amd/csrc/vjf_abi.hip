@@ -565,6 +565,13 @@ int refresh_aux(vjf_ctx* c) {
     return 0;
 }
 
+// the context's device for the duration of an entry point; the caller's current device is put back on the way out
+struct DeviceGuard {
+    int prev = -1, dev;
+    explicit DeviceGuard(int d) : dev(d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+
 constexpr unsigned kScAll = (1u << RS_N) - 1u;
 constexpr unsigned kScRls = 1u << RS_SDX2;                 // the one loss sum the RLS chain reads
 
@@ -942,12 +949,14 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
 int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
                      const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_local: null context");
+    DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
     VJF_HIP(hipSetDevice(c->cfg.device));
     return launch_local(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags, false);
 }
 
 int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_global: null context");
+    DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
     if (B_total < 1) return fail(-20, "vjf_filter_global: B_total=%d", B_total);
     if (c->fast_chol) {
         const float* red = (const float*)(c->ws + c->cv.red);
@@ -1042,6 +1051,7 @@ int seq_chunk() {
 int vjf_filter_step(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
                     const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, float* loss4, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_step: null context");
+    DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
     if (mega_route(c, flags) && eps_s && eps_t && eps_t == eps_s + (size_t)B * c->plan.dz)          // (the sequence layout of eps: (2, B, dz))
         return filter_seq_mega(c, 1, B, y, u, eps_s, mu_s, lv_s, mu_t, lv_t, loss4, flags);
     if (mega_route(c, flags)) {
@@ -1070,6 +1080,7 @@ int vjf_route(vjf_ctx* c, uint32_t flags) {
 int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
                    const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_seq: null context");
+    DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
     if (T < 1) return fail(-23, "vjf_filter_seq: T=%d", T);
     if (!y || !eps || !mu || !lv) return fail(-1, "vjf_filter_seq: null tensor");
     const size_t sy = (size_t)B * c->plan.dy, su = (size_t)B * c->plan.du, sz = (size_t)B * c->plan.dz;

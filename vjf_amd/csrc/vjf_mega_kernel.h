@@ -1049,6 +1049,7 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         for (int c0 = r0; c0 < r1; c0 += VJF_MG_GROWS) {
             __syncthreads();
             const int l4 = ldE >> 2;
+            const int ks = min(VJF_MG_GROWS / 2, (((min(VJF_MG_GROWS, r1 - c0) + 1) >> 1) + 1) & ~1);   // (a multiple of 2; rows beyond the range are zero)
             // xs = mu + eps e^{lv/2} (model.py:97-99; the prior at the first step of a run: model.py:188-190) and the inputs u
             for (int i = tid; i < VJF_MG_GROWS * dxu; i += NT) {
                 const int r = mg_div(i, m_dxu), c2 = i - r * dxu, b = c0 + r;
@@ -1071,13 +1072,21 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (c0 + r < r1 && k < npad) {
                     float d2[4] = {0.f, 0.f, 0.f, 0.f};
-                    for (int c2 = 0; c2 < dxu; ++c2) {
-                        const float x = s_x[r * dxu + c2];
-                        const float4 cc = *reinterpret_cast<const float4*>(s_cen + c2 * npad + k);
+                    auto dim = [&](float x, const float4& cc) {                     // (one input dimension: the trial role's order of operations)
                         float d;
                         d = x - cc.x; d2[0] = fmaf(d, d, d2[0]); d = x - cc.y; d2[1] = fmaf(d, d, d2[1]);
                         d = x - cc.z; d2[2] = fmaf(d, d, d2[2]); d = x - cc.w; d2[3] = fmaf(d, d, d2[3]);
+                    };
+                    int c2 = 0;
+                    for (; c2 + 3 < dxu; c2 += 4) {                                  // four dimensions' LDS loads in flight together
+                        const float x0 = s_x[r * dxu + c2], x1 = s_x[r * dxu + c2 + 1], x2 = s_x[r * dxu + c2 + 2], x3 = s_x[r * dxu + c2 + 3];
+                        const float4 c0v = *reinterpret_cast<const float4*>(s_cen + c2 * npad + k);
+                        const float4 c1v = *reinterpret_cast<const float4*>(s_cen + (c2 + 1) * npad + k);
+                        const float4 c2v = *reinterpret_cast<const float4*>(s_cen + (c2 + 2) * npad + k);
+                        const float4 c3v = *reinterpret_cast<const float4*>(s_cen + (c2 + 3) * npad + k);
+                        dim(x0, c0v); dim(x1, c1v); dim(x2, c2v); dim(x3, c3v);
                     }
+                    for (; c2 < dxu; ++c2) dim(s_x[r * dxu + c2], *reinterpret_cast<const float4*>(s_cen + c2 * npad + k));
                     const float4 iw = *reinterpret_cast<const float4*>(s_iw + k);
                     o.x = expf(d2[0] * iw.x); o.y = k + 1 < n ? expf(d2[1] * iw.y) : 0.f;
                     o.z = k + 2 < n ? expf(d2[2] * iw.z) : 0.f; o.w = k + 3 < n ? expf(d2[3] * iw.w) : 0.f;
@@ -1092,13 +1101,21 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
                     const int code = s_tab[tt], bi = code >> 8, bj = code & 255;
                     const float* pa = s_rows + (size_t)kh * ldE + bi * 32 + c;
                     const float* pb = s_rows + (size_t)kh * ldE + bj * 32 + c;
-#pragma unroll 4
-                    for (int s = 0; s < VJF_MG_GROWS / 2; s += 8) {
+                    int s = 0;
+#pragma unroll 2
+                    for (; s + 8 <= ks; s += 8) {                                  // ks = k-steps (row pairs) of this pass that hold rows
                         float a[8], b[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) { a[u] = pa[(size_t)(2 * (s + u)) * ldE]; b[u] = pb[(size_t)(2 * (s + u)) * ldE]; }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc[q], 0, 0, 0);
+                    }
+                    for (; s < ks; s += 2) {
+                        float a[2], b[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) { a[u] = pa[(size_t)(2 * (s + u)) * ldE]; b[u] = pb[(size_t)(2 * (s + u)) * ldE]; }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc[q], 0, 0, 0);
                     }
                 }
             }
@@ -1120,41 +1137,58 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
         // this workgroup's share of the sum over the slabs: a quad of elements per 4 lanes, lane p sums the slabs [p npq, (p+1) npq)
-        // (all of them in flight), then (s0 + s1) + (s2 + s3): a fixed order
+        // (all of them in flight -- for TWO quads at a time: one round trip for the whole share at config B), then
+        // (s0 + s1) + (s2 + s3): a fixed order
         {
             const int npq = (A.n_gram + 3) >> 2;
             const int part = tid & 3;
-            for (int quad = (hg * NT + tid) >> 2; quad < ntri * 256; quad += (A.n_gram * NT) >> 2) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int src = quad * 4;
-                for (int h0 = part * npq; h0 < min(A.n_gram, (part + 1) * npq); h0 += 16) {
-                    float4 tq[16];
+            const int qstride = (A.n_gram * NT) >> 2, nq = ntri * 256;
+            const int h1 = min(A.n_gram, (part + 1) * npq);
+            auto load16 = [&](float4 (&tq)[16], int quad, int h0) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        tq[q] = (h0 + q < min(A.n_gram, (part + 1) * npq)) ? mg_ld4(r_gslab, src + (h0 + q) * ntri * 1024)
-                                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < 16; ++q)
+                    tq[q] = (quad < nq && h0 + q < h1) ? mg_ld4(r_gslab, quad * 4 + (h0 + q) * ntri * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
+            auto add16 = [&](float4& v, const float4 (&tq)[16]) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
-                }
+                for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
+            };
+            auto finish = [&](int quad, float4 v) {
                 float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     vv[r] += __shfl_xor(vv[r], 1, 64);
                     vv[r] += __shfl_xor(vv[r], 2, 64);
                 }
-                if (part == 0) {
+                if (part == 0 && quad < nq) {
                     const int idx = quad * 4, tt = idx >> 10, el = idx & 1023, code = s_tab[tt];
                     const int j = el >> 8, ln = (el >> 2) & 63;
                     const int gc = (code & 255) * 32 + (ln & 31);
+                    const int gr0 = (code >> 8) * 32 + 8 * j + 4 * (ln >> 5);            // the quad: rows gr0 .. gr0 + 3 of column gc
+                    if ((code >> 8) != (code & 255) && gr0 + 3 < n && gc < n) {
+                        // off the diagonal blocks: the transposed entries are four consecutive floats of row gc
+                        mg_st4(red + P.red_G + (size_t)gc * n + gr0, vv[0], vv[1], vv[2], vv[3]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int gr = (code >> 8) * 32 + r + 8 * j + 4 * (ln >> 5);
-                        if (gr < n && gc <= gr) {
-                            mg_st(red + P.red_G + (size_t)gr * n + gc, vv[r]);
-                            mg_st(red + P.red_G + (size_t)gc * n + gr, vv[r]);
+                        for (int r = 0; r < 4; ++r) mg_st(red + P.red_G + (size_t)(gr0 + r) * n + gc, vv[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int gr = gr0 + r;
+                            if (gr < n && gc <= gr) {
+                                mg_st(red + P.red_G + (size_t)gr * n + gc, vv[r]);
+                                mg_st(red + P.red_G + (size_t)gc * n + gr, vv[r]);
+                            }
                         }
                     }
                 }
+            };
+            for (int quad = (hg * NT + tid) >> 2; quad < nq + qstride; quad += 2 * qstride) {   // (uniform trip count over the wavefront: shuffles inside)
+                const int quadB = quad + qstride;
+                float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+                float4 ta[16], tb[16];                                               // (at most 64 Gram workgroups: npq <= 16, one batch per lane)
+                load16(ta, quad, part * npq); load16(tb, quadB, part * npq);
+                add16(va, ta); add16(vb, tb);
+                finish(quad, va); finish(quadB, vb);
             }
         }
         vjf_wg_signal_wt(A.cnt + MG_C_STAT, tid);
