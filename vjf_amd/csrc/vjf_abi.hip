@@ -199,7 +199,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
 }
 
 struct Carve {
-    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_imgidx, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -233,7 +233,6 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
         c.mg_cnt = take((size_t)MG_C_WORDS * 4);
         c.mg_stamps = take((32 * 32 + kMegaMaxTrialWg * 8) * 8);   // ring of role stamps | 8 words per trial workgroup (last step)
         c.mg_pidx = take(slab_len * 4); c.mg_cidx = take(slab_len * 4); c.mg_grp = take(slab_len);
-        c.mg_imgidx = take((size_t)P.train_len * 4);
         c.mg_img = take((size_t)vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).th_len * 4 + 64);   // the parameters in the trial role's LDS layout
         c.mg_pmsave = take((size_t)max_batch * (P.dz + 1) * 4);
     }
@@ -430,7 +429,6 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
         block(1, VJF_SLOT_MEAN_W, -1, P.dz, hL);
         block(2, VJF_SLOT_LV_W, VJF_SLOT_LV_B, P.dz, hL);
         for (int l = P.L - 1; l >= 0; --l) block(3 + (P.L - 1 - l), VJF_SLOT_REC_W0 + 2 * l, VJF_SLOT_REC_B0 + 2 * l, P.h[l], l > 0 ? P.h[l - 1] : P.din);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_imgidx, img_of.data(), img_of.size() * 4, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_pidx, pidx.data(), pidx.size() * 4, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_cidx, cidx.data(), cidx.size() * 4, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_grp, grpv.data(), grpv.size() * 4, hipMemcpyHostToDevice, c->stream);
@@ -801,11 +799,9 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     MegaShape m{};
     if (!mega_shape(P, B, c->ncu, &m)) return fail(-26, "vjf_filter_seq: %d compute units are too few for the one-launch route", c->ncu);
     VJF_HIP(hipSetDevice(c->cfg.device));
-    rc = refresh_aux(c);
-    if (rc) return rc;
-    hipLaunchKernelGGL(vjf_img_kernel, dim3(16), dim3(256), 0, c->stream, (const float*)(c->state + P.train_off), (const int*)(c->ws + c->cv.mg_imgidx),
-                       (float*)(c->ws + c->cv.mg_img), P.train_len);
-    VJF_HIP(hipGetLastError());
+    // (parameters that fit the trial role's LDS: it reads the image the SGD role builds at the start of the launch; else the state
+    //  and its transposed copies, refreshed here)
+    if (!vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).theta) { rc = refresh_aux(c); if (rc) return rc; }
     unsigned* cnt = (unsigned*)(c->ws + c->cv.mg_cnt);
     VJF_HIP(hipMemsetAsync(cnt, 0, (size_t)MG_C_WORDS * 4, c->stream));                 // every counter and flag of the launch starts at 0
     const int nbl = (P.n + 31) / 32;

@@ -49,6 +49,7 @@ enum {
     MG_C_STARTED = 144,
     MG_C_REDO_B = 0,     // trial workgroups whose REPLAYED late slab is in memory             target (replays so far) n_trial
     MG_C_REDO_S = 176,   // SGD workgroups done with a replayed step                         target (replays so far) n_sgd
+    MG_C_IMG = 208,      // SGD workgroups whose share of the parameter image is in memory (start of the launch)  target n_sgd
     MG_C_MASK = 192,     // (step + 1) << 8 | non-finite loss components (1 recon, 2 dynamics, 4 entropy) of the last step that had one
     MG_C_COLFLAGS = 160, // [0 .. VJF_CHOL_MAXBLK]: column flags of the Cholesky loop; [VJF_CHOL_MAXBLK + 2]: its "operands loaded" word
     MG_C_WORDS = 256
@@ -575,6 +576,11 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
                 tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
                 rls_in = true;
+            }
+            if (first && tl && !replay && t == 0) {                            // (the image of this launch: the SGD role's first act)
+                if (!vjf_wg_wait_sc1(cnt + MG_C_IMG, (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS))
+                    vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
+                if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
             }
             if (first && tl && !replay) {                                      // (a replayed pass: they are in LDS, untouched since its step)
                 // the parameters of this step into LDS: the image the SGD role keeps has the layout of the region, so this is a flat
@@ -1364,6 +1370,24 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
         }
     };
     fetch(q00 + (tid >> 3), k_pi, k_ci, k_grp, k_w);
+    if (tl) {
+        // the parameter image of this launch (the caller may have rewritten the state blob since the last one): every lane group
+        // stores the parameters of its quads; the trial role waits for all of them before its first step
+        auto put = [&](const int4& pi, const int4& ci, const float (&w)[4]) {
+            float* img = const_cast<float*>(A.img);
+            if (pi.x >= 0 && ci.x >= 0) mg_st(img + ci.x, w[0]);
+            if (pi.y >= 0 && ci.y >= 0) mg_st(img + ci.y, w[1]);
+            if (pi.z >= 0 && ci.z >= 0) mg_st(img + ci.z, w[2]);
+            if (pi.w >= 0 && ci.w >= 0) mg_st(img + ci.w, w[3]);
+        };
+        put(k_pi, k_ci, k_w);
+        for (int q0 = q00 + qstride; q0 < nquad; q0 += qstride) {
+            int4 pi, ci; int grp; float w[4];
+            fetch(q0 + (tid >> 3), pi, ci, grp, w);
+            put(pi, ci, w);
+        }
+        vjf_wg_signal_wt(A.cnt + MG_C_IMG, tid);
+    }
     unsigned nredo = 0;
     for (int t = 0; t < A.T; ++t) {
       float l_recon = 0.f, l_dyn = 0.f, ent = 0.f;
@@ -1427,6 +1451,9 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
             if (!act || part != 0 || !grad_ok || (grp == 1 && freeze)) return;     // (frozen decoder)
             const int pidx[4] = {pi.x, pi.y, pi.z, pi.w}, cidx[4] = {ci.x, ci.y, ci.z, ci.w};
             float* cdst = tl ? const_cast<float*>(A.img) : A.aux;
+            // the state blob itself: nobody reads these parameters from it during the launch when the trial role has the image and
+            // this lane group keeps them in registers -- then it is brought up to date at the last step only
+            const bool wst = !tl || q0 != q00 || t == A.T - 1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (pidx[r] < 0) continue;                                     // (padding of the slab's rows)
@@ -1434,7 +1461,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
                 g = fminf(fmaxf(g, -1.f), 1.f);                                // clip_grad_value_ (model.py:210)
                 const float wn = wold[r] - (grp == 1 ? lr_dec : lr_rec) * g;
                 wold[r] = wn;
-                mg_st(S + P.train_off + pidx[r], wn);
+                if (wst) mg_st(S + P.train_off + pidx[r], wn);
                 if (cidx[r] >= 0) mg_st(cdst + cidx[r], wn);
             }
         };

@@ -77,11 +77,3 @@ __global__ void vjf_loss_kernel(int mode, const float* m1, const float* lv1, con
 __global__ void vjf_scale_kernel(float* p, float f, int n) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) p[e] *= f;
 }
-
-// the one-launch route's image of the optimised parameters: img[idx[e]] = theta[e] (idx < 0: alignment padding)
-__global__ void vjf_img_kernel(const float* __restrict__ theta, const int* __restrict__ idx, float* __restrict__ img, int n) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        const int i = idx[e];
-        if (i >= 0) img[i] = theta[e];
-    }
-}
