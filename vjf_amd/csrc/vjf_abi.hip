@@ -835,12 +835,14 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     C.wait_count = cnt + MG_C_PDONE; C.wait_target = 0; C.wait_stride = npost;
     C.stat_count = cnt + MG_C_STAT; C.stat_target = (unsigned)m.n_gram; C.stat_stride = (unsigned)m.n_gram;
     C.nsteps = T; C.step0 = 0;
+    C.sig_word = (const unsigned long long*)(cnt + MG_C_SIGW);
     { const char* ie = getenv("VJF_DEBUG_INJECT"); C.inject_epoch = ie ? (unsigned)atoi(ie) : 0u; }   // (test hook: a hand-off of step k - 1 reports a time-out)
     VjfPostArgs Q{};
     Q.state = c->state; Q.dinv = dinv; Q.gbuf = A.gbuf; Q.lscr = C.lscr; Q.flags = cnt + MG_C_COLFLAGS; Q.epoch = 1; Q.status = stw;
     Q.k1_done = cnt + MG_C_K1; Q.k1_target = (unsigned)m.n_trial; Q.k1_stride = (unsigned)m.n_trial;
     Q.done = cnt + MG_C_PDONE; Q.started = cnt + MG_C_STARTED;
     Q.red = rede[0]; Q.red2 = rede[1]; Q.B_total = B; Q.fold_sigma = 1; Q.stamps = C.stamps; Q.undo_P = 1;
+    Q.sig_word = (unsigned long long*)(cnt + MG_C_SIGW);
     Q.prep_count = cnt + MG_C_PREP; Q.prep_target = (unsigned)m.n_prep; Q.prep_stride = (unsigned)m.n_prep;
     Q.nsteps = T; Q.step0 = 0; Q.role = 2;
     VjfPlan Pk = P;

@@ -517,6 +517,9 @@ struct VjfCholArgs {
     unsigned inject_epoch; // test hook (VJF_DEBUG_INJECT=k): at this epoch the statistics wait is reported as timed out
     const float* red2;
     const unsigned* stat_count; unsigned stat_target, stat_stride, wait_stride;
+    const unsigned long long* sig_word;   // non-null (self_prep): sigma of the previous step arrives as ONE 8-byte word {epoch, bits} from the
+                                          //   y / W loop; *wait_count is then only awaited before the first column goes out (the scratch
+                                          //   copies of L and the inverted diagonal blocks must have been read by everybody)
     int no_triclean;       // post mode: the caller clears the zero halves of w_chol / w_pchol itself (vjf_triclean_kernel)
                            //            (vjf_rls_post_kernel copies it to w_pchol once the factor is known to be good)
 };
@@ -622,10 +625,31 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         // self_prep: every thread first issues its loads of P_old (pscr) and of G, then the workgroup waits for sigma of the
         // previous step, and P_new = P_old + G / v is formed in the registers (fmaf, as vjf_prepg_kernel forms the state's P).
         // Either way the blocks of P_new go to pscr for the next step's kernel.
+        bool lscr_guard = false;                                        // the post workgroups' exit count is still to be checked
         auto sigma_wait = [&]() {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // operands in registers: the state's P may now be overwritten
             __syncthreads();
             if (tid == 0) __hip_atomic_store(A.flags_out + VJF_CHOL_MAXBLK + 2, it_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (A.sig_word && it_wait_target != 0u) {
+                // sigma inside the hand-off word: one poll, no second load; the exit count of the post workgroups is checked by the
+                // wavefront that writes the first column out (below)
+                if (tid == 0) {
+                    bool there = false;
+                    unsigned bits = 0u;
+                    for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
+                        const unsigned long long v = __hip_atomic_load(A.sig_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(v >> 32) == it_epoch - 1u) { there = true; bits = (unsigned)v; break; }
+                        if ((spins & 255u) == 255u && vjf_abort_seen(SC + VJF_SC_STATUS)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    s_flag[2] = (int)bits; s_flag[3] = there ? 1 : 0;
+                }
+                __syncthreads();
+                sig = __uint_as_float((unsigned)s_flag[2]);
+                if (!s_flag[3] && tid == 0) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
+                lscr_guard = true;
+                return;
+            }
             // (no acquire: the one thing read behind this wait is sigma, with an sc1 load)
             if (!vjf_wg_wait_sc1(A.wait_count, it_wait_target, tid, SC + VJF_SC_STATUS)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
             sig = __hip_atomic_load(S + P.off[VJF_SLOT_TR_LOGVAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -737,6 +761,15 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                         // column k of L and Dinv_k are final: out they go beside the next chain.  Their flag follows one phase
                         // later, when the write-through stores have long drained: this wavefront never holds up the phase barrier
                         if (k > 0) publish(k - 1, k, 0u);
+                        if (k == 0 && lscr_guard) {                     // (this wavefront alone writes the scratch copies)
+                            bool there = false;
+                            for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
+                                if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - it_wait_target) >= 0) { there = true; break; }
+                                if ((spins & 255u) == 255u && vjf_abort_seen(SC + VJF_SC_STATUS)) break;
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            if (!there && lane == 0) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
+                        }
                         for (int it = 0; it < nbl - k; ++it) put_block(s_blk + (size_t)vtri(k + it, k) * 1024, A.lscr, n, (k + it) * 32, k * 32, it == 0);
                         put_block(s_aux + (size_t)k * 1024, A.dinv_out + (size_t)k * 1024, 32, 0, 0, false);
                         if (k == nbl - 1) publish(k, k + 1, 0u);

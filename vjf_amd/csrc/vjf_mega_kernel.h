@@ -50,6 +50,7 @@ enum {
     MG_C_REDO_B = 0,     // trial workgroups whose REPLAYED late slab is in memory             target (replays so far) n_trial
     MG_C_REDO_S = 176,   // SGD workgroups done with a replayed step                         target (replays so far) n_sgd
     MG_C_IMG = 208,      // SGD workgroups whose share of the parameter image is in memory (start of the launch)  target n_sgd
+    MG_C_SIGW = 224,     // 8 bytes: {epoch, sigma} from the y / W loop to the Cholesky loop of the next step
     MG_C_MASK = 192,     // (step + 1) << 8 | non-finite loss components (1 recon, 2 dynamics, 4 entropy) of the last step that had one
     MG_C_COLFLAGS = 160, // [0 .. VJF_CHOL_MAXBLK]: column flags of the Cholesky loop; [VJF_CHOL_MAXBLK + 2]: its "operands loaded" word
     MG_C_WORDS = 256
@@ -171,6 +172,33 @@ __device__ __forceinline__ float4 mg_ld4(__amdgpu_buffer_rsrc_t r, int float_ind
 // two batches in flight: while one batch's 32 MFMAs issue the next one's loads are on their way (and the SIMD's other wavefront
 // fills what latency is left).  The loads are sc1 (they bypass this CU's vector L1): these matrices are rewritten every step by
 // other roles, and the waits in front of them do not acquire.
+// one batch of mg_mma2 (below) on its own: the 16 A-operand loads of k-steps s0 .. s0 + 15, and their MFMAs -- for a product
+// whose loads are issued long before its turn (pt.mean: in front of the variance tiles)
+__device__ __forceinline__ void mg_mma2_ld16(float (&a)[16], const float* __restrict__ Ag, int lda, int M, int m0, int kb, int ke, int s0, int lane) {
+    const int i = lane & 15, kk = lane >> 4;
+    const bool rv = (m0 + i) < M;
+    const unsigned row = rv ? (unsigned)(m0 + i) : 0u;
+    const int klast = ke - 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const int k = min(kb + 4 * (s0 + q) + kk, klast); const float v = mg_ld(Ag + row + (unsigned)k * (unsigned)lda); a[q] = rv ? v : 0.f; }
+}
+__device__ __forceinline__ void mg_mma2_mm16(vjf_f32x4& acc0, vjf_f32x4& acc1, const float (&a)[16], const float* Xs, int kb, int ke, int s0, int lane) {
+    constexpr int LD = VJF_MG_LD;
+    const int i = lane & 15, kk = lane >> 4;
+    const float* xp = Xs + i;
+    const int nst = (ke - kb + 3) >> 2, klast = ke - 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (s0 + q < nst) {                            // (uniform)
+            const int k = kb + 4 * (s0 + q) + kk;
+            const int kc = min(k, klast);
+            const float av = k < ke ? a[q] : 0.f;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD + 16], acc1, 0, 0, 0);
+        }
+    }
+}
+
 template <bool DEEP = false>
 __device__ __forceinline__ void mg_mma2(vjf_f32x4& acc0, vjf_f32x4& acc1, const float* __restrict__ Ag, int lda, int M, int m0,
                                         const float* Xs, int kb, int ke, int lane) {
@@ -751,8 +779,18 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
             if (!replay) {
                 const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
+                const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
                 const int ntile = (n + 15) >> 4;
                 float v2a = 0.f, v2b = 0.f;
+                // pt.mean: dz <= 16 rows = one tile, K = n: every wavefront takes a K slice behind its variance tiles; the slice's
+                // operand loads (at most 16 k-steps when n <= 512) go out now, in front of the variance tiles' own
+                const int nsl = min(NW, part_rows / 16);
+                const int msl = nsl - 1 - wave;                                // (the last wavefronts have the lightest variance shares)
+                const int mper = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
+                const int mkb = msl * mper, mke = min(n, (msl + 1) * mper);
+                const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
+                float am[16];
+                if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
                 // tiles in descending cost, dealt to the wavefronts in a snake so that the triangular work balances
                 for (int r = 0;; ++r) {
                     const int idx = (r & 1) ? r * NW + NW - 1 - wave : r * NW + wave;
@@ -768,14 +806,11 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
                 v2b += __shfl_xor(v2b, 16, 64); v2b += __shfl_xor(v2b, 32, 64);
                 if (lane < 16) { s_red[wave * TR + lane] = v2a; s_red[wave * TR + 16 + lane] = v2b; }
-                // pt.mean: dz <= 16 rows = one tile, K = n: every wavefront takes a K slice behind its variance tiles
-                const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
-                const int nsl = min(NW, part_rows / 16);
                 if (wave < nsl) {
-                    const int sl = nsl - 1 - wave;                             // (the last wavefronts have the lightest variance shares)
-                    const int per = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
+                    const int sl = msl;
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, sl * per, min(n, (sl + 1) * per), lane);
+                    if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, mkb, mke, 0, lane); }
+                    else mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, mkb, mke, lane);
                     float* pr = s_part + (size_t)(sl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }

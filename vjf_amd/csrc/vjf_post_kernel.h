@@ -53,6 +53,8 @@ struct VjfPostArgs {
                             //    knowing whether the factorisation would succeed: on failure the y / W workgroup takes it back
     int fold_sigma;         // 1: the y / W workgroup goes on to the state-noise update (no vjf_resid / vjf_sigma launch)
     unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memrealtime of the y / W workgroup, slots 16..21
+    unsigned long long* sig_word; // non-null: the new sigma also goes out as ONE 8-byte word {epoch, bits of sigma} for the Cholesky loop
+                                  //   of the next step (it then needs neither this workgroup's exit count nor a second load)
 };
 
 #define VJF_POST_STAMP(i)                                                                   \
@@ -506,9 +508,12 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
             float* St = A.state;
             float* SC = St + P.off[VJF_SLOT_SCALARS];
             const float mse = (float)(t * pre_scale);
-            __hip_atomic_store(St + P.off[VJF_SLOT_TR_LOGVAR], logf(pre_old + ((float)A.B_total / pre_tot) * mse), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            const float new_sig = logf(pre_old + ((float)A.B_total / pre_tot) * mse);
+            __hip_atomic_store(St + P.off[VJF_SLOT_TR_LOGVAR], new_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(SC + VJF_SC_N_TR, pre_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (A.sig_word)
+                __hip_atomic_store(A.sig_word, ((unsigned long long)it_epoch << 32) | (unsigned long long)__float_as_uint(new_sig), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             if (failed) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
         }
         VJF_POST_STAMP(21);
