@@ -373,6 +373,31 @@ def test_nonfinite_component_is_dropped_like_the_reference(vjf, which):
     assert (m.recognition.mean.weight - w_before).abs().max() > 1e-4
 
 
+def test_refused_cooperative_launch_falls_back_to_per_step_kernels(vjf, monkeypatch):
+    """When the runtime refuses the cooperative launch (the grid cannot be resident as a whole: compute units masked off or held
+    by another process; injected here) the context leaves the one-launch route and the same call goes on with the per-step
+    kernels: same results to summation order, status clean."""
+    g = torch.Generator().manual_seed(15)
+    y, eps = torch.randn(6, 96, 10, generator=g), torch.randn(6, 2, 96, 3, generator=g)
+    torch.manual_seed(14)
+    ref = vjf.VJF.make_model(10, 3, 0, 40, [8], likelihood="gaussian")
+    mu_r, lv_r, loss_r = ref.filter_sequence(y, eps=eps)
+    assert ref.route() == "one-launch"
+    torch.manual_seed(14)
+    m = vjf.VJF.make_model(10, 3, 0, 40, [8], likelihood="gaussian")
+    monkeypatch.setenv("VJF_DEBUG_REFUSE_COOP", "1")
+    mu, lv, loss = m.filter_sequence(y, eps=eps)
+    monkeypatch.delenv("VJF_DEBUG_REFUSE_COOP")
+    assert m.route() == "per-step" and m.check_status() == 0
+    close(mu, mu_r, rtol=2e-5, atol=2e-5)
+    close(loss, loss_r, rtol=2e-5, atol=2e-5)
+    close(m.recognition.mean.weight, ref.recognition.mean.weight, rtol=5e-4, atol=2e-5)
+    close(m.transition.velocity.w_mean, ref.transition.velocity.w_mean, rtol=5e-3, atol=5e-5)
+    close(m.transition.logvar, ref.transition.logvar, rtol=0, atol=5e-5)
+    q, l1 = m.filter(y[0], eps=(eps[0, 0], eps[0, 1]))            # (and single steps stay there)
+    assert m.check_status() == 0
+
+
 def test_timed_out_handoff_ends_the_launch_and_raises(vjf, monkeypatch):
     """A hand-off inside the one-launch route that runs out of its bound (injected: the Cholesky loop reports its statistics wait
     of step 3 as timed out): every role leaves its loop at its next wait (nothing hangs, the grid drains), the sticky status

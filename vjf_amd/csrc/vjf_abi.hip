@@ -154,6 +154,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 constexpr size_t kMegaLds = kMaxLds - 512;             // dynamic LDS of every workgroup of the launch (one workgroup per CU)
 constexpr int kMegaMaxTrialWg = 256, kMegaMaxGramWg = 64;
 struct MegaShape { int n_rls, n_trial, n_gram, n_prep, n_sgd, ntiles, gram_rows; };
+constexpr int kMegaRefused = 1 << 20;                  // filter_seq_mega: the runtime refused the cooperative launch (not an error code of the ABI)
 
 bool mega_plan_ok(const VjfPlan& P) {
     const int nbl = (P.n + 31) / 32;
@@ -854,7 +855,18 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
         VJF_HIP(hipGetLastError());
         return 0;
     }
-    VJF_HIP(hipLaunchCooperativeKernel((const void*)vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), args, (unsigned)kMegaLds, c->stream));
+    // A cooperative launch is refused when the grid cannot be resident as a whole -- compute units masked off or held by another
+    // process: the context then leaves this route for good and the caller's entry point goes on with the per-step kernels
+    // (nothing of the state has been touched yet).
+    const char* refuse = getenv("VJF_DEBUG_REFUSE_COOP");                  // (test hook)
+    const hipError_t le = (refuse && atoi(refuse)) ? hipErrorCooperativeLaunchTooLarge
+                          : hipLaunchCooperativeKernel((const void*)vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), args, (unsigned)kMegaLds, c->stream);
+    if (le == hipErrorCooperativeLaunchTooLarge || le == hipErrorLaunchOutOfResources) {
+        (void)hipGetLastError();
+        c->mega_ok = false;
+        return kMegaRefused;
+    }
+    VJF_HIP(le);
     return 0;
 }
 
@@ -1050,8 +1062,10 @@ int vjf_filter_step(vjf_ctx* c, int32_t B, const float* y, const float* u, const
                     const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, float* loss4, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_step: null context");
     DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
-    if (mega_route(c, flags) && eps_s && eps_t && eps_t == eps_s + (size_t)B * c->plan.dz)          // (the sequence layout of eps: (2, B, dz))
-        return filter_seq_mega(c, 1, B, y, u, eps_s, mu_s, lv_s, mu_t, lv_t, loss4, flags);
+    if (mega_route(c, flags) && eps_s && eps_t && eps_t == eps_s + (size_t)B * c->plan.dz) {        // (the sequence layout of eps: (2, B, dz))
+        const int rc = filter_seq_mega(c, 1, B, y, u, eps_s, mu_s, lv_s, mu_t, lv_t, loss4, flags);
+        if (rc != kMegaRefused) return rc;
+    }
     if (mega_route(c, flags)) {
         // the two draws are separate tensors: the sequence entry point wants them adjacent -- stage them in the workspace
         int rc = check_step_args(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t);
@@ -1060,7 +1074,8 @@ int vjf_filter_step(vjf_ctx* c, int32_t B, const float* y, const float* u, const
         const size_t sz = (size_t)B * c->plan.dz;
         VJF_HIP(hipMemcpyAsync(st, eps_s, sz * 4, hipMemcpyDeviceToDevice, c->stream));
         VJF_HIP(hipMemcpyAsync(st + sz, eps_t, sz * 4, hipMemcpyDeviceToDevice, c->stream));
-        return filter_seq_mega(c, 1, B, y, u, st, mu_s, lv_s, mu_t, lv_t, loss4, flags);
+        rc = filter_seq_mega(c, 1, B, y, u, st, mu_s, lv_s, mu_t, lv_t, loss4, flags);
+        if (rc != kMegaRefused) return rc;
     }
     int rc = vjf_filter_local(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags);
     if (rc) return rc;
@@ -1093,6 +1108,10 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
             int rc = route(c, n, B, y + t0 * sy, u ? u + t0 * su : nullptr, eps + (size_t)t0 * 2 * sz,
                            t0 ? mu + (size_t)(t0 - 1) * sz : mu0, t0 ? lv + (size_t)(t0 - 1) * sz : lv0,
                            mu + (size_t)t0 * sz, lv + (size_t)t0 * sz, loss ? loss + 4 * (size_t)t0 : nullptr, flags);
+            if (rc == kMegaRefused)                                        // (the context has left the one-launch route: the rest per step)
+                return vjf_filter_seq(c, T - t0, B, y + t0 * sy, u ? u + t0 * su : nullptr, eps + (size_t)t0 * 2 * sz,
+                                      t0 ? mu + (size_t)(t0 - 1) * sz : mu0, t0 ? lv + (size_t)(t0 - 1) * sz : lv0,
+                                      mu + (size_t)t0 * sz, lv + (size_t)t0 * sz, loss ? loss + 4 * (size_t)t0 : nullptr, flags);
             if (rc) return rc;
             if (n > chunk) break;
         }
