@@ -191,3 +191,31 @@ def test_config_D_one_gpu_and_shard_sum(vjf):
 def _fresh(vjf, c):
     torch.manual_seed(13)
     return _model(vjf, c, lr=1e-4)
+
+
+def test_replay_with_several_tiles_per_workgroup(vjf):
+    """The replay of a step with a non-finite loss component (vjf/model.py:138-149) when a trial workgroup owns more than one tile
+    (B = 8192: two tiles each at 256 CUs; the predictive moments come back from their per-trial save, the late slab is stored by the
+    first tile and added to by the second), in the middle of a sequence; against the fp32 oracle."""
+    import warnings
+    c = dict(B=8192, dz=10, dy=50, n=200, hidden=[128], lik="gaussian")
+    T = 3
+    torch.manual_seed(17)
+    m = _model(vjf, c, lr=1e-2)
+    y, eps = _data(c, T, 27)
+    yd, ed = y.cuda(), eps.cuda()
+    mu0, lv0, _ = m.filter_sequence(yd[:1], eps=ed[:1])
+    with torch.no_grad():
+        m.transition.velocity.w_chol.mul_(1e25)                  # the predictive variance, and with it the dynamics term, overflows
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s = load_oracle_state(m, np.float32)
+        mu, lv, loss = m.filter_sequence(yd[1:], qs=vjf.Gaussian(mu0[-1], lv0[-1]), eps=ed[1:])
+        assert m.status() & 2                                    # VJF_STATUS_NONFINITE_DYN
+        om, ol = mu0[-1].cpu().numpy(), lv0[-1].cpu().numpy()
+        for t in range(1, T):
+            o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
+            om, ol = o.mu_t, o.lv_t
+            close(mu[t - 1], o.mu_t, rtol=2e-4, atol=2e-4)
+            close(loss[t - 1], [o.loss, o.recon, o.dyn, o.entropy], rtol=2e-4, atol=2e-4)
+        state_close(m, s, rtol=2e-3, atol=2e-4, rls_rtol=2e-2, rls_atol=2e-3)
