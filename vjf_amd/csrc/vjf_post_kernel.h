@@ -584,24 +584,53 @@ struct VjfResidArgs {
     unsigned flags;
 };
 
-// q = -2 tr(W^T FDX) + tr(W^T G W), G symmetric: rows i and n-1-i of the lower triangle per work item.
+// q = -2 tr(W^T FDX) + tr(W^T G W) = sum_i W_i . ((G W)_i - 2 FDX_i): workgroup b forms the 16-row strips b, b + 64, .. of
+// T = G W as an LDS-tiled product (64 columns of G x 64 columns of W per stage) and contracts them with W on the spot in fp64 (the
+// three terms of the residual cancel to a small difference); one fp64 partial per workgroup.
 __global__ __launch_bounds__(256) void vjf_resid_kernel(VjfPlan P, VjfResidArgs A) {
+    __shared__ float s_g[16][65];
+    __shared__ float s_w[64][65];
     __shared__ double s_d[4];
     const int tid = threadIdx.x, n = P.n, dz = P.dz;
     const float* S = A.state;
     const float* W = S + P.off[VJF_SLOT_W_MEAN];
-    const float* G = A.red + P.red_G;
+    const float* G = A.red + P.red_G;                            // (both triangles are in the reduce buffer)
     const float* FDX = A.red + P.red_FDX;
+    const int r = tid >> 4, cq = (tid & 15) * 4;
     double part = 0.0;
-    const int nitems = n * n;                                   // element (i, j), only j <= i contributes
-    for (int e = blockIdx.x * 256 + tid; e < nitems; e += VJF_RESID_BLOCKS * 256) {
-        const int i = e / n, j = e - i * n;
-        if (j > i) continue;
-        float d = 0.f;
-        for (int c = 0; c < dz; ++c) d = fmaf(W[(size_t)i * dz + c], W[(size_t)j * dz + c], d);
-        part += (double)G[e] * (double)d * (i == j ? 1.0 : 2.0);
+    for (int i0 = blockIdx.x * 16; i0 < n; i0 += VJF_RESID_BLOCKS * 16) {
+        for (int c0 = 0; c0 < dz; c0 += 64) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};            // (fp32 products and sums per 16 x 4 patch of T, as the LDS-resident path's matrix-core tiles; fp64 from there)
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = tid + 256 * q, rr = e >> 6, jj = e & 63;
+                    s_g[rr][jj] = (i0 + rr < n && j0 + jj < n) ? G[(size_t)(i0 + rr) * n + j0 + jj] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int e = tid + 256 * q, jj = e >> 6, cc = e & 63;
+                    s_w[jj][cc] = (j0 + jj < n && c0 + cc < dz) ? W[(size_t)(j0 + jj) * dz + c0 + cc] : 0.f;
+                }
+                __syncthreads();
+#pragma unroll 8
+                for (int jj = 0; jj < 64; ++jj) {
+                    const float g = s_g[r][jj];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] = fmaf(g, s_w[jj][cq + k], acc[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + r, c = c0 + cq + k;
+                if (i < n && c < dz) {
+                    const double w = (double)W[(size_t)i * dz + c];
+                    part += w * ((double)acc[k] - 2.0 * (double)FDX[(size_t)i * dz + c]);
+                }
+            }
+        }
     }
-    for (int e = blockIdx.x * 256 + tid; e < n * dz; e += VJF_RESID_BLOCKS * 256) part -= 2.0 * (double)W[e] * (double)FDX[e];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
     if ((tid & 63) == 0) s_d[tid >> 6] = part;
