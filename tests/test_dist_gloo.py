@@ -116,7 +116,13 @@ def test_two_ranks_share_one_gpu_caller_side_route(tmp_path):
     m = _make()
     y, u, eps = _gpu_data()
     mu, lv, ls = m.filter_sequence(y.cuda(), u.cuda(), None, eps=eps.cuda())
+    assert m.check_status() == 0                    # (raises on a timed-out hand-off inside the launch)
     ref_losses, ref_blob, ref_mu = ls[:, 0].cpu().numpy(), m._blob.cpu().numpy().copy(), mu[-1].cpu().numpy()
+    # the same on this process's per-step kernels: tells a deviation of the single-process reference from one of the ranks
+    m1 = _make()
+    m1.set_overlap(False)
+    _, _, ls1 = m1.filter_sequence(y.cuda(), u.cuda(), None, eps=eps.cuda())
+    np.testing.assert_allclose(ref_losses, ls1[:, 0].cpu().numpy(), rtol=2e-5, err_msg="one-launch route vs per-step kernels, single process")
     out = str(tmp_path / "rank")
     mp.spawn(_gpu_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     r = [np.load(out + f".{k}.npz") for k in range(2)]

@@ -596,6 +596,21 @@ VjfTrialArgs trial_args(vjf_ctx* c, int32_t B, const float* y, const float* u, c
 
 int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16 : (B + 3) / 4; }   // (wide path: 4 trials per loss workgroup)
 
+// one GEMM of the wide routes: 128 x 128 or 128 x 64 tiles when the shape fills the chip with them and the operands can be
+// read 16 bytes at a time, else the 64 x 64 kernel
+void launch_wide_gemm(const VjfWideGemm& g, hipStream_t st) {
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+    const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.K % 4 == 0) && al16(g.A) && al16(g.Bm) &&
+                     (g.ta ? g.M % 4 == 0 : true) && (g.nt ? true : g.N % 4 == 0);
+    const int tm = (g.M + 127) / 128;
+    if (vec && g.M >= 256 && g.N >= 256 && tm * ((g.N + 127) / 128) >= 192)
+        hipLaunchKernelGGL(vjf_wide_gemm2_kernel<128>, dim3((g.N + 127) / 128, tm), dim3(256), 0, st, g);
+    else if (vec && g.M >= 256 && g.N >= 128 && tm * ((g.N + 63) / 64) >= 128)
+        hipLaunchKernelGGL(vjf_wide_gemm2_kernel<64>, dim3((g.N + 63) / 64, tm), dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL(vjf_wide_gemm_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
+}
+
 // K1 of the per-step routes.  part: 0 whole step, 1 forward half, 2 backward half (matrix-core kernel only)
 int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bool count_fwd = false,
                  const unsigned* rls_done = nullptr, unsigned rls_target = 0) {
@@ -623,7 +638,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
             VjfWideGemm g{};
             g.A = A_; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.C = C_; g.ldc = ldc; g.M = a.B; g.N = N; g.K = K; g.nt = nt; g.epi = epi;
             g.bias = bias; g.src = src; g.lds = lds; g.src_scale = 1.f; g.eps_t = a.eps_t; g.lv_t = a.lv_t;
-            hipLaunchKernelGGL(vjf_wide_gemm_kernel, dim3((N + 63) / 64, (a.B + 63) / 64), dim3(256), 0, st, g);
+            launch_wide_gemm(g, st);
         };
         const int gx = 1024;
         hipLaunchKernelGGL(vjf_wide_in_kernel, dim3(gx), dim3(256), 0, st, P, w);
@@ -997,7 +1012,7 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
                 VjfWideGemm g{};
                 g.A = A_; g.lda = lda; g.ta = ta; g.Bm = Bm; g.ldb = ldb; g.C = C_; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.nt = 0;
                 g.epi = WEPI_NONE; g.ok = ok;
-                hipLaunchKernelGGL(vjf_wide_gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
+                launch_wide_gemm(g, st);
             };
             const float* Sx = c->state;
             gemm(Sx + P.off[VJF_SLOT_W_PREC], P.n, 0, Sx + P.off[VJF_SLOT_W_MEAN], P.dz, a.gbuf, P.dz, P.n, P.dz, P.n, nullptr);   // P W

@@ -146,6 +146,30 @@ __host__ __device__ inline VjfMegaSlab vjf_mega_slab_layout(const VjfPlan& P) {
     return L;
 }
 
+// One entry of the layouts above for a layer / block index that is only known at run time, recomputed from the plan by a short
+// scalar loop: indexing the structs' arrays with it would put them into scratch memory (the kernel then needs a scratch buffer
+// at launch and pays memory round trips for what is a handful of integer additions).
+__device__ __forceinline__ void mg_theta_layer(const VjfPlan& P, int th0, int l, int& w, int& ldw, int& b) {
+    int o = th0, prev = P.din;
+    w = ldw = b = 0;
+    for (int k = 0; k <= l && k < P.L; ++k) {
+        ldw = vjf_mega_ld(prev);
+        w = o; o += (P.h[k] * ldw + 3) & ~3;
+        b = o; o += (P.h[k] + 3) & ~3;
+        prev = P.h[k];
+    }
+}
+__device__ __forceinline__ void mg_slab_block(const VjfPlan& P, int blk, int& off, int& ldm, int& rows) {
+    const int hL = P.h[P.L - 1];
+    int o = 0;
+    auto step = [&](int M, int r, bool take_it) { if (take_it) { off = o; ldm = (M + 3) & ~3; rows = r; } o += r * ((M + 3) & ~3); };
+    off = 0; ldm = 4; rows = 0;
+    step(P.dy, P.dz + 1, blk == 0);
+    step(P.dz, hL, blk == 1);
+    step(P.dz, hL + 1, blk == 2);
+    for (int l = P.L - 1, k = 3; l >= 0; --l, ++k) step(P.h[l], (l > 0 ? P.h[l - 1] : P.din) + 1, blk == k);
+}
+
 static inline size_t vjf_mega_gram_lds_floats(const VjfPlan& P) {      // rows of Phi | tile table | centroids^T | -1/(2 w^2) | xs rows
     const size_t npad = (size_t)((P.n + 3) & ~3);
     return (size_t)VJF_MG_GROWS * P.ldE + 64 + npad * P.dxu + npad + (size_t)VJF_MG_GROWS * P.dxu + 16;
@@ -411,7 +435,6 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     unsigned* cnt = A.cnt;
     const unsigned npost = (unsigned)(A.n_rls - 1);
     float* late = A.slab_late + (size_t)wg * A.late_len;
-    const VjfMegaSlab SL = vjf_mega_slab_layout(P);
     const int ldn = (n + 3) & ~3;                      // early slab: [16 columns][ldn] Phi^T dx (transposed), then the scalars
     const size_t sy = (size_t)A.B * dy, su = (size_t)A.B * du, sz = (size_t)A.B * dz;
     int ntl = 0;
@@ -641,12 +664,14 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 int kin = din, aoff = 0;
                 for (int l = 0; l < P.L; ++l) {
                     const float* WT = A.aux + P.aux_recT[l];                   // (kin, hl)
-                    const float* bias = tl ? smem + Lo.th_b[l] : S + P.off[VJF_SLOT_REC_B0 + 2 * l];
+                    int th_w = 0, th_ldw = 0, th_b = 0;
+                    if (tl) mg_theta_layer(P, Lo.th0, l, th_w, th_ldw, th_b);
+                    const float* bias = tl ? smem + th_b : S + P.off[VJF_SLOT_REC_B0 + 2 * l];
                     float* out = s_act + aoff * LD;
                     const int hl = P.h[l], mt = (hl + 15) >> 4;
                     for (int tt = wave; tt < mt; tt += NW) {
                         vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                        if (tl) mg_mma2_lds<false>(acc0, acc1, smem + Lo.th_w[l], Lo.th_ldw[l], hl, tt * 16, xin, 0, kin, lane);
+                        if (tl) mg_mma2_lds<false>(acc0, acc1, smem + th_w, th_ldw, hl, tt * 16, xin, 0, kin, lane);
                         else mg_mma2(acc0, acc1, WT, hl, hl, tt * 16, xin, 0, kin, lane);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -909,11 +934,13 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             //      waits for them to reach memory (vmcnt counts in order).
             int gbase = 0;                                                     // running tile count: gradient tiles go round the wavefronts
             auto grad_tensor = [&](const float* D, int M, const float* Bact, int Kin, int blkid) {
+                int b_off, b_ldm, b_rows;
+                mg_slab_block(P, blkid, b_off, b_ldm, b_rows);
                 const int ntm = (M + 15) >> 4, ntj = (Kin + 1 + 15) >> 4;
                 const unsigned mj = mg_magic(ntj);
                 for (int q = (wave - gbase) & (NW - 1); q < ntm * ntj; q += NW) {                   // this wavefront's tiles of the tensor
                     const int tm = mg_div(q, mj), tj = q - tm * ntj;
-                    mg_grad_tile(D, M, tm * 16, Bact, Kin, tj * 16, s_one, s_zero, late + SL.off[blkid], SL.ldm[blkid], SL.rows[blkid], first, lane);
+                    mg_grad_tile(D, M, tm * 16, Bact, Kin, tj * 16, s_one, s_zero, late + b_off, b_ldm, b_rows, first, lane);
                 }
                 gbase += ntm * ntj;
             };
@@ -953,6 +980,8 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     for (int q = 0; q < l - 1; ++q) aoff += P.h[q];
                     const float* hprev = s_act + aoff * LD;
                     const int mt = (hp + 15) >> 4;
+                    int d_w = 0, d_ldw = 0, d_b = 0;
+                    if (tl && l < P.L) mg_theta_layer(P, Lo.th0, l, d_w, d_ldw, d_b);
                     for (int tt = wave; tt < mt; tt += NW) {
                         vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                         if (l == P.L) {
@@ -964,7 +993,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                                 mg_mma2(acc0, acc1, Wl, hL, hL, tt * 16, s_dlv, 0, dz, lane);
                             }
                         } else if (tl) {
-                            mg_mma2_lds<true>(acc0, acc1, smem + Lo.th_w[l], Lo.th_ldw[l], hp, tt * 16, src, 0, P.h[l], lane);
+                            mg_mma2_lds<true>(acc0, acc1, smem + d_w, d_ldw, hp, tt * 16, src, 0, P.h[l], lane);
                         } else {
                             mg_mma2(acc0, acc1, S + P.off[VJF_SLOT_REC_W0 + 2 * l], hp, hp, tt * 16, src, 0, P.h[l], lane);   // (h_l, h_{l-1}): k-major
                         }

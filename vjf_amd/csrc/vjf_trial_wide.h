@@ -100,6 +100,146 @@ __global__ __launch_bounds__(256) void vjf_wide_gemm_kernel(VjfWideGemm g) {
     }
 }
 
+// The same product for large shapes: 128 x TN tiles (TN = 128 or 64), 2 x 2 wavefronts of 64 x TN/2 each (four or two
+// 32x32 accumulators), K chunks of 16 through LDS; the NEXT chunk's 16-byte global loads are issued before the current
+// chunk's MFMAs (register double buffering), so a wavefront has 32 (16) MFMAs per 32 (24) LDS reads and several workgroups
+// share a CU.  Rows of A / B that the loader reads 16 bytes at a time: lda, ldb multiples of 4 and 16-byte aligned bases
+// (the host checks; other shapes take vjf_wide_gemm_kernel).
+template <int TN>
+__global__ __launch_bounds__(256) void vjf_wide_gemm2_kernel(VjfWideGemm g) {
+    constexpr int TM = 128, KC = 16, NB = TN / 64;       // NB: 32-column blocks per wavefront
+    __shared__ float s_a[TM][KC + 1];
+    __shared__ float s_b[KC][TN + 1];
+    if (g.ok && g.ok[0] == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int wr = wave >> 1, wc = wave & 1;
+    vjf_f32x16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // loader roles: "k-contiguous" operands (A row-major, B as (N, K)): thread = (row, 8 consecutive k); "row-contiguous" ones
+    // (A transposed, B as (K, N)): thread = (k, 8 consecutive rows)
+    float4 ra[2], rb[TN / 64];
+    auto load_a = [&](int k0) {
+        if (!g.ta) {
+            const int row = tid >> 1, kq = (tid & 1) * 8, m = m0 + row;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = k0 + kq + 4 * q;
+                ra[q] = (m < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.A + (size_t)m * g.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < g.M && k + 3 >= g.K) { if (k + 1 >= g.K) ra[q].y = 0.f; if (k + 2 >= g.K) ra[q].z = 0.f; if (k + 3 >= g.K) ra[q].w = 0.f; }
+            }
+        } else {
+            const int kk = tid >> 4, mq = (tid & 15) * 8, k = k0 + kk;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + mq + 4 * q;
+                ra[q] = (k < g.K && m < g.M) ? *reinterpret_cast<const float4*>(g.A + (size_t)k * g.lda + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < g.K && m + 3 >= g.M) { if (m + 1 >= g.M) ra[q].y = 0.f; if (m + 2 >= g.M) ra[q].z = 0.f; if (m + 3 >= g.M) ra[q].w = 0.f; }
+            }
+        }
+    };
+    auto store_a = [&]() {
+        if (!g.ta) {
+            const int row = tid >> 1, kq = (tid & 1) * 8;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { float* d = &s_a[row][kq + 4 * q]; d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w; }
+        } else {
+            const int kk = tid >> 4, mq = (tid & 15) * 8;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { s_a[mq + 4 * q][kk] = ra[q].x; s_a[mq + 4 * q + 1][kk] = ra[q].y; s_a[mq + 4 * q + 2][kk] = ra[q].z; s_a[mq + 4 * q + 3][kk] = ra[q].w; }
+        }
+    };
+    auto load_b = [&](int k0) {
+        if (g.nt) {          // (N, K): TN rows x 16 k; TN = 128: (row, 8 k) as A; TN = 64: (row, 4 k)
+            constexpr int KPT = TN / 16;                                  // k per thread
+            const int nn = tid / (16 / KPT), kq = (tid % (16 / KPT)) * KPT, n = n0 + nn;
+#pragma unroll
+            for (int q = 0; q < TN / 64; ++q) {
+                const int k = k0 + kq + 4 * q;
+                rb[q] = (n < g.N && k < g.K) ? *reinterpret_cast<const float4*>(g.Bm + (size_t)n * g.ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < g.N && k + 3 >= g.K) { if (k + 1 >= g.K) rb[q].y = 0.f; if (k + 2 >= g.K) rb[q].z = 0.f; if (k + 3 >= g.K) rb[q].w = 0.f; }
+            }
+        } else {             // (K, N): 16 k x TN columns: thread = (k, TN / 16 consecutive columns)
+            constexpr int NPT = TN / 16;
+            const int kk = tid >> 4, nq = (tid & 15) * NPT, k = k0 + kk;
+#pragma unroll
+            for (int q = 0; q < TN / 64; ++q) {
+                const int n = n0 + nq + 4 * q;
+                rb[q] = (k < g.K && n < g.N) ? *reinterpret_cast<const float4*>(g.Bm + (size_t)k * g.ldb + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < g.K && n + 3 >= g.N) { if (n + 1 >= g.N) rb[q].y = 0.f; if (n + 2 >= g.N) rb[q].z = 0.f; if (n + 3 >= g.N) rb[q].w = 0.f; }
+            }
+        }
+    };
+    auto store_b = [&]() {
+        if (g.nt) {
+            constexpr int KPT = TN / 16;
+            const int nn = tid / (16 / KPT), kq = (tid % (16 / KPT)) * KPT;
+#pragma unroll
+            for (int q = 0; q < TN / 64; ++q) { s_b[kq + 4 * q][nn] = rb[q].x; s_b[kq + 4 * q + 1][nn] = rb[q].y; s_b[kq + 4 * q + 2][nn] = rb[q].z; s_b[kq + 4 * q + 3][nn] = rb[q].w; }
+        } else {
+            constexpr int NPT = TN / 16;
+            const int kk = tid >> 4, nq = (tid & 15) * NPT;
+#pragma unroll
+            for (int q = 0; q < TN / 64; ++q) { float* d = &s_b[kk][nq + 4 * q]; d[0] = rb[q].x; d[1] = rb[q].y; d[2] = rb[q].z; d[3] = rb[q].w; }
+        }
+    };
+    load_a(0); load_b(0);
+    for (int k0 = 0; k0 < g.K; k0 += KC) {
+        __syncthreads();                                   // (the previous chunk's readers are done)
+        store_a(); store_b();
+        __syncthreads();
+        if (k0 + KC < g.K) { load_a(k0 + KC); load_b(k0 + KC); }
+        const int rl = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < KC / 2; ++t) {
+            float a[2], b[NB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = s_a[wr * 64 + i * 32 + rl][2 * t + h];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) b[j] = s_b[2 * t + h][wc * (TN / 2) + j * 32 + rl];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = n0 + wc * (TN / 2) + j * 32 + (lane & 31);
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + i * 32 + vrow(r, h);
+                if (m >= g.M) continue;
+                float v = acc[i][j][r];
+                float* c = g.C + (size_t)m * g.ldc + n;
+                switch (g.epi) {
+                    case WEPI_BIAS: v += g.bias[n]; break;
+                    case WEPI_TANH_BIAS: v = tanhf(v + g.bias[n]); break;
+                    case WEPI_ADD_SRC: v = fmaf(g.src_scale, g.src[(size_t)m * g.lds + n], v); break;
+                    case WEPI_DTANH: { const float hv = g.src[(size_t)m * g.lds + n]; v *= (1.f - hv * hv); break; }
+                    case WEPI_ADDC_DTANH: { const float hv = g.src[(size_t)m * g.lds + n]; v = (*c + v) * (1.f - hv * hv); break; }
+                    case WEPI_SEED: {
+                        const float e = g.eps_t[(size_t)m * g.N + n], lv = g.lv_t[(size_t)m * g.N + n];
+                        c[g.N] = fmaf(v * e, 0.5f * expf(0.5f * lv), c[g.N]);            // dlv
+                        v += *c;                                                         // dmu
+                        break;
+                    }
+                    default: break;
+                }
+                *c = v;
+            }
+        }
+}
+
 struct VjfWideArgs {
     VjfTrialArgs t;
     float* XU;      // (B, dxu)  [xs | u]
