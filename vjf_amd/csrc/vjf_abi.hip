@@ -598,14 +598,15 @@ int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16
 
 // one GEMM of the wide routes: 128 x 128 or 128 x 64 tiles when the shape fills the chip with them and the operands can be
 // read 16 bytes at a time, else the 64 x 64 kernel
-void launch_wide_gemm(const VjfWideGemm& g, hipStream_t st) {
+void launch_wide_gemm(const VjfWideGemm& g0, hipStream_t st) {
+    VjfWideGemm g = g0;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
-    const bool vec = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.K % 4 == 0) && al16(g.A) && al16(g.Bm) &&
-                     (g.ta ? g.M % 4 == 0 : true) && (g.nt ? true : g.N % 4 == 0);
+    g.va = (g.lda % 4 == 0) && al16(g.A);
+    g.vb = (g.ldb % 4 == 0) && al16(g.Bm);
     const int tm = (g.M + 127) / 128;
-    if (vec && g.M >= 256 && g.N >= 256 && tm * ((g.N + 127) / 128) >= 192)
+    if (g.M >= 256 && g.N >= 256 && tm * ((g.N + 127) / 128) >= 192)
         hipLaunchKernelGGL(vjf_wide_gemm2_kernel<128>, dim3((g.N + 127) / 128, tm), dim3(256), 0, st, g);
-    else if (vec && g.M >= 256 && g.N >= 128 && tm * ((g.N + 63) / 64) >= 128)
+    else if (g.M >= 256 && g.N >= 64 && tm * ((g.N + 63) / 64) >= 32)
         hipLaunchKernelGGL(vjf_wide_gemm2_kernel<64>, dim3((g.N + 63) / 64, tm), dim3(256), 0, st, g);
     else
         hipLaunchKernelGGL(vjf_wide_gemm_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);

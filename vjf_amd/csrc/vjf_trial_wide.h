@@ -26,6 +26,7 @@ struct VjfWideGemm {
     // WEPI_SEED (dxt = dpy C):  dmu += dxt;  dlv += dxt * eps_t * exp(lv_t / 2) / 2   (C -> dmu, C + N -> dlv; ldc = ldD)
     const float* eps_t; const float* lv_t;
     const int* ok;                 // non-null: nothing is done when ok[0] == 0 (the RLS path after a failed factorisation)
+    int va, vb;                    // vjf_wide_gemm2_kernel: A / B can be read 16 bytes at a time (set by the launcher)
 };
 
 #define VJF_WG_KC 16
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256) void vjf_wide_gemm_kernel(VjfWideGemm g) {
 // The same product for large shapes: 128 x TN tiles (TN = 128 or 64), 2 x 2 wavefronts of 64 x TN/2 each (four or two
 // 32x32 accumulators), K chunks of 16 through LDS; the NEXT chunk's 16-byte global loads are issued before the current
 // chunk's MFMAs (register double buffering), so a wavefront has 32 (16) MFMAs per 32 (24) LDS reads and several workgroups
-// share a CU.  Rows of A / B that the loader reads 16 bytes at a time: lda, ldb multiples of 4 and 16-byte aligned bases
-// (the host checks; other shapes take vjf_wide_gemm_kernel).
+// share a CU.  An operand whose rows start on 16-byte boundaries (leading dimension a multiple of 4, aligned base: g.va / g.vb, set
+// by the launcher) is read 16 bytes at a time, another one float by float.
 template <int TN>
 __global__ __launch_bounds__(256) void vjf_wide_gemm2_kernel(VjfWideGemm g) {
     constexpr int TM = 128, KC = 16, NB = TN / 64;       // NB: 32-column blocks per wavefront
@@ -124,22 +125,30 @@ __global__ __launch_bounds__(256) void vjf_wide_gemm2_kernel(VjfWideGemm g) {
     // loader roles: "k-contiguous" operands (A row-major, B as (N, K)): thread = (row, 8 consecutive k); "row-contiguous" ones
     // (A transposed, B as (K, N)): thread = (k, 8 consecutive rows)
     float4 ra[2], rb[TN / 64];
+    // four consecutive floats at p (the first `valid` of them inside the matrix): one 16-byte load when the operand allows it
+    auto ld4 = [](const float* p, int valid, bool vec) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid >= 4 && vec) return *reinterpret_cast<const float4*>(p);
+        if (valid > 0) v.x = p[0];
+        if (valid > 1) v.y = p[1];
+        if (valid > 2) v.z = p[2];
+        if (valid > 3) v.w = p[3];
+        return v;
+    };
     auto load_a = [&](int k0) {
         if (!g.ta) {
             const int row = tid >> 1, kq = (tid & 1) * 8, m = m0 + row;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int k = k0 + kq + 4 * q;
-                ra[q] = (m < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.A + (size_t)m * g.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < g.M && k + 3 >= g.K) { if (k + 1 >= g.K) ra[q].y = 0.f; if (k + 2 >= g.K) ra[q].z = 0.f; if (k + 3 >= g.K) ra[q].w = 0.f; }
+                ra[q] = ld4(g.A + (size_t)(m < g.M ? m : 0) * g.lda + (k < g.K ? k : 0), m < g.M ? g.K - k : 0, g.va != 0);
             }
         } else {
             const int kk = tid >> 4, mq = (tid & 15) * 8, k = k0 + kk;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int m = m0 + mq + 4 * q;
-                ra[q] = (k < g.K && m < g.M) ? *reinterpret_cast<const float4*>(g.A + (size_t)k * g.lda + m) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < g.K && m + 3 >= g.M) { if (m + 1 >= g.M) ra[q].y = 0.f; if (m + 2 >= g.M) ra[q].z = 0.f; if (m + 3 >= g.M) ra[q].w = 0.f; }
+                ra[q] = ld4(g.A + (size_t)(k < g.K ? k : 0) * g.lda + (m < g.M ? m : 0), k < g.K ? g.M - m : 0, g.va != 0);
             }
         }
     };
@@ -161,8 +170,7 @@ __global__ __launch_bounds__(256) void vjf_wide_gemm2_kernel(VjfWideGemm g) {
 #pragma unroll
             for (int q = 0; q < TN / 64; ++q) {
                 const int k = k0 + kq + 4 * q;
-                rb[q] = (n < g.N && k < g.K) ? *reinterpret_cast<const float4*>(g.Bm + (size_t)n * g.ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n < g.N && k + 3 >= g.K) { if (k + 1 >= g.K) rb[q].y = 0.f; if (k + 2 >= g.K) rb[q].z = 0.f; if (k + 3 >= g.K) rb[q].w = 0.f; }
+                rb[q] = ld4(g.Bm + (size_t)(n < g.N ? n : 0) * g.ldb + (k < g.K ? k : 0), n < g.N ? g.K - k : 0, g.vb != 0);
             }
         } else {             // (K, N): 16 k x TN columns: thread = (k, TN / 16 consecutive columns)
             constexpr int NPT = TN / 16;
@@ -170,8 +178,7 @@ __global__ __launch_bounds__(256) void vjf_wide_gemm2_kernel(VjfWideGemm g) {
 #pragma unroll
             for (int q = 0; q < TN / 64; ++q) {
                 const int n = n0 + nq + 4 * q;
-                rb[q] = (k < g.K && n < g.N) ? *reinterpret_cast<const float4*>(g.Bm + (size_t)k * g.ldb + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < g.K && n + 3 >= g.N) { if (n + 1 >= g.N) rb[q].y = 0.f; if (n + 2 >= g.N) rb[q].z = 0.f; if (n + 3 >= g.N) rb[q].w = 0.f; }
+                rb[q] = ld4(g.Bm + (size_t)(k < g.K ? k : 0) * g.ldb + (n < g.N ? n : 0), k < g.K ? g.N - n : 0, g.vb != 0);
             }
         }
     };
