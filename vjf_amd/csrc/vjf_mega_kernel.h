@@ -89,6 +89,9 @@ struct VjfMegaTrialLds {
     int theta, th_w[VJF_MAX_HIDDEN], th_ldw[VJF_MAX_HIDDEN], th_head, th_ldh, th_dec, th_ldd, th_b[VJF_MAX_HIDDEN], th_bl, th_bd;
 };
 __host__ __device__ inline int vjf_mega_ld(int K) { return ((K + 1) & ~3) + 2; }
+// LAYERS = false (device code): the per-layer arrays are left alone -- filling them in a loop with a run-time index would put the
+// whole struct into scratch memory; the kernels get a layer's entries from mg_theta_layer
+template <bool LAYERS = true>
 __host__ __device__ inline VjfMegaTrialLds vjf_mega_trial_lds(const VjfPlan& P, int lds_limit_floats = 0) {
     VjfMegaTrialLds l;
     const int LD = VJF_MG_LD;
@@ -112,8 +115,12 @@ __host__ __device__ inline VjfMegaTrialLds vjf_mega_trial_lds(const VjfPlan& P, 
     {
         int prev = P.din;
         l.th0 = o;
-        for (int k = 0; k < VJF_MAX_HIDDEN; ++k) { l.th_w[k] = l.th_ldw[k] = l.th_b[k] = 0; }
-        for (int k = 0; k < P.L; ++k) { l.th_ldw[k] = vjf_mega_ld(prev); l.th_w[k] = take(P.h[k] * l.th_ldw[k]); l.th_b[k] = take(P.h[k]); prev = P.h[k]; }
+        if (LAYERS) for (int k = 0; k < VJF_MAX_HIDDEN; ++k) { l.th_w[k] = l.th_ldw[k] = l.th_b[k] = 0; }
+        for (int k = 0; k < P.L; ++k) {
+            const int ldw = vjf_mega_ld(prev), w = take(P.h[k] * ldw), b = take(P.h[k]);
+            if (LAYERS) { l.th_ldw[k] = ldw; l.th_w[k] = w; l.th_b[k] = b; }
+            prev = P.h[k];
+        }
         l.th_ldh = vjf_mega_ld(prev); l.th_head = take(2 * P.dz * l.th_ldh); l.th_bl = take(P.dz);
         l.th_ldd = vjf_mega_ld(P.dz); l.th_dec = take(P.dy * l.th_ldd); l.th_bd = take(P.dy);
         l.th_len = o - l.th0;
@@ -415,7 +422,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     float* SCW = A.state + P.off[VJF_SLOT_SCALARS];
     const bool warm = false;                           // (this launch only runs sgd + update without warm-up)
     const unsigned m_dy = mg_magic(dy), m_dz = mg_magic(dz), m_du = mg_magic(du > 0 ? du : 1);
-    const VjfMegaTrialLds Lo = vjf_mega_trial_lds(P, A.lds_floats);
+    const VjfMegaTrialLds Lo = vjf_mega_trial_lds<false>(P, A.lds_floats);
     const bool tl = Lo.theta != 0;                    // the optimised parameters are staged in LDS once per step
     float* s_cen = smem + Lo.cen; float* s_iw = smem + Lo.iw;
     float* s_in = smem + Lo.in; float* s_xu = smem + Lo.xu; float* s_phi = smem + Lo.phi; float* s_act = smem + Lo.act;
@@ -823,7 +830,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     const int tt = ntile - 1 - idx, j0 = tt * 16;
                     const int K = tri ? min(n, j0 + 16) : n;
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2<true>(acc0, acc1, Wc, n, n, j0, s_phi, 0, K, lane);
+                    mg_mma2(acc0, acc1, Wc, n, n, j0, s_phi, 0, K, lane);
                     v2a = fmaf(acc0[0], acc0[0], fmaf(acc0[1], acc0[1], fmaf(acc0[2], acc0[2], fmaf(acc0[3], acc0[3], v2a))));
                     v2b = fmaf(acc1[0], acc1[0], fmaf(acc1[1], acc1[1], fmaf(acc1[2], acc1[2], fmaf(acc1[3], acc1[3], v2b))));
                 }
@@ -1403,7 +1410,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     // (set by the host between launches, never inside one)
     const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
     const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
-    const bool tl = vjf_mega_trial_lds(P, A.lds_floats).theta != 0;   // the trial role reads the LDS image (else: the state and its transposed copies)
+    const bool tl = vjf_mega_trial_lds<false>(P, A.lds_floats).theta != 0;   // the trial role reads the LDS image (else: the state and its transposed copies)
     // a quad of the slab (four consecutive output units of one input: vjf_mega_slab_layout) per 8 lanes: lane p sums the late slabs [p npq, (p+1) npq) (16-byte loads, all in flight together with
     // the quad's old values, its table entries and the step's loss sums), then a fixed xor tree; lane 0 of the group clips and
     // steps its four parameters (model.py:210-211)
