@@ -41,17 +41,17 @@ extern "C" {
 #define VJF_STATUS_NONFINITE_DYN 2u     /* l_dynamics non-finite (model.py:141-142)               */
 #define VJF_STATUS_NONFINITE_ENT 4u     /* entropy non-finite (model.py:144-145)                  */
 #define VJF_STATUS_RLS_FAILED 8u        /* Cholesky pivot <= 0 in rls: RLS state left unchanged   */
-/* detail bits beside VJF_STATUS_RLS_FAILED: which bounded wait of vjf_filter_seq's multi-stream schedule ran out (a kernel
-   waited for a kernel of another stream that did not deliver in time; results of the call are then not to be used) */
-#define VJF_STATUS_WAIT_RESIDENT 0x100u  /* SGD kernel: RLS kernels not resident                  */
-#define VJF_STATUS_WAIT_OPERAND 0x200u   /* operand kernel: previous step's RLS update            */
-#define VJF_STATUS_WAIT_STATS 0x400u     /* Cholesky loop: statistics reduced                     */
-#define VJF_STATUS_WAIT_SIGMA 0x800u     /* Cholesky loop: previous step's RLS update             */
-#define VJF_STATUS_WAIT_GATE 0x1000u     /* a gate kernel / in-kernel gate of the Gram kernel     */
-#define VJF_STATUS_WAIT_GATE2 0x2000u    /* a two-count gate kernel                               */
-#define VJF_STATUS_WAIT_G 0x4000u        /* y / W loop: operands (g)                              */
-#define VJF_STATUS_WAIT_COLUMN 0x8000u   /* post kernel: a column of L, or the trial kernel's readers */
-#define VJF_STATUS_WAIT_K1 0x10000u      /* trial kernel: previous step's RLS update              */
+/* detail bits beside VJF_STATUS_RLS_FAILED: which bounded in-kernel wait of vjf_filter_seq / vjf_filter_step ran out (a role or
+   kernel waited for another one that did not deliver in time; results of the call are then not to be used) */
+#define VJF_STATUS_WAIT_RESIDENT 0x100u  /* SGD role / kernel: the trial role's late slabs                         */
+#define VJF_STATUS_WAIT_OPERAND 0x200u   /* operand role / kernel: its inputs (early slabs, statistics, previous RLS update) */
+#define VJF_STATUS_WAIT_STATS 0x400u     /* Cholesky loop: statistics reduced                                      */
+#define VJF_STATUS_WAIT_SIGMA 0x800u     /* Cholesky loop: previous step's sigma / RLS update                      */
+#define VJF_STATUS_WAIT_GATE 0x1000u     /* trial role: parameters of the previous step; a gate kernel of the per-step route */
+#define VJF_STATUS_WAIT_GATE2 0x2000u    /* Gram role: posterior, previous slab sum                                */
+#define VJF_STATUS_WAIT_G 0x4000u        /* y / W loop: operands (g)                                               */
+#define VJF_STATUS_WAIT_COLUMN 0x8000u   /* y / W and inverse loops: a column of L, or the trial role's readers    */
+#define VJF_STATUS_WAIT_K1 0x10000u      /* trial role / kernel: previous step's RLS update                        */
 
 /* Slots of the state blob, in the reference's state_dict order followed by the plain-attribute
  * RLS tensors and the scalars the reference keeps as Python numbers. */
@@ -179,12 +179,14 @@ int vjf_filter_global(vjf_ctx* ctx, int32_t B_total, float* loss4, uint32_t flag
 /* T successive steps, each fed the previous posterior: the inner loop of VJF.fit
  * (model.py:252-261).  y (T,B,ydim); u (T,B,udim) or NULL; eps (T,2,B,xdim);
  * mu0/lv0 (B,xdim) or NULL => prior; outputs mu, lv (T,B,xdim), loss (T,4).
- * With update and without warm-up the steps run as a multi-stream schedule (bit-identical to the
- * one-stream order).  On a single rank its RLS chain runs in kernels that stay resident for the
- * sequence; the call then checkpoints the state blob, synchronises the caller's stream ONCE at
- * the end to read the status word, and if one of the schedule's bounded waits ran out
- * (VJF_STATUS_WAIT_*) restores the blob and runs the sequence again with a launch per step
- * (VJF_NO_SEQ_GUARD=1: no checkpoint, no synchronisation, no re-run). */
+ * On a single rank with sgd + update and no warm-up (plans the one-launch route serves: see vjf_route) the whole call -- per
+ * chunk of 16384 steps -- is ONE cooperative kernel launch; the call stays asynchronous.  With communicators (vjf_comm_init)
+ * the steps run as per-step kernels on three internal streams with the sums over ranks done by RCCL; otherwise step by step
+ * on the caller's stream.  Every in-kernel wait is bounded: one that runs out raises VJF_STATUS_RLS_FAILED plus a
+ * VJF_STATUS_WAIT_* detail bit (vjf_get_status), ends the other waits of the call at once, and the outputs of the call are
+ * not to be used.  A loss component that is not finite (VJF_STATUS_NONFINITE_*) is handled as vjf/model.py:138-149 does on the
+ * one-launch route (the component becomes 0 and the step's gradient is that of the others); on the per-step routes the SGD
+ * step of such a step is skipped. */
 int vjf_filter_seq(vjf_ctx* ctx, int32_t T, int32_t B, const float* y, const float* u, const float* eps,
                    const float* mu0, const float* lv0, float* mu, float* lv, float* loss, uint32_t flags);
 
