@@ -509,7 +509,7 @@ struct VjfCholArgs {
                            //   P and forms g runs beside this kernel, on the post kernel's stream, instead of before it
     const unsigned* wait_count; unsigned wait_target;
     int src_state;         // self_prep: P_old comes from the state's P (first step of a sequence) instead of pscr
-    // persistent form (vjf_filter_seq): nsteps > 0 -> ONE launch runs the factorisations of nsteps consecutive steps on its CU
+    // looping form (the Cholesky role of the one-launch route, vjf_mega_kernel.h): nsteps > 0 -> ONE launch runs the factorisations of nsteps consecutive steps on its CU
     // (a kernel of this size is not placed while trial-kernel workgroups hold LDS on every CU; resident, it starts the moment
     // sigma arrives).  Step `it`: epoch + it, statistics in red (even step0 + it) or red2 (odd), ready when *stat_count has
     // reached stat_target + it * stat_stride; sigma when *wait_count has reached wait_target + it * wait_stride.
@@ -562,7 +562,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                                               const float* it_red, const unsigned it_wait_target, const unsigned it_stat_target,
                                               const bool it_src_state) {
     int tid = threadIdx.x;
-    // (the persistent loop calls this body once per step: without the barrier the compiler hoists every lane-dependent address
+    // (the looping form calls this body once per step: without the barrier the compiler hoists every lane-dependent address
     //  of the body out of that loop and spills hundreds of registers)
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
@@ -1046,7 +1046,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
 
 // One-time clearing of the halves that the post kernel never writes (block-lower part of w_chol, block-upper part of
 // w_pchol), for callers that run the Cholesky kernel beside a reader of w_chol (vjf_filter_seq).  grid-stride.
-// One pass (nsteps <= 0) or the persistent form: nsteps factorisations, one after the other (see VjfCholArgs::nsteps).  The
+// One pass (nsteps <= 0) or the looping form: nsteps factorisations, one after the other (see VjfCholArgs::nsteps).  The
 // per-step values travel as scalars beside the kernel arguments, which stay in scalar registers.
 template <int DZP>
 __device__ __forceinline__ void vjf_chol_loop(const VjfPlan& P, const VjfCholArgs& A, float* lds, int* s_dead) {
@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void vjf_chol_loop(const VjfPlan& P, const VjfCholArg
 template <int DZP>
 __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_chol_lds_kernel(VjfPlan P, VjfCholArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int s_dead;                             // a wait timed out: the persistent form stops (status says so)
+    __shared__ int s_dead;                             // a wait timed out: the looping form stops (status says so)
     if (threadIdx.x == 0) s_dead = 0;
     __syncthreads();
     vjf_chol_loop<DZP>(P, A, lds, &s_dead);

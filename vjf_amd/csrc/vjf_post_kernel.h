@@ -43,7 +43,7 @@ struct VjfPostArgs {
     int role;               // 0: one launch, 2 nbl + 1 workgroups; 1: the 2 nbl inverse workgroups alone -- they keep only the
                             //    current column of L in LDS (48 KB: they fit beside a trial-kernel workgroup on its CU);
                             //    2: the y / W workgroup alone (it needs all of L for the backward substitution)
-    // persistent form (vjf_filter_seq): nsteps > 0 -> one launch serves nsteps consecutive steps (its workgroups stay on their
+    // looping form (the y / W and inverse roles of the one-launch route, vjf_mega_kernel.h): nsteps > 0 -> one launch serves nsteps consecutive steps (its workgroups stay on their
     // CUs).  Step `it`: epoch + it, statistics in red / red2 by the parity of step0 + it, k1_target + it * k1_stride, and g
     // (from the operand kernel, another stream) is there when *prep_count has reached prep_target + it * prep_stride.
     int nsteps, step0;
@@ -521,7 +521,7 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
     leave();
 }
 
-// One pass (nsteps <= 0) or the persistent form: nsteps steps, one after the other (see VjfPostArgs::nsteps)
+// One pass (nsteps <= 0) or the looping form: nsteps steps, one after the other (see VjfPostArgs::nsteps)
 __device__ __forceinline__ void vjf_rls_post_loop(const VjfPlan& P, const VjfPostArgs& A, float* lds, int* s_dead, const int role, const int bix) {
     const int steps = A.nsteps > 0 ? A.nsteps : 1;
     for (int it = 0; it < steps; ++it) {
@@ -535,17 +535,15 @@ __device__ __forceinline__ void vjf_rls_post_loop(const VjfPlan& P, const VjfPos
 
 __global__ __launch_bounds__(VJF_POST_THREADS) void vjf_rls_post_kernel(VjfPlan P, VjfPostArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int s_dead;                                     // a wait timed out: the persistent form stops (status says so)
+    __shared__ int s_dead;                                     // a wait timed out: the looping form stops (status says so)
     if (threadIdx.x == 0) s_dead = 0;
     __syncthreads();
     vjf_rls_post_loop(P, A, lds, &s_dead, A.role, (int)blockIdx.x);
 }
 
-// vjf_filter_seq, persistent RLS chain: workgroup 0 is the Cholesky kernel's loop, workgroup 1 the y / W workgroup's loop, for all
-// the steps of the sequence in ONE launch.  Each asks for a CU's whole LDS, so they sit on two CUs of their own from the first
-// step to the last: no launch, no gate and -- what decided it -- no waiting for a CU without trial-kernel workgroups on it between
-// sigma(t-1) and the first column of step t.  The 2 nbl inverse workgroups (one column of L in LDS, they share their CUs with the
-// trial kernel) are a second persistent launch of vjf_rls_post_kernel with role 1.
+// The RLS update of ONE step as one launch (the per-step three-stream route): workgroup 0 is the Cholesky workgroup, workgroup 1
+// the y / W workgroup, the rest the inverse workgroups; they hand columns over through the flags as the workgroups of the
+// one-launch route do.
 template <int DZP>
 __global__ __launch_bounds__(VJF_CHOL_THREADS) void vjf_rls_pair_kernel(VjfPlan P, VjfCholArgs C, VjfPostArgs Q) {
     static_assert(VJF_CHOL_THREADS == VJF_POST_THREADS, "one workgroup size for both halves");
