@@ -308,7 +308,7 @@ def main():
             meta = json.load(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_meta.json")))
             nst = meta.get("steps_in_all_launches")
             kstats = {"file": "profiles/r02_kernel_stats.csv", "command": meta.get("command"), "steps_per_launch": meta.get("steps_per_launch"),
-                      "note": meta.get("note"),
+                      "note": meta.get("note"), "mega_launches_us": meta.get("mega_launches_us"),
                       "kernels": [{"name": r_["Name"].split("(")[0].replace("void ", ""), "calls": int(r_["Calls"]), "avg_us": float(r_["AverageNs"]) / 1e3,
                                    "max_us": float(r_["MaxNs"]) / 1e3,
                                    "us_per_step": (float(r_["TotalDurationNs"]) / 1e3 / nst) if (nst and "mega" in r_["Name"]) else None}

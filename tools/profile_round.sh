@@ -21,8 +21,14 @@ f=$(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1)
 [ -s "$f" ] || { echo "stats failed"; tail -5 $O/${TAG}_stats.err; exit 1; }
 cp "$f" $O/${TAG}_kernel_stats.csv
 python - <<PY
-import json
-json.dump({"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps $K --warmup $W --repeats 1 --no-cpu-baseline --no-elbo-check",
+import csv, glob, json
+tr = glob.glob("$O/${TAG}_stats/**/*kernel_trace.csv", recursive=True)
+launches = []
+if tr:
+    for r in csv.DictReader(open(tr[0])):
+        if "vjf_mega_kernel" in r["Kernel_Name"]:
+            launches.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+json.dump({"mega_launches_us": launches, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps $K --warmup $W --repeats 1 --no-cpu-baseline --no-elbo-check",
            "steps_per_launch": $K, "steps_in_all_launches": $K + $W,
            "note": "vjf_mega_kernel: the warm-up steps ($W, in two launches) and ONE launch of the $K timed steps (= MaxNs); AverageNs is over all three launches, TotalDurationNs / ($K + $W) is the time per step",
            "bench_line": json.load(open("$O/${TAG}_stats.json"))}, open("$O/${TAG}_kernel_stats_meta.json", "w"), indent=1)
