@@ -651,7 +651,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                 return;
             }
             // (no acquire: the one thing read behind this wait is sigma, with an sc1 load)
-            if (!vjf_wg_wait_sc1(A.wait_count, it_wait_target, tid, SC + VJF_SC_STATUS)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
+            if (!vjf_wg_wait_sc1(A.wait_count, it_wait_target, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
             sig = __hip_atomic_load(S + P.off[VJF_SLOT_TR_LOGVAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto g4 = [&](int gi, int gj) {                                 // 4 entries of G, zero outside the matrix

@@ -512,7 +512,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     }
                     const bool rls = !rls_in && (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
                     const unsigned mw = __hip_atomic_load(cnt + MG_C_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!tl) {                                                 // (parameters read from the state with plain loads)
+                    if (!tl || (A.flags & VJF_FLAG_HANDOFF_ACQUIRE)) {         // (parameters read from the state with plain loads; or the conservative hand-off)
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
@@ -604,6 +604,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 if (t > 0) {
                     if (tid == 0) {
                         const bool there = (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
+                        if (there && (A.flags & VJF_FLAG_HANDOFF_ACQUIRE)) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                         s_try[0] = there ? 1u : 0u;
                     }
                     __syncthreads(); MG_PHASE();
@@ -636,7 +637,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 rls_in = true;
             }
             if (first && tl && !replay && t == 0) {                            // (the image of this launch: the SGD role's first act)
-                if (!vjf_wg_wait_sc1(cnt + MG_C_IMG, (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS))
+                if (!vjf_wg_wait_sc1(cnt + MG_C_IMG, (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
                 if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
             }
@@ -800,7 +801,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (last) { VJF_MG_STAMPX(28, -1); VJF_MG_STAMPW(1); }
             // ---- the RLS update of the previous step, if it had not landed before the forward pass
             if (first && !rls_in) {
-                if (!vjf_wg_wait_sc1(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS))
+                if (!vjf_wg_wait_sc1(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
                 if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
                 mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
@@ -1055,7 +1056,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         if (replay) {
             // the SGD role's step on the replayed late slabs; then this step starts over (inputs, features, parameters)
             ++nredo;
-            if (!(tl ? vjf_wg_wait_sc1(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS)
+            if (!(tl ? vjf_wg_wait_sc1(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u)
                      : vjf_wg_wait(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS)))
                 vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
             if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
@@ -1111,10 +1112,10 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         const float* eps_s = A.eps + (size_t)e * 2 * sz;
         const float* u_e = A.u ? A.u + (size_t)e * su : nullptr;
         // (the posterior of step e - 1: write-through stores of the trial role, in memory before its early slab's signal)
-        if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)e * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS))
+        if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)e * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         // (the slab of the previous event: every Gram workgroup has summed its share)
-        if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)e * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS))
+        if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)e * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
         { const int wg = hg, t = e; VJF_MG_STAMP(11); }
@@ -1210,7 +1211,7 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         }
         vjf_wg_signal_wt(A.cnt + MG_C_GRAM, tid);
         { const int wg = hg, t = e; VJF_MG_STAMP(12); }
-        if (!vjf_wg_wait_sc1(A.cnt + MG_C_GRAM, (unsigned)(e + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS))
+        if (!vjf_wg_wait_sc1(A.cnt + MG_C_GRAM, (unsigned)(e + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
         // this workgroup's share of the sum over the slabs: a quad of elements per 4 lanes, lane p sums the slabs [p npq, (p+1) npq)
@@ -1291,10 +1292,10 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
     const __amdgpu_buffer_rsrc_t r_early = mg_rsrc(A.slab_early);
     for (int t = 0; t < A.T; ++t) {
         float* red = (t & 1) ? A.red1 : A.red0;
-        bool ok = vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS);
-        ok = vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)(t + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS) && ok;
-        if (t > 0) ok = vjf_wg_wait_sc1(A.cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS) && ok;
-        ok = vjf_wg_wait_sc1(runw, (unsigned)(t + 1), tid, SCW + VJF_SC_STATUS) && ok;      // the Cholesky loop holds its operands (it reads the state's P at step 0)
+        bool ok = vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u);
+        ok = vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)(t + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) && ok;
+        if (t > 0) ok = vjf_wg_wait_sc1(A.cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) && ok;
+        ok = vjf_wg_wait_sc1(runw, (unsigned)(t + 1), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) && ok;      // the Cholesky loop holds its operands (it reads the state's P at step 0)
         if (!ok) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_OPERAND);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
         { const int wg = pw; VJF_MG_STAMP(14); }
@@ -1467,11 +1468,11 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
       // the parameters alone and publishes which components the trial role is to drop; pass 1 steps on its replayed late slabs
       for (int pass = 0; pass < 2; ++pass) {
         if (pass == 0) {
-            if (!vjf_wg_wait_sc1(A.cnt + MG_C_BWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
+            if (!vjf_wg_wait_sc1(A.cnt + MG_C_BWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                 vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
         } else {
             ++nredo;
-            if (!vjf_wg_wait_sc1(A.cnt + MG_C_REDO_B, nredo * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
+            if (!vjf_wg_wait_sc1(A.cnt + MG_C_REDO_B, nredo * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                 vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
             grad_ok = true;
         }

@@ -53,6 +53,7 @@ struct VjfPostArgs {
                             //    knowing whether the factorisation would succeed: on failure the y / W workgroup takes it back
     int fold_sigma;         // 1: the y / W workgroup goes on to the state-noise update (no vjf_resid / vjf_sigma launch)
     unsigned long long* stamps;   // diagnostic only (null in normal runs): s_memrealtime of the y / W workgroup, slots 16..21
+    int acquire;                  // 1: every wait acquires at agent scope as well (the one-launch route's default)
     unsigned long long* sig_word; // non-null: the new sigma also goes out as ONE 8-byte word {epoch, bits of sigma} for the Cholesky loop
                                   //   of the next step (it then needs neither this workgroup's exit count nor a second load)
 };
@@ -111,7 +112,7 @@ __device__ __forceinline__ float post_ld(const float* p) { return __hip_atomic_l
 
 // Wait (one lane polls, relaxed, bounded) until the Cholesky kernel has published flag word `k` for this epoch; the workgroup
 // barrier; then the sc1 loads of the column (see above).  Returns 0 = there, 1 = the factorisation failed, 2 = timed out.
-__device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned epoch, int k, int* s_ctl, int tid, const float* status) {
+__device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned epoch, int k, int* s_ctl, int tid, const float* status, bool fence = false) {
     if (tid == 0) {
         int st = 2;
         for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
@@ -120,6 +121,7 @@ __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned 
             if ((spins & 255u) == 255u && vjf_abort_seen(status)) break;
             __builtin_amdgcn_s_sleep(4);
         }
+        if (fence) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         s_ctl[0] = st;
     }
     __syncthreads();
@@ -133,7 +135,8 @@ __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned 
 // s_ctl[0] = 1 if a column reports a failed pivot, s_ctl[1] = the last column found published (from - 1: none new), s_ctl[2] =
 // g is there.  With wait_first the first flag is waited for as post_wait_column does (returns its codes in s_ctl[0]).
 __device__ __forceinline__ void post_peek_columns(const unsigned* flags, unsigned epoch, int from, int kmax, bool wait_first,
-                                                  const unsigned* prep_count, unsigned prep_target, int* s_ctl, int tid, const float* status) {
+                                                  const unsigned* prep_count, unsigned prep_target, int* s_ctl, int tid, const float* status,
+                                                  bool fence = false) {
     if (tid == 0) {
         int st = 0, kr = from - 1;
         if (wait_first) {
@@ -155,6 +158,7 @@ __device__ __forceinline__ void post_peek_columns(const unsigned* flags, unsigne
             }
         const int g = prep_count ? ((int)(__hip_atomic_load(prep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - prep_target) >= 0 ? 1 : 0) : 1;
         if (kr < from && !g) __builtin_amdgcn_s_sleep(8);
+        else if (fence) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         s_ctl[0] = st; s_ctl[1] = kr; s_ctl[2] = g;
     }
     __syncthreads();
@@ -285,12 +289,12 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
     int staged = j0;                                           // (y / W workgroup) columns < staged are in LDS
     for (int k = j0; k < nbl; ++k) {
         if (!solve) {
-            bad = post_wait_column(A.flags, it_epoch, k, s_ctl, tid, A.status);
+            bad = post_wait_column(A.flags, it_epoch, k, s_ctl, tid, A.status, A.acquire != 0);
             if (bad) break;
             stage_column(k);
         } else {
             if (k >= staged) {                                 // wait for column k, take whatever else is there with it
-                post_peek_columns(A.flags, it_epoch, k, nbl - 1, true, nullptr, 0u, s_ctl, tid, A.status);
+                post_peek_columns(A.flags, it_epoch, k, nbl - 1, true, nullptr, 0u, s_ctl, tid, A.status, A.acquire != 0);
                 bad = s_ctl[0];
                 const int kr = s_ctl[1];
                 __syncthreads();                               // (s_ctl is reused)
@@ -305,7 +309,7 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
                 if (!g_there && A.fold_sigma) { prefetch_G(); g_pre = true; }
                 if (!g_there) {
                     for (unsigned spins = 0;; ++spins) {
-                        post_peek_columns(A.flags, it_epoch, staged, nbl - 1, false, A.prep_count, it_prep_target, s_ctl, tid, A.status);
+                        post_peek_columns(A.flags, it_epoch, staged, nbl - 1, false, A.prep_count, it_prep_target, s_ctl, tid, A.status, A.acquire != 0);
                         const int st = s_ctl[0], kr = s_ctl[1], g = s_ctl[2];
                         __syncthreads();
                         if (st) { bad = st; break; }
