@@ -1112,10 +1112,10 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         const float* eps_s = A.eps + (size_t)e * 2 * sz;
         const float* u_e = A.u ? A.u + (size_t)e * su : nullptr;
         // (the posterior of step e - 1: write-through stores of the trial role, in memory before its early slab's signal)
-        if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)e * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+        // (the slab of the previous event: every Gram workgroup has summed its share -- nothing is read behind this one: no acquire)
+        if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)e * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
-        // (the slab of the previous event: every Gram workgroup has summed its share)
-        if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)e * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+        if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)e * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
         { const int wg = hg, t = e; VJF_MG_STAMP(11); }
@@ -1292,9 +1292,10 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
     const __amdgpu_buffer_rsrc_t r_early = mg_rsrc(A.slab_early);
     for (int t = 0; t < A.T; ++t) {
         float* red = (t & 1) ? A.red1 : A.red0;
-        bool ok = vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u);
-        ok = vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)(t + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) && ok;
-        if (t > 0) ok = vjf_wg_wait_sc1(A.cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) && ok;
+        // (four counts, ONE acquire: behind the last of them)
+        bool ok = vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS);
+        ok = vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)(t + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS) && ok;
+        if (t > 0) ok = vjf_wg_wait_sc1(A.cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS) && ok;
         ok = vjf_wg_wait_sc1(runw, (unsigned)(t + 1), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) && ok;      // the Cholesky loop holds its operands (it reads the state's P at step 0)
         if (!ok) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_OPERAND);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
