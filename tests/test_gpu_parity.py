@@ -645,3 +645,25 @@ def test_fit_harness_golden(vjf):
         close(yf, z["fc_y"], rtol=1e-3, atol=1e-3)
     finally:
         torch.set_default_dtype(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [1, 0, 3], ids=["one_launch", "one_stream", "three_streams"])
+def test_results_do_not_depend_on_workspace_contents(vjf, monkeypatch, overlap):
+    """The caller's workspace arrives uninitialised (torch.empty).  A workspace of NaNs (every byte 0xFF, also in every counter
+    word) must give the bits a workspace of zeros gives: nothing is read before the library has written it."""
+    g = torch.Generator().manual_seed(77)
+    T, B = 4, 100
+    y, u, eps = torch.randn(T, B, 10, generator=g), torch.randn(T, B, 2, generator=g), torch.randn(T, 2, B, 3, generator=g)
+    outs = []
+    for pattern in ("0x00", "0xFF"):
+        monkeypatch.setenv("VJF_DEBUG_POISON_WS", pattern)
+        torch.manual_seed(8)
+        m = vjf.VJF.make_model(10, 3, 2, 20, [16], likelihood="gaussian", lr=1e-2)
+        m.set_overlap(overlap)
+        mu, lv, ls = m.filter_sequence(y.cuda(), u.cuda(), None, eps=eps.cuda())
+        assert m.check_status() == 0
+        outs.append((mu.cpu().numpy(), ls.cpu().numpy(), m._blob.cpu().numpy().copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)

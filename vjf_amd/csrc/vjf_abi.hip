@@ -217,7 +217,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.red = take((size_t)P.red_len * 4);
     c.red2 = take((size_t)P.red_len * 4);                  // RLS statistics of even / odd steps in the multi-stream sequence
     c.red3 = take((size_t)P.red_len * 4);
-    c.tbig = take(P.n > 32 * VJF_CHOL_MAXBLK ? (size_t)P.n * P.n * 4 : 16);   // multi-launch RLS: T of the recursive inverse
+    c.tbig = take(P.n > 32 * VJF_CHOL_MAXBLK ? (size_t)((P.n + 31) / 32) * 1024 * 4 * 3 : 16);   // multi-launch RLS: the diagonal blocks of L, two sets of column sums
     // GEMM-per-layer trial path (working set beyond LDS): [xs|u], pt.mean, pt.logvar, decoder output, Phi w_chol per trial
     c.wide = take(vjf_trial_mfma_lds_floats(P) * 4 > kMaxLds - 1024 ? (size_t)max_batch * (P.dxu + P.dz + 1 + P.dy + P.n) * 4 + 1024 : 16);
     c.work = take(vjf_serial_work_floats(P) * 4 + 10 * 256);  // + 10 x 32 u64 diagnostic stamps (a ring over the steps of a sequence)
@@ -601,18 +601,26 @@ VjfTrialArgs trial_args(vjf_ctx* c, int32_t B, const float* y, const float* u, c
 
 int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16 : (B + 3) / 4; }   // (wide path: 4 trials per loss workgroup)
 
-// one GEMM of the wide routes: 128 x 128 or 128 x 64 tiles when the shape fills the chip with them and the operands can be
-// read 16 bytes at a time, else the 64 x 64 kernel
+// one GEMM of the wide routes: a narrow output (N <= 64) splits K over the wavefronts of 32-row workgroups; else 128 x 128 or
+// 128 x 64 tiles when the shape fills the chip with them, else the 64 x 64 kernel
 void launch_wide_gemm(const VjfWideGemm& g0, hipStream_t st) {
     VjfWideGemm g = g0;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
-    g.va = (g.lda % 4 == 0) && al16(g.A);
-    g.vb = (g.ldb % 4 == 0) && al16(g.Bm);
+    // 16-byte loads: aligned rows whose extent along the contiguous direction is a multiple of 4
+    g.va = (g.lda % 4 == 0) && al16(g.A) && ((g.ta ? g.M : g.K) % 4 == 0);
+    g.vb = (g.ldb % 4 == 0) && al16(g.Bm) && ((g.nt ? g.K : g.N) % 4 == 0);
     const int tm = (g.M + 127) / 128;
-    if (g.M >= 256 && g.N >= 256 && tm * ((g.N + 127) / 128) >= 192)
-        hipLaunchKernelGGL(vjf_wide_gemm2_kernel<128>, dim3((g.N + 127) / 128, tm), dim3(256), 0, st, g);
-    else if (g.M >= 256 && g.N >= 64 && tm * ((g.N + 63) / 64) >= 32)
-        hipLaunchKernelGGL(vjf_wide_gemm2_kernel<64>, dim3((g.N + 63) / 64, tm), dim3(256), 0, st, g);
+    if (g.N <= 64)
+        hipLaunchKernelGGL(vjf_skinny_gemm_kernel<8>, dim3((g.M + 31) / 32, (g.N + 31) / 32), dim3(512), 0, st, g);
+    else if (!g.ta && g.va && g.vb && g.M >= 256 && g.N >= 256 && tm * ((g.N + 127) / 128) >= 192) {
+        const dim3 grid((g.N + 127) / 128, tm);
+        if (g.nt) hipLaunchKernelGGL((vjf_wide_gemm3_kernel<128, 16, 4, false, true>), grid, dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((vjf_wide_gemm3_kernel<128, 16, 4, false, false>), grid, dim3(512), 0, st, g);
+    } else if (!g.ta && g.va && g.vb && g.M >= 256 && g.N >= 64 && tm * ((g.N + 63) / 64) >= 32) {
+        const dim3 grid((g.N + 63) / 64, tm);
+        if (g.nt) hipLaunchKernelGGL((vjf_wide_gemm3_kernel<64, 32, 4, false, true>), grid, dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((vjf_wide_gemm3_kernel<64, 32, 4, false, false>), grid, dim3(512), 0, st, g);
+    }
     else
         hipLaunchKernelGGL(vjf_wide_gemm_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
 }
@@ -1012,6 +1020,8 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
         a.state = c->state; a.red = red; a.Lw = (float*)(c->ws + c->cv.lscr);
         a.X = work; a.gbuf = work + (size_t)P.n * P.n; a.ybuf = a.gbuf + (size_t)P.n * P.dz;
         a.Dinv = (float*)(c->ws + c->cv.post);
+        a.Ld = (float*)(c->ws + c->cv.tbig);
+        a.Pacc = a.Ld + (size_t)nbl * 1024;
         a.ok = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
         const bool rls = !(flags & VJF_FLAG_WARM_UP);
         if (rls) {
@@ -1025,25 +1035,13 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
             const float* Sx = c->state;
             gemm(Sx + P.off[VJF_SLOT_W_PREC], P.n, 0, Sx + P.off[VJF_SLOT_W_MEAN], P.dz, a.gbuf, P.dz, P.n, P.dz, P.n, nullptr);   // P W
             hipLaunchKernelGGL(vjf_rlsb_prep_kernel, dim3(gx), dim3(256), 0, st, P, a);
-            for (int k = 0; k < nbl; ++k) {
+            // block column k of L and block row k - 1 of X = L^-1 per launch (the block-upper part of X stays zero: the solves
+            // below read all of it)
+            VJF_HIP(hipMemsetAsync(a.X, 0, (size_t)P.n * P.n * 4, st));
+            for (int k = 0; k <= nbl; ++k) {
                 a.k = k;
-                hipLaunchKernelGGL(vjf_rlsb_diag_kernel, dim3(1), dim3(64), 0, st, P, a);
-                const int m = nbl - 1 - k;
-                if (m > 0) {
-                    hipLaunchKernelGGL(vjf_rlsb_panel_kernel, dim3(m), dim3(64), 0, st, P, a);
-                    hipLaunchKernelGGL(vjf_rlsb_trail_kernel, dim3(m * (m + 1) / 2), dim3(64), 0, st, P, a);
-                }
-            }
-            {   // X = L^-1 by recursive doubling over the inverted diagonal blocks (block-upper part: zero)
-                float* T = (float*)(c->ws + c->cv.tbig);
-                VJF_HIP(hipMemsetAsync(a.X, 0, (size_t)P.n * P.n * 4, st));
-                hipLaunchKernelGGL(vjf_rlsb_inv_diag_kernel, dim3(64), dim3(256), 0, st, P, a);
-                for (int sb = 1; sb < nbl; sb *= 2) {
-                    const int pairs = (nbl + 2 * sb - 1) / (2 * sb);
-                    VjfRlsbLevel lv{sb};
-                    hipLaunchKernelGGL(vjf_rlsb_inv_t_kernel, dim3(pairs * sb * sb), dim3(64), 0, st, P, a, lv, T);
-                    hipLaunchKernelGGL(vjf_rlsb_inv_x_kernel, dim3(pairs * sb * sb), dim3(64), 0, st, P, a, lv, (const float*)T);
-                }
+                const int ncol = nbl - k, grid = ncol + (ncol > 1 ? ncol - 1 : 0) + (k > 1 ? k - 1 : 0);
+                hipLaunchKernelGGL(vjf_rlsc_col_kernel, dim3(grid), dim3(VJF_RLSC_THREADS), 0, st, P, a);
             }
             gemm(a.X, P.n, 0, a.gbuf, P.dz, a.ybuf, P.dz, P.n, P.dz, P.n, a.ok);                                      // y = X g
             gemm(a.X, P.n, 1, a.ybuf, P.dz, c->state + P.off[VJF_SLOT_W_MEAN], P.dz, P.n, P.dz, P.n, a.ok);          // W = X^T y
@@ -1053,7 +1051,13 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
         VjfResidArgs ra{};
         ra.state = c->state; ra.red = red; ra.partial = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
         ra.B_total = B_total; ra.flags = flags;
-        hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra);
+        {   // state-noise update (model.py:373-377): T = G W with the GEMM kernel (y's buffer is free again), contraction in fp64
+            VjfWideGemm g{};
+            g.A = red + P.red_G; g.lda = P.n; g.Bm = c->state + P.off[VJF_SLOT_W_MEAN]; g.ldb = P.dz; g.C = a.ybuf; g.ldc = P.dz;
+            g.M = P.n; g.N = P.dz; g.K = P.n; g.epi = WEPI_NONE;
+            launch_wide_gemm(g, st);
+            hipLaunchKernelGGL(vjf_resid_dot_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra, (const float*)a.ybuf);
+        }
         hipLaunchKernelGGL(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, P, ra, (const int*)nullptr);
         VJF_HIP(hipGetLastError());
         return 0;

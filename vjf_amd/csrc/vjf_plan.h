@@ -108,14 +108,16 @@ static inline int vjf_make_plan(const vjf_config* c, VjfPlan* p) {
     // workspace matrices
     p->ldE = (int)vjf_align(p->n + p->dz, VJF_TILE);
     int col = 0;
-    p->colA_act[0] = col; col += p->din + 1;
-    for (int k = 0; k < p->L; ++k) { p->colA_act[k + 1] = col; col += p->h[k] + 1; }
+    // (every segment starts on a 16-byte boundary: the GEMMs of the wide route read them 16 bytes at a time; the padding
+    //  columns behind a segment's 1 are never read)
+    p->colA_act[0] = col; col = (int)vjf_align(col + p->din + 1, 4);
+    for (int k = 0; k < p->L; ++k) { p->colA_act[k + 1] = col; col = (int)vjf_align(col + p->h[k] + 1, 4); }
     p->colA_xt = col; col += p->dz + 1;
     p->ldA = (int)vjf_align(col, 4);
     col = 0;
-    for (int k = 0; k < p->L; ++k) { p->colD_da[k] = col; col += p->h[k]; }
-    p->colD_dmu = col; col += p->dz;
-    p->colD_dlv = col; col += p->dz;
+    for (int k = 0; k < p->L; ++k) { p->colD_da[k] = col; col = (int)vjf_align(col + p->h[k], 4); }
+    p->colD_dmu = col; col += p->dz;                       // (dlv follows dmu directly: the dxt epilogue writes both)
+    p->colD_dlv = col; col = (int)vjf_align(col + p->dz, 4);
     p->colD_dpy = col; col += p->dy;
     p->ldD = (int)vjf_align(col, 4);
     int64_t r = vjf_align(p->train_len, 4);            // (G is read as float4)

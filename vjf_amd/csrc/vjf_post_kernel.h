@@ -640,6 +640,22 @@ __global__ __launch_bounds__(256) void vjf_resid_kernel(VjfPlan P, VjfResidArgs 
     if (tid == 0) A.partial[blockIdx.x] = ((s_d[0] + s_d[1]) + s_d[2]) + s_d[3];
 }
 
+// the same partial sums from T = G W given as a matrix (the wide route forms it with its GEMM kernel): fp64 contraction only
+__global__ __launch_bounds__(256) void vjf_resid_dot_kernel(VjfPlan P, VjfResidArgs A, const float* T) {
+    __shared__ double s_d[4];
+    const int tid = threadIdx.x, tot = P.n * P.dz;
+    const float* W = A.state + P.off[VJF_SLOT_W_MEAN];
+    const float* FDX = A.red + P.red_FDX;
+    double part = 0.0;
+    for (int e = blockIdx.x * 256 + tid; e < tot; e += VJF_RESID_BLOCKS * 256)
+        part += (double)W[e] * ((double)T[e] - 2.0 * (double)FDX[e]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((tid & 63) == 0) s_d[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) A.partial[blockIdx.x] = ((s_d[0] + s_d[1]) + s_d[2]) + s_d[3];
+}
+
 __global__ __launch_bounds__(64) void vjf_sigma_kernel(VjfPlan P, VjfResidArgs A, const int* ok) {
     // one wavefront: lane b holds partial b (VJF_RESID_BLOCKS == 64), fixed-order xor tree
     double t = A.partial[threadIdx.x];

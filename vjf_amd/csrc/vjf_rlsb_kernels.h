@@ -1,15 +1,10 @@
 // vjf_rlsb_kernels.h -- the RLS update (module.py:79-112) for feature counts that do not fit one compute unit's LDS
-// (n_rbf > 224; BASELINE config E has 1000): the same right-looking blocked Cholesky, inverse and solves as the
-// LDS-resident kernels, but with the matrix in global memory (L2-resident: 4 MB at n = 1000) and one launch per phase,
-// so that the trailing updates and the block rows of the inverse spread over the whole chip.
+// (n_rbf > 224; BASELINE config E has 1000): a blocked Cholesky, inverse and solves on the matrix in global memory
+// (L2-resident: 4 MB at n = 1000), one launch per block column, the tiles of a column spread over the chip.
 //
 //   GEMM + vjf_rlsb_prep_kernel   g = P W + Phi^T dx / v (module.py:94);  A := P + Phi^T Phi / v into a work buffer (module.py:96)
-//   per block column k:     vjf_rlsb_diag_kernel   L_kk, L_kk^-1      (one wavefront: the rank-2 column chain)
-//                           vjf_rlsb_panel_kernel  L_ik = A_ik L_kk^-T (one wavefront per block)
-//                           vjf_rlsb_trail_kernel  A_ij -= L_ik L_jk^T (one wavefront per lower block)
-//   inverse X = L^-1 (module.py:102): vjf_rlsb_inv_diag_kernel (diagonal blocks), then per level of a binary recursion over the
-//                           block rows vjf_rlsb_inv_t_kernel / vjf_rlsb_inv_x_kernel (T = L_21 X_11, X_21 = -X_22 T)
-//   two GEMMs (vjf_wide_gemm_kernel)        y = X g,  W = X^T y                      (module.py:101)
+//   nbl + 1 launches of vjf_rlsc_col_kernel: block column k of L (module.py:99) and block row k - 1 of X = L^-1 (module.py:102)
+//   two GEMMs (vjf_skinny_gemm_kernel)      y = X g,  W = X^T y                      (module.py:101)
 //   vjf_rlsb_final_kernel   w_chol = X^T, w_pchol = L, P += Phi^T Phi / v -- or, after a failed pivot, nothing but the status
 // All block products on v_mfma_f32_32x32x2_f32 through the helpers of vjf_chol_kernel.h.  Matrices are padded to a
 // multiple of 32 with the identity on the fly (loads) and never stored outside n x n.
@@ -26,6 +21,9 @@ struct VjfRlsbArgs {
     float* gbuf;         // (n, dz)
     float* ybuf;         // (n, dz)
     float* Dinv;         // nbl blocks (32x32 row-major): inverted diagonal blocks of L
+    float* Ld;           // nbl blocks (32x32 row-major): the diagonal blocks of L (the diagonal tiles of Lw keep A_kk: every workgroup
+                         // of launch k reads that tile while one of them has the factor ready)
+    float* Pacc;         // 2 x nbl tiles (accumulator order): the sums the ahead role leaves for column k (set k & 1)
     int* ok;             // [0]: 1 while every pivot so far was positive
     int k;               // block column (factorisation) or block row (inverse) of this launch
 };
@@ -63,134 +61,206 @@ __global__ __launch_bounds__(256) void vjf_rlsb_prep_kernel(VjfPlan P, VjfRlsbAr
     for (int e = gid; e < n * n; e += gsz) Lm[e] = Pm[e] + G[e] * inv_v;
 }
 
-__global__ __launch_bounds__(64) void vjf_rlsb_diag_kernel(VjfPlan P, VjfRlsbArgs A) {
-    __shared__ __attribute__((aligned(16))) float s_d[1024], s_i[1024];
-    if (A.ok[0] == 0) return;
-    const int n = P.n, k = A.k, lane = threadIdx.x;
-    float* Lm = A.Lw;
-    rlsb_tile_in(s_d, Lm, n, k, k, lane);
-    const bool good = potrf_inv_chain2(s_d, s_i, lane);
-    if (!good) { if (lane == 0) A.ok[0] = 0; return; }
+// One block column of the factorisation and one block row of the inverse per launch (left-looking, so that a column needs ONE
+// launch instead of diagonal / panel / trailing-update launches, and the inverse rides along instead of following as a phase
+// of its own).  Launch k, workgroups of eight wavefronts, three roles:
+//   column role, block rows i = k .. nbl-1:  D = A_kk - sum_{j<k} L_kj L_kj^T  and  T = A_ik - sum_{j<k} L_ij L_kj^T, of which
+//       the terms j <= k-2 were summed by launch k-1 (ahead role) and only j = k-1 -- the column the previous launch produced --
+//       is formed here (one wavefront each); L_kk = chol(D) with its inverse (EVERY workgroup: the same bits, no hand-off);
+//       i = k: L_kk, L_kk^-1 -> Ld, Dinv, X_kk;   i > k: L_ik = T L_kk^-T -> Lw.
+//   ahead role, block rows i = k+1 .. nbl-1:  Pacc_{k+1}[i] = sum_{j<=k-1} L_ij L_{k+1,j}^T  for the NEXT column (columns <= k-1
+//       are complete when launch k starts): the j range split over the wavefronts, operands straight from global memory into
+//       the MFMA operand layout, partial tiles summed through LDS in a fixed order.  The bulk of the multiply-adds of a column
+//       thus runs beside the previous column's serial part (loads, 32x32 factorisation, solve) on other compute units.
+//   inverse role, block row r = k-1, tiles j = 0 .. r-1:  X_rj = -L_rr^-1 sum_{m=j}^{r-1} L_rm X_mj   (rows < r of X, row r of L
+//       and L_rr^-1 are all complete when launch k starts).
+// Launch nbl has the inverse role only (the last block row).
+// Operand layout: lane (row, half) of v_mfma_f32_32x32x2_f32 takes k = 8 q + 4 half + e at step (q, e) -- any order of the k
+// indices is a valid product as long as both operands use it -- so a k-contiguous operand row is four 16-byte loads.
+__device__ __forceinline__ void rlsc_ld_kc(float (&v)[16], const float* M, int n, int brow, int bcol, int lane, bool vec) {
+    const int row = brow * 32 + (lane & 31), c0 = bcol * 32 + 4 * (lane >> 5);
+    if (row < n) {
+        const float* p = M + (size_t)row * n + c0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = lane + 64 * q, r = e >> 5, c = e & 31;
-        const int gi = k * 32 + r, gj = k * 32 + c;
-        if (gi < n && gj < n) Lm[(size_t)gi * n + gj] = c <= r ? s_d[vsw(r, c)] : 0.f;
-        A.Dinv[(size_t)k * 1024 + e] = s_i[vsw(r, c)];
-    }
-}
-
-__global__ __launch_bounds__(64) void vjf_rlsb_panel_kernel(VjfPlan P, VjfRlsbArgs A) {
-    __shared__ __attribute__((aligned(16))) float s_a[1024], s_d[1024];
-    if (A.ok[0] == 0) return;
-    const int n = P.n, k = A.k, bi = k + 1 + (int)blockIdx.x, lane = threadIdx.x;
-    float* Lm = A.Lw;
+        for (int q = 0; q < 4; ++q) {
+            if (vec) { const float4 x = *reinterpret_cast<const float4*>(p + 8 * q); v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+            else {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = lane + 64 * q, r = e >> 5, c = e & 31;
-        const int gi = bi * 32 + r, gj = k * 32 + c;
-        s_a[vsw(r, c)] = (gi < n && gj < n) ? Lm[(size_t)gi * n + gj] : 0.f;
-        s_d[vsw(r, c)] = A.Dinv[(size_t)k * 1024 + e];
-    }
-    vjf_f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    blk_mma<true>(acc, s_a, s_d, 1.f, lane);                   // A_ik L_kk^-T
-    rlsb_acc_out(acc, Lm, n, bi, k, lane, false);
-}
-
-__global__ __launch_bounds__(64) void vjf_rlsb_trail_kernel(VjfPlan P, VjfRlsbArgs A) {
-    __shared__ __attribute__((aligned(16))) float s_a[1024], s_b[1024];
-    if (A.ok[0] == 0) return;
-    const int n = P.n, k = A.k, lane = threadIdx.x;
-    int ii = 0;
-    const int t = blockIdx.x;
-    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-    const int jj = t - ii * (ii + 1) / 2, bi = k + 1 + ii, bj = k + 1 + jj;
-    float* Lm = A.Lw;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = lane + 64 * q, r = e >> 5, c = e & 31;
-        const int gj = k * 32 + c;
-        s_a[vsw(r, c)] = (bi * 32 + r < n && gj < n) ? Lm[(size_t)(bi * 32 + r) * n + gj] : 0.f;
-        s_b[vsw(r, c)] = (bj * 32 + r < n && gj < n) ? Lm[(size_t)(bj * 32 + r) * n + gj] : 0.f;
-    }
-    vjf_f32x16 acc;
-    const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gi = bi * 32 + vrow(r, h), gj = bj * 32 + c;
-        acc[r] = (gi < n && gj < n) ? Lm[(size_t)gi * n + gj] : (gi == gj ? 1.f : 0.f);
-    }
-    blk_mma<true>(acc, s_a, s_b, -1.f, lane);                  // A_ij -= L_ik L_jk^T
-    rlsb_acc_out(acc, Lm, n, bi, bj, lane, false);
-}
-
-
-// X = L^-1 by recursive doubling instead of block row after block row (nbl dependent launches with up to nbl - 1 chained
-// block products each): with the diagonal blocks inverted, level l joins pairs of 2^l-tile diagonal blocks,
-//     inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]],
-// as two launches of independent tiles:  T = C A^-1  (vjf_rlsb_inv_t_kernel),  X21 = -B^-1 T  (vjf_rlsb_inv_x_kernel).
-// 2 log2(nbl) launches, every tile of a level in parallel.  Tiles of `half` x `half` 32-blocks; workgroup = one output tile.
-struct VjfRlsbLevel { int sb; };      // tiles per half at this level (1, 2, 4, ..)
-__device__ __forceinline__ bool rlsb_level_tile(int nbl, int sb, int t, int& bi, int& bj, int& s0) {
-    // output tiles of a level: for every pair starting at s0 = 2 sb p: rows [s0 + sb, min(s0 + 2 sb, nbl)), columns [s0, s0 + sb)
-    const int per = sb * sb, p = t / per, r = t - p * per;
-    s0 = 2 * sb * p;
-    bi = s0 + sb + r / sb;
-    bj = s0 + r % sb;
-    return bi < nbl;
-}
-__global__ __launch_bounds__(64) void vjf_rlsb_inv_t_kernel(VjfPlan P, VjfRlsbArgs A, VjfRlsbLevel Lv, float* T) {
-    __shared__ __attribute__((aligned(16))) float s_l[1024], s_x[1024];
-    if (A.ok[0] == 0) return;
-    const int n = P.n, nbl = (n + 31) / 32, lane = threadIdx.x;
-    int bi, bj, s0;
-    if (!rlsb_level_tile(nbl, Lv.sb, blockIdx.x, bi, bj, s0)) return;
-    vjf_f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k = bj; k < s0 + Lv.sb; ++k) {                     // T_ij = sum_k L_ik X_kj, X11 block-lower: k >= bj
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = lane + 64 * q, r = e >> 5, c = e & 31;
-            const int li = bi * 32 + r, lj = k * 32 + c, xi = k * 32 + r, xj = bj * 32 + c;
-            s_l[vsw(r, c)] = (li < n && lj < n) ? A.Lw[(size_t)li * n + lj] : 0.f;
-            s_x[vsw(r, c)] = (xi < n && xj < n) ? A.X[(size_t)xi * n + xj] : 0.f;
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = p[8 * q + e];
+            }
         }
-        blk_mma<false>(acc, s_l, s_x, 1.f, lane);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = 0.f;
     }
-    rlsb_acc_out(acc, T, n, bi, bj, lane, false);
 }
-__global__ __launch_bounds__(64) void vjf_rlsb_inv_x_kernel(VjfPlan P, VjfRlsbArgs A, VjfRlsbLevel Lv, const float* T) {
-    __shared__ __attribute__((aligned(16))) float s_l[1024], s_x[1024];
+// B operand from a row-major (k, column) tile: lane (column, half), same k order
+__device__ __forceinline__ void rlsc_ld_rc(float (&v)[16], const float* M, int n, int brow, int bcol, int lane) {
+    const float* p = M + (size_t)(brow * 32 + 4 * (lane >> 5)) * n + bcol * 32 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = p[(size_t)(8 * q + e) * n];
+}
+
+#define VJF_RLSC_THREADS 512
+__global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_col_kernel(VjfPlan P, VjfRlsbArgs A) {
+    __shared__ __attribute__((aligned(16))) float s_p[4][2][1024];
+    __shared__ __attribute__((aligned(16))) float s_d[1024], s_i[1024], s_t[1024];
+    __shared__ int s_good;
     if (A.ok[0] == 0) return;
-    const int n = P.n, nbl = (n + 31) / 32, lane = threadIdx.x;
-    int bi, bj, s0;
-    if (!rlsb_level_tile(nbl, Lv.sb, blockIdx.x, bi, bj, s0)) return;
-    vjf_f32x16 acc;
+    const int n = P.n, nbl = (n + 31) / 32, k = A.k, ncol = nbl - k, nahead = ncol > 1 ? ncol - 1 : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool vec = (n & 3) == 0;
+    float* Lm = A.Lw;
+    vjf_f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k = s0 + Lv.sb; k <= bi; ++k) {                    // X_ij = - sum_k X22_ik T_kj, X22 block-lower: k <= bi
+    for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
+    // the eight wavefronts' partial tiles -> s_p[0..3] (wavefront w + 4 onto w, through LDS), fixed order
+    auto fold = [&](bool second) {
+        if (wave >= 4) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = lane + 64 * q, r = e >> 5, c = e & 31;
-            const int xi = bi * 32 + r, xj = k * 32 + c, ti = k * 32 + r, tj = bj * 32 + c;
-            s_l[vsw(r, c)] = (xi < n && xj < n) ? A.X[(size_t)xi * n + xj] : 0.f;
-            s_x[vsw(r, c)] = (ti < n && tj < n) ? T[(size_t)ti * n + tj] : 0.f;
+            for (int q = 0; q < 16; ++q) { s_p[wave - 4][0][q * 64 + lane] = acc0[q]; if (second) s_p[wave - 4][1][q * 64 + lane] = acc1[q]; }
         }
-        blk_mma<false>(acc, s_l, s_x, -1.f, lane);
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                s_p[wave][0][q * 64 + lane] += acc0[q];
+                if (second) s_p[wave][1][q * 64 + lane] += acc1[q];
+            }
+        }
+        __syncthreads();
+    };
+    if ((int)blockIdx.x < ncol) {
+        const int i = k + (int)blockIdx.x;
+        const bool below = i != k;
+        // the tiles the sums are taken from and the sums launch k - 1 left (this thread's two elements of each), and the operands
+        // of the one term formed here, all requested before anything waits
+        float dkk[2], aik[2], pkk[2] = {0.f, 0.f}, pik[2] = {0.f, 0.f};
+        const float* pc = A.Pacc + (size_t)(k & 1) * nbl * 1024;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 512 * q, row = vrow(e >> 6, (e >> 5) & 1), col = e & 31;
+            const int gk = k * 32 + row, gi = i * 32 + row, gj = k * 32 + col;
+            dkk[q] = (gk < n && gj < n) ? Lm[(size_t)gk * n + gj] : (gk == gj ? 1.f : 0.f);
+            aik[q] = (below && gi < n && gj < n) ? Lm[(size_t)gi * n + gj] : 0.f;
+            if (k > 0) { pkk[q] = pc[(size_t)k * 1024 + e]; if (below) pik[q] = pc[(size_t)i * 1024 + e]; }
+        }
+        if (k > 0 && wave < 2) {                            // wavefront 0: L_k,k-1 L_k,k-1^T; wavefront 1: L_i,k-1 L_k,k-1^T
+            float lk[16], li[16];
+            rlsc_ld_kc(lk, Lm, n, k, k - 1, lane, vec);
+            if (wave == 1 && below) rlsc_ld_kc(li, Lm, n, i, k - 1, lane, vec);
+            if (wave == 0) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lk[t], lk[t], acc0, 0, 0, 0);
+            } else if (below) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(li[t], lk[t], acc0, 0, 0, 0);
+            }
+        }
+        if (wave < 2) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s_p[wave][0][q * 64 + lane] = acc0[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 512 * q, row = vrow(e >> 6, (e >> 5) & 1), col = e & 31;
+            s_d[vsw(row, col)] = dkk[q] - (pkk[q] + s_p[0][0][e]);
+            if (below) s_t[vsw(row, col)] = aik[q] - (pik[q] + s_p[1][0][e]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const bool good = potrf_inv_chain2(s_d, s_i, lane);
+            if (lane == 0) s_good = good ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_good) { if (!below && tid == 0) A.ok[0] = 0; return; }
+        if (!below) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + 512 * q, r = e >> 5, c = e & 31;
+                const int gi = k * 32 + r, gj = k * 32 + c;
+                const float x = s_i[vsw(r, c)];
+                if (gi < n && gj < n) A.X[(size_t)gi * n + gj] = x;
+                A.Dinv[(size_t)k * 1024 + e] = x;
+                A.Ld[(size_t)k * 1024 + e] = c <= r ? s_d[vsw(r, c)] : 0.f;
+            }
+        } else if (wave == 0) {
+            vjf_f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            blk_mma<true>(acc, s_t, s_i, 1.f, lane);               // T L_kk^-T
+            rlsb_acc_out(acc, Lm, n, i, k, lane, false);
+        }
+        return;
     }
-    rlsb_acc_out(acc, A.X, n, bi, bj, lane, false);
-}
-// X_ii = L_ii^-1 for every diagonal block (the base of the recursion)
-__global__ __launch_bounds__(256) void vjf_rlsb_inv_diag_kernel(VjfPlan P, VjfRlsbArgs A) {
-    if (A.ok[0] == 0) return;
-    const int n = P.n, nbl = (n + 31) / 32;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < nbl * 1024; e += gridDim.x * 256) {
-        const int b = e >> 10, r = (e >> 5) & 31, c = e & 31;
-        const int gi = b * 32 + r, gj = b * 32 + c;
-        if (gi < n && gj < n) A.X[(size_t)gi * n + gj] = A.Dinv[e];
+    if ((int)blockIdx.x < ncol + nahead) {
+        // ahead role: the sums over the finished columns j <= k - 1 for column k + 1, rows i >= k + 1
+        const int c1 = k + 1, i = c1 + ((int)blockIdx.x - ncol);
+        // block columns j = wave, wave + 8, ..: the tiles come from other compute units' launches (memory-side latency), so the
+        // operands of FOUR block columns are requested before the first MFMA
+        for (int jb = wave; jb < k; jb += 32) {
+            float lk[4][16], li[4][16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (jb + 8 * u < k) {
+                    rlsc_ld_kc(lk[u], Lm, n, c1, jb + 8 * u, lane, vec);
+                    rlsc_ld_kc(li[u], Lm, n, i, jb + 8 * u, lane, vec);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (jb + 8 * u < k) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(li[u][t], lk[u][t], acc0, 0, 0, 0);
+                }
+        }
+        fold(false);
+        float* pn = A.Pacc + ((size_t)(c1 & 1) * nbl + i) * 1024;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 512 * q;
+            pn[e] = ((s_p[0][0][e] + s_p[1][0][e]) + s_p[2][0][e]) + s_p[3][0][e];
+        }
+        return;
+    }
+    // inverse role
+    const int r = k - 1, j = (int)blockIdx.x - ncol - nahead;
+    if (r < 1 || j >= r) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + 512 * q;
+        s_i[vsw(e >> 5, e & 31)] = A.Dinv[(size_t)r * 1024 + e];
+    }
+    for (int mb = j + wave; mb < r; mb += 32) {
+        float a[4][16], b[4][16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (mb + 8 * u < r) {
+                rlsc_ld_kc(a[u], Lm, n, r, mb + 8 * u, lane, vec);
+                rlsc_ld_rc(b[u], A.X, n, mb + 8 * u, j, lane);
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (mb + 8 * u < r) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u][t], acc0, 0, 0, 0);
+            }
+    }
+    fold(false);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + 512 * q, row = vrow(e >> 6, (e >> 5) & 1), col = e & 31;
+        s_t[vsw(row, col)] = ((s_p[0][0][e] + s_p[1][0][e]) + s_p[2][0][e]) + s_p[3][0][e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        vjf_f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        blk_mma<false>(acc, s_i, s_t, -1.f, lane);                 // -L_rr^-1 S
+        rlsb_acc_out(acc, A.X, n, r, j, lane, false);
     }
 }
 
@@ -213,7 +283,8 @@ __global__ __launch_bounds__(256) void vjf_rlsb_final_kernel(VjfPlan P, VjfRlsbA
     for (int e = gid; e < n * n; e += gsz) {
         const int i = e / n, j = e - i * n;
         Wc[e] = (j >> 5) >= (i >> 5) ? A.X[(size_t)j * n + i] : 0.f;
-        Lm[e] = (j >> 5) > (i >> 5) ? 0.f : A.Lw[e];             // w_pchol = L (module.py:99-100)
+        const int bi = i >> 5, bj = j >> 5;                        // w_pchol = L (module.py:99-100)
+        Lm[e] = bj > bi ? 0.f : bj == bi ? A.Ld[(size_t)bi * 1024 + (i & 31) * 32 + (j & 31)] : A.Lw[e];
         Pm[e] += G[e] * inv_v;
     }
 }

@@ -521,8 +521,11 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             for (int j = lane; P.colA_xt + j < P.ldA; j += 64) arow[P.colA_xt + j] = j < dz ? s_xt[j * LD + b] : (j == dz ? 1.f : 0.f);
         }
         if (!bwd) continue;
-        float* drow = A.DEL + (size_t)(b0 + b) * P.ldD + P.colD_dmu;
-        for (int c = lane; c < 2 * dz + dy; c += 64) drow[c] = c < 2 * dz ? s_dmu[c * LD + b] : s_dpy[(c - 2 * dz) * LD + b];   // s_dlv follows s_dmu
+        float* drow = A.DEL + (size_t)(b0 + b) * P.ldD;
+        for (int c = lane; c < 2 * dz + dy; c += 64) {                      // (dlv follows dmu in DEL as s_dlv follows s_dmu)
+            if (c < 2 * dz) drow[P.colD_dmu + c] = s_dmu[c * LD + b];
+            else drow[P.colD_dpy + c - 2 * dz] = s_dpy[(c - 2 * dz) * LD + b];
+        }
     }
     VJF_K1_STAMP(30);
     if (AA.stamps && tid == 0) {

@@ -29,6 +29,26 @@ struct VjfWideGemm {
     int va, vb;                    // vjf_wide_gemm2_kernel: A / B can be read 16 bytes at a time (set by the launcher)
 };
 
+// the fused epilogues of the wide GEMM kernels: C[m][n] <- f(v)
+__device__ __forceinline__ void vjf_wide_epilogue(const VjfWideGemm& g, int m, int n, float v) {
+    float* c = g.C + (size_t)m * g.ldc + n;
+    switch (g.epi) {
+        case WEPI_BIAS: v += g.bias[n]; break;
+        case WEPI_TANH_BIAS: v = tanhf(v + g.bias[n]); break;
+        case WEPI_ADD_SRC: v = fmaf(g.src_scale, g.src[(size_t)m * g.lds + n], v); break;
+        case WEPI_DTANH: { const float hv = g.src[(size_t)m * g.lds + n]; v *= (1.f - hv * hv); break; }
+        case WEPI_ADDC_DTANH: { const float hv = g.src[(size_t)m * g.lds + n]; v = (*c + v) * (1.f - hv * hv); break; }
+        case WEPI_SEED: {
+            const float e = g.eps_t[(size_t)m * g.N + n], lv = g.lv_t[(size_t)m * g.N + n];
+            c[g.N] = fmaf(v * e, 0.5f * expf(0.5f * lv), c[g.N]);            // dlv
+            v += *c;                                                         // dmu
+            break;
+        }
+        default: break;
+    }
+    *c = v;
+}
+
 #define VJF_WG_KC 16
 __global__ __launch_bounds__(256) void vjf_wide_gemm_kernel(VjfWideGemm g) {
     __shared__ float s_a[64][VJF_WG_KC + 1];
@@ -81,170 +101,247 @@ __global__ __launch_bounds__(256) void vjf_wide_gemm_kernel(VjfWideGemm g) {
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wr * 32 + vrow(r, h);
         if (m >= g.M) continue;
-        float v = acc[r];
-        float* c = g.C + (size_t)m * g.ldc + n;
-        switch (g.epi) {
-            case WEPI_BIAS: v += g.bias[n]; break;
-            case WEPI_TANH_BIAS: v = tanhf(v + g.bias[n]); break;
-            case WEPI_ADD_SRC: v = fmaf(g.src_scale, g.src[(size_t)m * g.lds + n], v); break;
-            case WEPI_DTANH: { const float hv = g.src[(size_t)m * g.lds + n]; v *= (1.f - hv * hv); break; }
-            case WEPI_ADDC_DTANH: { const float hv = g.src[(size_t)m * g.lds + n]; v = (*c + v) * (1.f - hv * hv); break; }
-            case WEPI_SEED: {
-                const float e = g.eps_t[(size_t)m * g.N + n], lv = g.lv_t[(size_t)m * g.N + n];
-                c[g.N] = fmaf(v * e, 0.5f * expf(0.5f * lv), c[g.N]);            // dlv
-                v += *c;                                                         // dmu
-                break;
-            }
-            default: break;
-        }
-        *c = v;
+        vjf_wide_epilogue(g, m, n, acc[r]);
     }
 }
 
-// The same product for large shapes: 128 x TN tiles (TN = 128 or 64), 2 x 2 wavefronts of 64 x TN/2 each (four or two
-// 32x32 accumulators), K chunks of 16 through LDS; the NEXT chunk's 16-byte global loads are issued before the current
-// chunk's MFMAs (register double buffering), so a wavefront has 32 (16) MFMAs per 32 (24) LDS reads and several workgroups
-// share a CU.  An operand whose rows start on 16-byte boundaries (leading dimension a multiple of 4, aligned base: g.va / g.vb, set
-// by the launcher) is read 16 bytes at a time, another one float by float.
-template <int TN>
-__global__ __launch_bounds__(256) void vjf_wide_gemm2_kernel(VjfWideGemm g) {
-    constexpr int TM = 128, KC = 16, NB = TN / 64;       // NB: 32-column blocks per wavefront
-    __shared__ float s_a[TM][KC + 1];
-    __shared__ float s_b[KC][TN + 1];
+// The same product for large shapes: 128 x TN tiles (TN = 128 or 64), NWR x 2 wavefronts of (128 / NWR) x TN/2 each, K chunks
+// of KC through two LDS images (one barrier per chunk); global loads run two chunks ahead of their LDS store, in registers.  Both operands
+// sit in LDS k-major, [k][row]: every MFMA operand read is 32 consecutive floats per lane half (conflict-free), issued eight k
+// steps at a time (the compiler's own order waits for every step's reads before its MFMAs).
+// Global loads are 16 bytes per lane (a k-contiguous operand: 16 consecutive lanes take 16 rows at one k offset, the next 16
+// the same rows 16 bytes on, so that the transposing LDS stores -- row stride = 4 mod 32 banks -- are conflict-free) -- the
+// launcher picks this kernel only for operands that allow that (16-byte aligned rows, extent along the contiguous direction a
+// multiple of 4: g.va and g.vb).
+// (TA / BT: the layouts g.ta / g.nt as template parameters -- with run-time branches inside the loop the compiler can no longer
+//  count which loads a store has to wait for, and waits for all of them.)
+template <int TN, int KC, int NWR, bool TA, bool BT>
+__global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(4))) void vjf_wide_gemm3_kernel(VjfWideGemm g) {
+    constexpr int TM = 128, NB = TN / 64;                                   // NB: 32-column blocks per wavefront
+    constexpr int NT = NWR * 128, RB = TM / NWR / 32;                       // NWR x 2 wavefronts of (RB x 32) x TN/2 each
+    constexpr int FA = KC * TM / (4 * NT), FB = KC * TN / (4 * NT);         // 16-byte pieces per thread and chunk
+    constexpr int L = KC / 4;                                               // lanes per row of a k-contiguous operand
+    __shared__ __attribute__((aligned(16))) float s_a[2][KC * (TM + 4)];
+    __shared__ __attribute__((aligned(16))) float s_b[2][KC * (TN + 4)];
     if (g.ok && g.ok[0] == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    // workgroup -> tile: consecutive workgroups go to the eight XCDs in turn, so workgroup id = 8 t + x gets row tile x + 8 (t / gn),
+    // column tile t % gn -- an XCD's L2 then holds a few row tiles of A and the matrix B instead of streaming all of A
+    int bm = blockIdx.y, bn = blockIdx.x;
+    {
+        const int gn = gridDim.x, gm = gridDim.y;
+        if ((gm & 7) == 0) {
+            const int id = blockIdx.y * gn + blockIdx.x, x = id & 7, t = id >> 3;
+            bm = x + 8 * (t / gn); bn = t % gn;
+        }
+    }
+    const int m0 = bm * TM, n0 = bn * TN;
     const int wr = wave >> 1, wc = wave & 1;
-    vjf_f32x16 acc[2][NB];
+    constexpr int sa = TM + 4, sb = TN + 4;                                 // LDS row strides
+    vjf_f32x16 acc[RB][NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // loader roles: "k-contiguous" operands (A row-major, B as (N, K)): thread = (row, 8 consecutive k); "row-contiguous" ones
-    // (A transposed, B as (K, N)): thread = (k, 8 consecutive rows)
-    float4 ra[2], rb[TN / 64];
-    // four consecutive floats at p (the first `valid` of them inside the matrix): one 16-byte load when the operand allows it
-    auto ld4 = [](const float* p, int valid, bool vec) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid >= 4 && vec) return *reinterpret_cast<const float4*>(p);
-        if (valid > 0) v.x = p[0];
-        if (valid > 1) v.y = p[1];
-        if (valid > 2) v.z = p[2];
-        if (valid > 3) v.w = p[3];
-        return v;
-    };
-    auto load_a = [&](int k0) {
-        if (!g.ta) {
-            const int row = tid >> 1, kq = (tid & 1) * 8, m = m0 + row;
+    float4 ra[2][FA], rb[2][FB];                            // two chunks ahead of the MFMAs
+    // k-contiguous operand, R rows of the tile starting at r0 (A row-major, B as (N, K)): piece q = (row q RP + kc_row, k 4 kc_kq)
+    const int kc_kq = (tid >> 4) % L, kc_row = (tid & 15) + 16 * (tid / (16 * L));
+    // (pieces outside the matrix are read from a clamped address and zeroed when they are STORED to LDS: a select on a load's
+    //  destination right behind the load would wait for it and undo the prefetch)
+    auto load_kc = [&](float4* rv, int F, const float* base, int ld, int r0, int rows, int k0) {
+        constexpr int RP = NT / L;
+        const int k = k0 + 4 * kc_kq;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int k = k0 + kq + 4 * q;
-                ra[q] = ld4(g.A + (size_t)(m < g.M ? m : 0) * g.lda + (k < g.K ? k : 0), m < g.M ? g.K - k : 0, g.va != 0);
-            }
-        } else {
-            const int kk = tid >> 4, mq = (tid & 15) * 8, k = k0 + kk;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int m = m0 + mq + 4 * q;
-                ra[q] = ld4(g.A + (size_t)(k < g.K ? k : 0) * g.lda + (m < g.M ? m : 0), k < g.K ? g.M - m : 0, g.va != 0);
-            }
+        for (int q = 0; q < F; ++q) {
+            const int gr = min(r0 + q * RP + kc_row, rows - 1);
+            rv[q] = *reinterpret_cast<const float4*>(base + (size_t)gr * ld + (k < g.K ? k : 0));
         }
     };
-    auto store_a = [&]() {
-        if (!g.ta) {
-            const int row = tid >> 1, kq = (tid & 1) * 8;
+    auto store_kc = [&](float* sx, int S, const float4* rv, int F, int k0) {
+        constexpr int RP = NT / L;
+        const bool in = k0 + 4 * kc_kq < g.K;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) { float* d = &s_a[row][kq + 4 * q]; d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w; }
-        } else {
-            const int kk = tid >> 4, mq = (tid & 15) * 8;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { s_a[mq + 4 * q][kk] = ra[q].x; s_a[mq + 4 * q + 1][kk] = ra[q].y; s_a[mq + 4 * q + 2][kk] = ra[q].z; s_a[mq + 4 * q + 3][kk] = ra[q].w; }
+        for (int q = 0; q < F; ++q) {
+            float* d = sx + (size_t)(4 * kc_kq) * S + q * RP + kc_row;
+            d[0] = in ? rv[q].x : 0.f; d[S] = in ? rv[q].y : 0.f; d[2 * S] = in ? rv[q].z : 0.f; d[3 * S] = in ? rv[q].w : 0.f;
         }
     };
-    auto load_b = [&](int k0) {
-        if (g.nt) {          // (N, K): TN rows x 16 k; TN = 128: (row, 8 k) as A; TN = 64: (row, 4 k)
-            constexpr int KPT = TN / 16;                                  // k per thread
-            const int nn = tid / (16 / KPT), kq = (tid % (16 / KPT)) * KPT, n = n0 + nn;
+    // row-contiguous operand (A transposed, B as (K, N)), R columns of the tile starting at c0: piece f = tid + NT q of the KC x R/4 grid
+    auto load_rc = [&](float4* rv, int F, const float* base, int ld, int c0, int cols, int R, int k0) {
 #pragma unroll
-            for (int q = 0; q < TN / 64; ++q) {
-                const int k = k0 + kq + 4 * q;
-                rb[q] = ld4(g.Bm + (size_t)(n < g.N ? n : 0) * g.ldb + (k < g.K ? k : 0), n < g.N ? g.K - k : 0, g.vb != 0);
+        for (int q = 0; q < F; ++q) {
+            const int f = tid + NT * q, k = k0 + f / (R / 4), c = c0 + (f % (R / 4)) * 4;
+            const bool in = k < g.K && c < cols;
+            rv[q] = *reinterpret_cast<const float4*>(base + (in ? (size_t)k * ld + c : 0));
+        }
+    };
+    auto store_rc = [&](float* sx, int S, const float4* rv, int F, int c0, int cols, int R, int k0) {
+#pragma unroll
+        for (int q = 0; q < F; ++q) {
+            const int f = tid + NT * q, kk = f / (R / 4), c = (f % (R / 4)) * 4;
+            const bool in = k0 + kk < g.K && c0 + c < cols;
+            float4 v = rv[q];
+            if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(sx + (size_t)kk * S + c) = v;
+        }
+    };
+    auto load = [&](int buf, int k0) {
+        if constexpr (!TA) load_kc(ra[buf], FA, g.A, g.lda, m0, g.M, k0); else load_rc(ra[buf], FA, g.A, g.lda, m0, g.M, TM, k0);
+        if constexpr (BT) load_kc(rb[buf], FB, g.Bm, g.ldb, n0, g.N, k0); else load_rc(rb[buf], FB, g.Bm, g.ldb, n0, g.N, TN, k0);
+    };
+    auto store = [&](int buf, int k0) {                    // register set `buf` (chunk at k0) -> LDS image `buf`
+        if constexpr (!TA) store_kc(s_a[buf], sa, ra[buf], FA, k0); else store_rc(s_a[buf], sa, ra[buf], FA, m0, g.M, TM, k0);
+        if constexpr (BT) store_kc(s_b[buf], sb, rb[buf], FB, k0); else store_rc(s_b[buf], sb, rb[buf], FB, n0, g.N, TN, k0);
+    };
+    const int rl = lane & 31, h = lane >> 5;
+    const int oa = h * sa + wr * RB * 32 + rl, ob = h * sb + wc * (TN / 2) + rl;
+    constexpr int NBAT = KC / 16;                          // batches of eight k steps
+    // Chunk c (at k0) is computed from LDS image c & 1 while chunk c + 1 goes from registers into the other image and the loads of
+    // chunk c + 3 start (register set (c + 1) & 1; the other set holds chunk c + 2): ONE barrier per chunk, global loads two
+    // chunks ahead of their LDS store.
+    auto chunk = [&](int cur, int k0) {
+        const int nxt = cur ^ 1;
+        if (k0 + KC < g.K) store(nxt, k0 + KC);
+        if (k0 + 3 * KC < g.K) load(nxt, k0 + 3 * KC);
+        const float* pa = s_a[cur] + oa;
+        const float* pb = s_b[cur] + ob;
+#pragma unroll
+        for (int bt = 0; bt < NBAT; ++bt) {                // eight k steps: their operand reads, then their MFMAs (the other
+            float av[8][RB], bv[8][NB];                    // wavefronts of the SIMD fill the matrix pipe meanwhile)
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int t = bt * 8 + st;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) av[st][i] = pa[2 * t * sa + i * 32];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) bv[st][j] = pb[2 * t * sb + j * 32];
             }
-        } else {             // (K, N): 16 k x TN columns: thread = (k, TN / 16 consecutive columns)
-            constexpr int NPT = TN / 16;
-            const int kk = tid >> 4, nq = (tid & 15) * NPT, k = k0 + kk;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < TN / 64; ++q) {
-                const int n = n0 + nq + 4 * q;
-                rb[q] = ld4(g.Bm + (size_t)(k < g.K ? k : 0) * g.ldb + (n < g.N ? n : 0), k < g.K ? g.N - n : 0, g.vb != 0);
-            }
+            for (int st = 0; st < 8; ++st)
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][i], bv[st][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-    };
-    auto store_b = [&]() {
-        if (g.nt) {
-            constexpr int KPT = TN / 16;
-            const int nn = tid / (16 / KPT), kq = (tid % (16 / KPT)) * KPT;
-#pragma unroll
-            for (int q = 0; q < TN / 64; ++q) { s_b[kq + 4 * q][nn] = rb[q].x; s_b[kq + 4 * q + 1][nn] = rb[q].y; s_b[kq + 4 * q + 2][nn] = rb[q].z; s_b[kq + 4 * q + 3][nn] = rb[q].w; }
-        } else {
-            constexpr int NPT = TN / 16;
-            const int kk = tid >> 4, nq = (tid & 15) * NPT;
-#pragma unroll
-            for (int q = 0; q < TN / 64; ++q) { float* d = &s_b[kk][nq + 4 * q]; d[0] = rb[q].x; d[1] = rb[q].y; d[2] = rb[q].z; d[3] = rb[q].w; }
-        }
-    };
-    load_a(0); load_b(0);
-    for (int k0 = 0; k0 < g.K; k0 += KC) {
-        __syncthreads();                                   // (the previous chunk's readers are done)
-        store_a(); store_b();
         __syncthreads();
-        if (k0 + KC < g.K) { load_a(k0 + KC); load_b(k0 + KC); }
-        const int rl = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int t = 0; t < KC / 2; ++t) {
-            float a[2], b[NB];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = s_a[wr * 64 + i * 32 + rl][2 * t + h];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) b[j] = s_b[2 * t + h][wc * (TN / 2) + j * 32 + rl];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+    };
+    load(0, 0);
+    store(0, 0);
+    if (KC < g.K) load(1, KC);
+    if (2 * KC < g.K) load(0, 2 * KC);
+    __syncthreads();
+    for (int k0 = 0; k0 < g.K; k0 += 2 * KC) {
+        chunk(0, k0);
+        if (k0 + KC < g.K) chunk(1, k0 + KC);
     }
-    const int h = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int n = n0 + wc * (TN / 2) + j * 32 + (lane & 31);
             if (n >= g.N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + i * 32 + vrow(r, h);
+                const int m = m0 + (wr * RB + i) * 32 + vrow(r, h);
                 if (m >= g.M) continue;
-                float v = acc[i][j][r];
-                float* c = g.C + (size_t)m * g.ldc + n;
-                switch (g.epi) {
-                    case WEPI_BIAS: v += g.bias[n]; break;
-                    case WEPI_TANH_BIAS: v = tanhf(v + g.bias[n]); break;
-                    case WEPI_ADD_SRC: v = fmaf(g.src_scale, g.src[(size_t)m * g.lds + n], v); break;
-                    case WEPI_DTANH: { const float hv = g.src[(size_t)m * g.lds + n]; v *= (1.f - hv * hv); break; }
-                    case WEPI_ADDC_DTANH: { const float hv = g.src[(size_t)m * g.lds + n]; v = (*c + v) * (1.f - hv * hv); break; }
-                    case WEPI_SEED: {
-                        const float e = g.eps_t[(size_t)m * g.N + n], lv = g.lv_t[(size_t)m * g.N + n];
-                        c[g.N] = fmaf(v * e, 0.5f * expf(0.5f * lv), c[g.N]);            // dlv
-                        v += *c;                                                         // dmu
-                        break;
-                    }
-                    default: break;
-                }
-                *c = v;
+                vjf_wide_epilogue(g, m, n, acc[i][j][r]);
             }
         }
+}
+
+// C = A B for the products with a narrow output (N <= 64: heads, pt.mean, dxt, the RLS solves) -- a 128 x 64 tile grid would
+// leave most of the chip idle behind a serial K loop.  Workgroup = one 32 x 32 tile of C; its NW wavefronts split K (contiguous
+// ranges), every wavefront reads its operands from global memory straight into the MFMA operand layout -- the order of the
+// k indices inside a group of 8 is free as long as A and B agree: lane (row, half) takes k = k0 + 4 half + {0..3}, four
+// consecutive floats of a k-contiguous operand in one 16-byte load -- no LDS staging and no barrier in the K loop; the NW partial
+// tiles are summed through LDS in a fixed order.  Rows / columns beyond M / N are computed on clamped addresses and dropped.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void vjf_skinny_gemm_kernel(VjfWideGemm g) {
+    __shared__ float s_p[NW][1024];
+    if (g.ok && g.ok[0] == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int m = min(m0 + r, g.M - 1), n = min(n0 + r, g.N - 1);
+    const int kw = ((g.K + NW - 1) / NW + 7) / 8 * 8;           // k range of a wavefront: a multiple of 8
+    const int kb = wave * kw, ke = min(g.K, kb + kw);
+    vjf_f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    // four k values of the group at k0 for this lane; `full`: all of them inside [0, K)
+    auto ld_a = [&](float (&a)[4], int k0, bool full) {
+        const int kk = k0 + 4 * h;
+        if (!g.ta) {
+            const float* p = g.A + (size_t)m * g.lda + kk;
+            if (full && g.va) { const float4 v = *reinterpret_cast<const float4*>(p); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (full || kk + e < ke) ? p[e] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (full || kk + e < ke) ? g.A[(size_t)(kk + e) * g.lda + m] : 0.f;
+        }
+    };
+    auto ld_b = [&](float (&b)[4], int k0, bool full) {
+        const int kk = k0 + 4 * h;
+        if (g.nt) {
+            const float* p = g.Bm + (size_t)n * g.ldb + kk;
+            if (full && g.vb) { const float4 v = *reinterpret_cast<const float4*>(p); b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = (full || kk + e < ke) ? p[e] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = (full || kk + e < ke) ? g.Bm[(size_t)(kk + e) * g.ldb + n] : 0.f;
+        }
+    };
+    // rounds of 32 k (four groups of 8): the next round's loads are in flight while this round's MFMAs issue
+    float a0[4][4], p0[4][4], a1[4][4], p1[4][4];
+    auto load = [&](float (&a)[4][4], float (&p)[4][4], int kr) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ld_a(a[u], kr + 8 * u, true); ld_b(p[u], kr + 8 * u, true); }
+    };
+    auto mma = [&](const float (&a)[4][4], const float (&p)[4][4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], p[u][e], acc, 0, 0, 0);
+    };
+    int k0 = kb;
+    const int kfull = kb + (ke > kb ? (ke - kb) / 32 * 32 : 0);
+    if (k0 < kfull) load(a0, p0, k0);
+    while (k0 < kfull) {
+        if (k0 + 32 < kfull) load(a1, p1, k0 + 32);
+        mma(a0, p0);
+        k0 += 32;
+        if (k0 >= kfull) break;
+        if (k0 + 32 < kfull) load(a0, p0, k0 + 32);
+        mma(a1, p1);
+        k0 += 32;
+    }
+    for (; k0 < ke; k0 += 8) {                                  // the tail of the range, element-wise guards
+        float a[4], b[4];
+        ld_a(a, k0, false);
+        ld_b(b, k0, false);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s_p[wave][q * 64 + lane] = acc[q];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += NW * 64) {
+        float v = s_p[0][e];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += s_p[w][e];
+        const int mm = m0 + vrow(e >> 6, (e >> 5) & 1), nn = n0 + (e & 31);
+        if (mm < g.M && nn < g.N) vjf_wide_epilogue(g, mm, nn, v);
+    }
 }
 
 struct VjfWideArgs {

@@ -14,6 +14,7 @@ Drop-in notes:
     in the reference's order (xs then xt), so `torch.manual_seed` reproduces the reference's
     trajectory; `noise="device"` draws on the GPU instead (faster, different stream).
 """
+import os
 import ctypes
 import logging
 import weakref
@@ -373,6 +374,9 @@ class VJF(Module):
         nbytes = ctypes.c_int64()
         N.check(L.vjf_workspace_size(ctypes.byref(cfg), ctypes.byref(nbytes)), "vjf_workspace_size")
         self._workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=self._blob.device)
+        poison = os.environ.get("VJF_DEBUG_POISON_WS")         # (tests: a workspace of NaNs / of a byte pattern shows any read of a
+        if poison:                                             #  region the library has not written)
+            self._workspace.fill_(int(poison, 0) & 0xFF)
         ctx = ctypes.c_void_p()
         N.check(L.vjf_ctx_create(ctypes.byref(cfg), N.ptr(self._blob), N.ptr(self._workspace), nbytes.value, stream_ptr(),
                                  ctypes.byref(ctx)), "vjf_ctx_create")
