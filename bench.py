@@ -304,15 +304,24 @@ def main():
         kstats = None
         try:                                                    # the committed rocprofv3 --kernel-trace --stats summary of this build
             import csv
-            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv"))))
-            meta = json.load(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_meta.json")))
-            nst = meta.get("steps_in_all_launches")
-            kstats = {"file": "profiles/r02_kernel_stats.csv", "command": meta.get("command"), "steps_per_launch": meta.get("steps_per_launch"),
-                      "note": meta.get("note"), "mega_launches_us": meta.get("mega_launches_us"),
-                      "kernels": [{"name": r_["Name"].split("(")[0].replace("void ", ""), "calls": int(r_["Calls"]), "avg_us": float(r_["AverageNs"]) / 1e3,
-                                   "max_us": float(r_["MaxNs"]) / 1e3,
-                                   "us_per_step": (float(r_["TotalDurationNs"]) / 1e3 / nst) if (nst and "mega" in r_["Name"]) else None}
-                                  for r_ in rows if "vjf_" in r_["Name"]]}
+            if a.config == "E":                                 # (tools/profile_configE.sh: every kernel of the per-step route)
+                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_configE_kernel_stats.csv"))))
+                nst = 23
+                kstats = {"file": "profiles/r02_configE_kernel_stats.csv",
+                          "command": "rocprofv3 --kernel-trace --stats -- python bench.py --config E --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-elbo-check",
+                          "steps_in_profile": nst,
+                          "kernels": [{"name": r_["Name"].split("(")[0].replace("void ", ""), "calls": int(r_["Calls"]), "avg_us": float(r_["AverageNs"]) / 1e3,
+                                       "us_per_step": float(r_["TotalDurationNs"]) / 1e3 / nst} for r_ in rows if "vjf_" in r_["Name"]]}
+            elif a.config == "B":
+                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv"))))
+                meta = json.load(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_meta.json")))
+                nst = meta.get("steps_in_all_launches")
+                kstats = {"file": "profiles/r02_kernel_stats.csv", "command": meta.get("command"), "steps_per_launch": meta.get("steps_per_launch"),
+                          "note": meta.get("note"), "mega_launches_us": meta.get("mega_launches_us"),
+                          "kernels": [{"name": r_["Name"].split("(")[0].replace("void ", ""), "calls": int(r_["Calls"]), "avg_us": float(r_["AverageNs"]) / 1e3,
+                                       "max_us": float(r_["MaxNs"]) / 1e3,
+                                       "us_per_step": (float(r_["TotalDurationNs"]) / 1e3 / nst) if (nst and "mega" in r_["Name"]) else None}
+                                      for r_ in rows if "vjf_" in r_["Name"]]}
         except Exception:
             pass
         one_launch = world == 1 and not a.no_overlap and not a.streams_route and not a.force_dist and model.route() == "one-launch"

@@ -645,7 +645,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
         w.t = a;
         float* wb = (float*)(c->ws + c->cv.wide);
         const size_t Bz = (size_t)a.B;
-        w.XU = wb; w.PM = w.XU + Bz * P.dxu; w.PLV = w.PM + Bz * P.dz; w.PY = w.PLV + ((Bz + 3) / 4) * 4; w.Z = w.PY + Bz * P.dy;
+        w.XU = wb; w.PM = w.XU + Bz * P.dxu; w.PY = w.PM + Bz * P.dz + ((Bz + 3) / 4) * 4; w.Z = w.PY + Bz * P.dy;
         const float* S = c->state;
         auto gemm = [&](const float* A_, int lda, const float* Bm, int ldb, float* C_, int ldc, int N, int K, int nt, int epi,
                         const float* bias = nullptr, const float* src = nullptr, int lds = 0) {
@@ -655,7 +655,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
             launch_wide_gemm(g, st);
         };
         const int gx = 1024;
-        hipLaunchKernelGGL(vjf_wide_in_kernel, dim3(gx), dim3(256), 0, st, P, w);
+        hipLaunchKernelGGL(vjf_wide_in_kernel, dim3(a.B < 2048 ? a.B : 2048), dim3(256), 0, st, P, w);
         hipLaunchKernelGGL(vjf_wide_rbf_kernel, dim3((P.n + 255) / 256, (a.B + 15) / 16), dim3(256), (size_t)16 * P.dxu * 4, st, P, w);
         int kin = P.din;
         for (int l = 0; l < P.L; ++l) {                            // h_l = tanh(h_{l-1} W_l^T + b_l)   (recognition.py:31-36)
@@ -669,7 +669,6 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
         gemm(a.ACT + P.colA_xt, P.ldA, S + P.off[VJF_SLOT_DEC_W], P.dz, w.PY, P.dy, P.dy, P.dz, 1, WEPI_BIAS, S + P.off[VJF_SLOT_DEC_B]);
         gemm(a.E, P.ldE, S + P.off[VJF_SLOT_W_MEAN], P.dz, w.PM, P.dz, P.dz, P.n, 0, WEPI_ADD_SRC, nullptr, w.XU, P.dxu);
         gemm(a.E, P.ldE, S + P.off[VJF_SLOT_W_CHOL], P.n, w.Z, P.n, P.n, P.n, 0, WEPI_NONE);
-        hipLaunchKernelGGL(vjf_wide_rownorm_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, P, w);
         hipLaunchKernelGGL(vjf_wide_loss_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, P, w);
         // backward: dxt = dpy C into dmu / dlv; dh_L = dmu Wm + dlv Wl; da_l = (da_{l+1} W_{l+1}) (1 - h_l^2)
         gemm(a.DEL + P.colD_dpy, P.ldD, S + P.off[VJF_SLOT_DEC_W], P.dz, a.DEL + P.colD_dmu, P.ldD, P.dz, P.dy, 0, WEPI_SEED);

@@ -348,7 +348,6 @@ struct VjfWideArgs {
     VjfTrialArgs t;
     float* XU;      // (B, dxu)  [xs | u]
     float* PM;      // (B, dz)   pt.mean
-    float* PLV;     // (B)       pt.logvar
     float* PY;      // (B, dy)   decoder output
     float* Z;       // (B, n)    Phi w_chol
 };
@@ -359,35 +358,32 @@ __global__ __launch_bounds__(256) void vjf_wide_in_kernel(VjfPlan P, VjfWideArgs
     const int dz = P.dz, dy = P.dy, du = P.du, din = P.din, dxu = P.dxu;
     const float* S = A.state;
     const bool prior = A.mu_s == nullptr;
-    const size_t tot = (size_t)A.B * P.ldA;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += (size_t)gridDim.x * 256) {
-        const size_t b = e / P.ldA;
-        const int c = (int)(e - b * P.ldA);
-        float v = 0.f;
-        if (c < dy) v = A.y[b * dy + c];
-        else if (c < dy + du) v = A.u[b * du + (c - dy)];
-        else if (c < dy + du + dz) { const int j = c - dy - du; v = prior ? S[P.off[VJF_SLOT_PRIOR_MEAN] + j] : A.mu_s[b * dz + j]; }
-        else if (c < din) { const int j = c - dy - du - dz; v = prior ? S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j] : A.lv_s[b * dz + j]; }
-        else {
-            // the ones that follow every segment (the bias column of the gradient Gram); everything else is written later
-            bool one = c == din || c == P.colA_xt + dz;
-            for (int l = 0; l < P.L; ++l) one = one || c == P.colA_act[l + 1] + P.h[l];
-            if (!one && c < P.colA_xt + dz) continue;            // hidden activations / xt: by the GEMMs / vjf_wide_mid_kernel
-            v = one ? 1.f : 0.f;
+    for (size_t b = blockIdx.x; b < (size_t)A.B; b += gridDim.x) {     // one trial row per workgroup and round
+        float* arow = A.ACT + b * P.ldA;
+        for (int c = threadIdx.x; c < P.ldA; c += 256) {
+            float v = 0.f;
+            if (c < dy) v = A.y[b * dy + c];
+            else if (c < dy + du) v = A.u[b * du + (c - dy)];
+            else if (c < dy + du + dz) { const int j = c - dy - du; v = prior ? S[P.off[VJF_SLOT_PRIOR_MEAN] + j] : A.mu_s[b * dz + j]; }
+            else if (c < din) { const int j = c - dy - du - dz; v = prior ? S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j] : A.lv_s[b * dz + j]; }
+            else {
+                // the ones that follow every segment (the bias column of the gradient Gram); everything else is written later
+                bool one = c == din || c == P.colA_xt + dz;
+                for (int l = 0; l < P.L; ++l) one = one || c == P.colA_act[l + 1] + P.h[l];
+                if (!one && c < P.colA_xt + dz) continue;            // hidden activations / xt: by the GEMMs / vjf_wide_mid_kernel
+                v = one ? 1.f : 0.f;
+            }
+            arow[c] = v;
         }
-        A.ACT[e] = v;
-    }
-    const size_t totx = (size_t)A.B * dxu;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < totx; e += (size_t)gridDim.x * 256) {
-        const size_t b = e / dxu;
-        const int c = (int)(e - b * dxu);
-        float v;
-        if (c < dz) {
-            const float mu = prior ? S[P.off[VJF_SLOT_PRIOR_MEAN] + c] : A.mu_s[b * dz + c];
-            const float lv = prior ? S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c] : A.lv_s[b * dz + c];
-            v = fmaf(A.eps_s[b * dz + c], expf(0.5f * lv), mu);
-        } else v = A.u[b * du + (c - dz)];
-        W.XU[e] = v;
+        for (int c = threadIdx.x; c < dxu; c += 256) {
+            float v;
+            if (c < dz) {
+                const float mu = prior ? S[P.off[VJF_SLOT_PRIOR_MEAN] + c] : A.mu_s[b * dz + c];
+                const float lv = prior ? S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c] : A.lv_s[b * dz + c];
+                v = fmaf(A.eps_s[b * dz + c], expf(0.5f * lv), mu);
+            } else v = A.u[b * du + (c - dz)];
+            W.XU[b * dxu + c] = v;
+        }
     }
 }
 
@@ -411,8 +407,29 @@ __global__ __launch_bounds__(256) void vjf_wide_rbf_kernel(VjfPlan P, VjfWideArg
     for (int b = 0; b < 16; ++b) d2[b] = 0.f;
     for (int c0 = 0; c0 < dxu; c0 += 8) {                       // 8 centroid coordinates at a time
         float cv[8];
+        if ((dxu & 3) == 0) {
+            const float4 ca = *reinterpret_cast<const float4*>(cen + c0);
+            const float4 cb = c0 + 4 < dxu ? *reinterpret_cast<const float4*>(cen + c0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            cv[0] = ca.x; cv[1] = ca.y; cv[2] = ca.z; cv[3] = ca.w; cv[4] = cb.x; cv[5] = cb.y; cv[6] = cb.z; cv[7] = cb.w;
+        } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) cv[q] = c0 + q < dxu ? cen[c0 + q] : 0.f;
+            for (int q = 0; q < 8; ++q) cv[q] = c0 + q < dxu ? cen[c0 + q] : 0.f;
+        }
+        if ((dxu & 3) == 0) {                                  // (c0 + 8 <= dxu or c0 + 4 == dxu: whole 16-byte groups; same order of sums)
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const float4 x0 = *reinterpret_cast<const float4*>(&s_x[b * dxu + c0]);
+                float d;
+                d = x0.x - cv[0]; d2[b] = fmaf(d, d, d2[b]); d = x0.y - cv[1]; d2[b] = fmaf(d, d, d2[b]);
+                d = x0.z - cv[2]; d2[b] = fmaf(d, d, d2[b]); d = x0.w - cv[3]; d2[b] = fmaf(d, d, d2[b]);
+                if (c0 + 4 < dxu) {
+                    const float4 x1 = *reinterpret_cast<const float4*>(&s_x[b * dxu + c0 + 4]);
+                    d = x1.x - cv[4]; d2[b] = fmaf(d, d, d2[b]); d = x1.y - cv[5]; d2[b] = fmaf(d, d, d2[b]);
+                    d = x1.z - cv[6]; d2[b] = fmaf(d, d, d2[b]); d = x1.w - cv[7]; d2[b] = fmaf(d, d, d2[b]);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (c0 + q < dxu) {
@@ -442,18 +459,6 @@ __global__ __launch_bounds__(256) void vjf_wide_mid_kernel(VjfPlan P, VjfWideArg
         }
         A.E[b * P.ldE + n + j] = v;
     }
-}
-
-// pt.logvar = log sum_j Z[b][j]^2 : one wavefront per trial, fixed-order lane sums
-__global__ __launch_bounds__(256) void vjf_wide_rownorm_kernel(VjfPlan P, VjfWideArgs W) {
-    const int n = P.n, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= W.t.B) return;
-    float v = 0.f;
-    for (int j = lane; j < n; j += 64) { const float z = W.Z[(size_t)b * n + j]; v = fmaf(z, z, v); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) W.PLV[b] = logf(v);
 }
 
 // per-trial loss terms and backward seeds (no 1/B): one wavefront per trial, 4 trials per workgroup; partial sums per workgroup
@@ -490,7 +495,11 @@ __global__ __launch_bounds__(256) void vjf_wide_loss_kernel(VjfPlan P, VjfWideAr
                 drow[P.colD_dpy + i] = (pv <= 10.f) ? (ex - yv) : 0.f;
             }
         }
-        const float p = expf(-0.5f * sig), e = expf(-sig), plv = W.PLV[b];
+        float zz = 0.f;                                        // pt.logvar = log sum_j Z[b][j]^2 (module.py:76), fixed-order lane sums
+        for (int j = lane; j < P.n; j += 64) { const float z = W.Z[(size_t)b * P.n + j]; zz = fmaf(z, z, zz); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) zz += __shfl_xor(zz, o, 64);
+        const float p = expf(-0.5f * sig), e = expf(-sig), plv = logf(zz);
         for (int j = lane; j < dz; j += 64) {                  // model.py:390-391, functional.py:62-75
             const float mp = W.PM[(size_t)b * dz + j], mu = A.mu_t[(size_t)b * dz + j], lv = A.lv_t[(size_t)b * dz + j];
             const float dsc = mp * p - mu * p;
