@@ -199,7 +199,7 @@ __device__ __forceinline__ float4 mg_ld4(__amdgpu_buffer_rsrc_t r, int float_ind
 }
 
 // acc_g(row = 4*(lane>>4)+r, col = lane&15) += sum_{kb <= k < ke} Ag[k*lda + m0 + row] * Xs[k*LD + 16 g + col]   (g = 0, 1)
-// Rows m0 + i >= M contribute 0 (their A operand is read from a clamped address and masked).  kb is a multiple of 4.  The A operands come straight from L2 (k-major matrices: row k contiguous over the output features), 16 k-steps per batch,
+// Rows m0 + i >= M contribute 0 (their A operand is read from a clamped address and masked at use).  kb is a multiple of 4.  The A operands come straight from L2 (k-major matrices: row k contiguous over the output features), 16 k-steps per batch,
 // two batches in flight: while one batch's 32 MFMAs issue the next one's loads are on their way (and the SIMD's other wavefront
 // fills what latency is left).  The loads are sc1 (they bypass this CU's vector L1): these matrices are rewritten every step by
 // other roles, and the waits in front of them do not acquire.
@@ -211,11 +211,14 @@ __device__ __forceinline__ void mg_mma2_ld16(float (&a)[16], const float* __rest
     const unsigned row = rv ? (unsigned)(m0 + i) : 0u;
     const int klast = ke - 1;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { const int k = min(kb + 4 * (s0 + q) + kk, klast); const float v = mg_ld(Ag + row + (unsigned)k * (unsigned)lda); a[q] = rv ? v : 0.f; }
+    for (int q = 0; q < 16; ++q) { const int k = min(kb + 4 * (s0 + q) + kk, klast); a[q] = mg_ld(Ag + row + (unsigned)k * (unsigned)lda); }
+    // (rows beyond M are masked where the value is USED: a select on a load's destination right behind the load makes the compiler
+    //  wait for the load there, and the batch would no longer be in flight beside the previous batch's MFMAs)
 }
-__device__ __forceinline__ void mg_mma2_mm16(vjf_f32x4& acc0, vjf_f32x4& acc1, const float (&a)[16], const float* Xs, int kb, int ke, int s0, int lane) {
+__device__ __forceinline__ void mg_mma2_mm16(vjf_f32x4& acc0, vjf_f32x4& acc1, const float (&a)[16], const float* Xs, int M, int m0, int kb, int ke, int s0, int lane) {
     constexpr int LD = VJF_MG_LD;
     const int i = lane & 15, kk = lane >> 4;
+    const bool rv = (m0 + i) < M;
     const float* xp = Xs + i;
     const int nst = (ke - kb + 3) >> 2, klast = ke - 1;
 #pragma unroll
@@ -223,7 +226,7 @@ __device__ __forceinline__ void mg_mma2_mm16(vjf_f32x4& acc0, vjf_f32x4& acc1, c
         if (s0 + q < nst) {                            // (uniform)
             const int k = kb + 4 * (s0 + q) + kk;
             const int kc = min(k, klast);
-            const float av = k < ke ? a[q] : 0.f;
+            const float av = (rv && k < ke) ? a[q] : 0.f;
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD + 16], acc1, 0, 0, 0);
         }
@@ -243,7 +246,7 @@ __device__ __forceinline__ void mg_mma2(vjf_f32x4& acc0, vjf_f32x4& acc1, const 
     const int klast = ke - 1;
     auto ld16 = [&](float (&a)[16], int s0) {          // steps s0 .. s0 + 15: clamped rows, masked at use
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { const int k = min(kb + 4 * (s0 + q) + kk, klast); const float v = mg_ld(Ag + row + (unsigned)k * ulda); a[q] = rv ? v : 0.f; }
+        for (int q = 0; q < 16; ++q) { const int k = min(kb + 4 * (s0 + q) + kk, klast); a[q] = mg_ld(Ag + row + (unsigned)k * ulda); }
     };
     auto mm16 = [&](const float (&a)[16], int s0) {
 #pragma unroll
@@ -251,7 +254,7 @@ __device__ __forceinline__ void mg_mma2(vjf_f32x4& acc0, vjf_f32x4& acc1, const 
             if (s0 + q < nst) {                        // (uniform)
                 const int k = kb + 4 * (s0 + q) + kk;
                 const int kc = min(k, klast);
-                const float av = k < ke ? a[q] : 0.f;
+                const float av = (rv && k < ke) ? a[q] : 0.f;
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD + 16], acc1, 0, 0, 0);
             }
@@ -842,7 +845,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 if (wave < nsl) {
                     const int sl = msl;
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, mkb, mke, 0, lane); }
+                    if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, dz, 0, mkb, mke, 0, lane); }
                     else mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, mkb, mke, lane);
                     float* pr = s_part + (size_t)(sl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
 #pragma unroll

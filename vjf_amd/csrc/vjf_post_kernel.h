@@ -275,11 +275,12 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
             const int gi = (k + it) * 32 + r, gj = k * 32 + c4;
             const bool real = it < nb && (it == 0 || (gi < n && gj < n));  // (padding rows / columns of L are zero)
             v[q] = it == 0 ? post_ld4(r_dinv, real ? (size_t)k * 1024 + r * 32 + c4 : 0) : post_ld4(r_L, real ? (size_t)gi * n + gj : 0);
-            if (!real) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
+        }                                                                  // (zeroed below, where they are stored: a select right behind a
+#pragma unroll                                                             //  load waits for it, and the four would go one after the other)
         for (int q = 0; q < 4; ++q) {
             const int it = 2 * q + bh;
+            const int gi = (k + it) * 32 + r, gj = k * 32 + c4;
+            if (!(it < nb && (it == 0 || (gi < n && gj < n)))) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (it < nb) {
                 float* dst = (it == 0 ? dblk(k) : lblk(k + it, k)) + (size_t)r * LB + c4;
                 dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
