@@ -173,7 +173,9 @@ int vjf_filter_local(vjf_ctx* ctx, int32_t B, const float* y, const float* u, co
 int vjf_reduce_buffer(vjf_ctx* ctx, float** ptr, int64_t* n_floats);
 /* Serial half: finite guards, clip, SGD, likelihood running variance, RLS (Cholesky, solve,
  * triangular inverse), state-noise running variance, from the (all-reduced) buffer.
- * B_total = trials summed over all devices. */
+ * B_total = trials summed over all devices.  (A step with a non-finite loss component: this half alone cannot re-form the
+ * gradient without the dropped component -- the SGD step is skipped, the status bit raised; vjf_filter_step / vjf_filter_seq
+ * on one rank replay the backward half, see vjf_filter_seq.) */
 int vjf_filter_global(vjf_ctx* ctx, int32_t B_total, float* loss4, uint32_t flags);
 
 /* T successive steps, each fed the previous posterior: the inner loop of VJF.fit
@@ -184,9 +186,13 @@ int vjf_filter_global(vjf_ctx* ctx, int32_t B_total, float* loss4, uint32_t flag
  * the steps run as per-step kernels on three internal streams with the sums over ranks done by RCCL; otherwise step by step
  * on the caller's stream.  Every in-kernel wait is bounded: one that runs out raises VJF_STATUS_RLS_FAILED plus a
  * VJF_STATUS_WAIT_* detail bit (vjf_get_status), ends the other waits of the call at once, and the outputs of the call are
- * not to be used.  A loss component that is not finite (VJF_STATUS_NONFINITE_*) is handled as vjf/model.py:138-149 does on the
- * one-launch route (the component becomes 0 and the step's gradient is that of the others); on the per-step routes the SGD
- * step of such a step is skipped. */
+ * not to be used.  A loss component that is not finite (VJF_STATUS_NONFINITE_*) is handled as vjf/model.py:138-149 does
+ * (the component becomes 0 and the step's gradient is that of the others) on the one-launch route and on the one-stream
+ * per-step route of a single rank (there the backward half, the gradient sums and the SGD pass are launched again behind the
+ * first SGD pass; they return at once on ordinary steps).  Where trials are sharded over ranks (communicators, or
+ * vjf_filter_local / vjf_filter_global around the caller's all-reduce: a replay would need a second sum over ranks), on the
+ * three-stream route of one rank and on plans served by the generic single-workgroup serial kernel the SGD step of such a
+ * step is skipped. */
 int vjf_filter_seq(vjf_ctx* ctx, int32_t T, int32_t B, const float* y, const float* u, const float* eps,
                    const float* mu0, const float* lv0, float* mu, float* lv, float* loss, uint32_t flags);
 

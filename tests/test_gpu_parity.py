@@ -311,23 +311,30 @@ def test_nonfinite_loss_is_flagged(vjf):
     assert float(recon) == 0.0             # replaced by the constant 0 (model.py:138-139)
 
 
+@pytest.mark.parametrize("route", ["one_launch", "one_stream", "rls_launches", "wide"])
 @pytest.mark.parametrize("which", ["recon", "dynamics"])
-def test_nonfinite_component_is_dropped_like_the_reference(vjf, which):
+def test_nonfinite_component_is_dropped_like_the_reference(vjf, which, route):
     """vjf/model.py:138-149: a loss component whose batch mean is not finite becomes the constant 0 -- the step's gradient is that
     of the OTHER components, clipped and applied as usual.  Overflow in fp32 (the reference's dtype): the oracle runs in fp32 too.
       recon:    Poisson, one decoder bias at -3e38 and counts of 2 there: -y * eta overflows, everything else stays finite;
       dynamics: w_chol scaled by 1e25: the predictive variance and with it the 'trace' term exp(logvar sums) overflow.
-    The flagged step is replayed inside the launch (the middle of a sequence) and behind the last step of a call (filter())."""
+    The flagged step is replayed inside the launch (the middle of a sequence) and behind the last step of a call (filter()).
+    Routes: the one-launch route; the per-step kernels on one stream (the backward half, the gradient sums and the SGD pass are
+    launched again behind the first SGD pass and return at once on ordinary steps); the same with the multi-launch RLS (RBF(260)) and on
+    the GEMM-per-layer trial path (d_y = 300, RBF(1200), hidden [400])."""
     import warnings
     lik = "poisson" if which == "recon" else "gaussian"
-    B, dz, dy, n, T = 40, 3, 10, 16, 4
+    B, dz, dy, n, T = {"wide": (20, 6, 300, 1200, 3), "rls_launches": (40, 3, 10, 260, 4)}.get(route, (40, 3, 10, 16, 4))
+    hidden = [400] if route == "wide" else [8]
     g = torch.Generator().manual_seed(31)
     y = torch.poisson(torch.exp(0.3 * torch.randn(T, B, dy, generator=g)), generator=g) if lik == "poisson" else torch.randn(T, B, dy, generator=g)
     eps = torch.randn(T, 2, B, dz, generator=g)
 
     def fresh():
         torch.manual_seed(30)
-        m = vjf.VJF.make_model(dy, dz, 0, n, [8], likelihood=lik, lr=1e-2)
+        m = vjf.VJF.make_model(dy, dz, 0, n, hidden, likelihood=lik, lr=1e-2)
+        if route != "one_launch":
+            m.set_overlap(False)
         return m
 
     def poison(m):
@@ -347,6 +354,7 @@ def test_nonfinite_component_is_dropped_like_the_reference(vjf, which):
         poison(m)
         s = load_oracle_state(m, np.float32)
         mu, lv, loss = m.filter_sequence(y[1:], qs=vjf.Gaussian(mu0[-1], lv0[-1]), eps=eps[1:])
+        assert m.route() == ("one-launch" if route == "one_launch" else "per-step")
         st = m.status()
         assert st & bit and not (st & ~0x7 & ~8), hex(st)
         om, ol = mu0[-1].cpu().numpy(), lv0[-1].cpu().numpy()

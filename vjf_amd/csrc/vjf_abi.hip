@@ -576,6 +576,7 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
 };
 
+constexpr int kReplayMaskWord = 56, kReplayRhoWord = 57;   // words of the flag block no hand-off uses
 constexpr unsigned kScAll = (1u << RS_N) - 1u;
 constexpr unsigned kScRls = 1u << RS_SDX2;                 // the one loss sum the RLS chain reads
 
@@ -634,6 +635,12 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
         VjfTrialMfmaArgs m{};
         m.t = a; m.aux = (const float*)(c->ws + c->cv.aux); m.part = part;
         m.rls_done = rls_done; m.rls_target = rls_target;
+        if (a.replay) {                                            // the backward half again, nothing counted
+            m.part = 2;
+            hipLaunchKernelGGL(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, P, m);
+            VJF_HIP(hipGetLastError());
+            return 0;
+        }
         m.done = (unsigned*)(c->ws + c->cv.flags) + 16;
         if (part != 1) c->k1_count += (unsigned)nblk;
         if (part == 1 && count_fwd) { m.fwd_done = (unsigned*)(c->ws + c->cv.flags) + 48; c->fwd_count += (unsigned)nblk; }
@@ -652,9 +659,11 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
             VjfWideGemm g{};
             g.A = A_; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.C = C_; g.ldc = ldc; g.M = a.B; g.N = N; g.K = K; g.nt = nt; g.epi = epi;
             g.bias = bias; g.src = src; g.lds = lds; g.src_scale = 1.f; g.eps_t = a.eps_t; g.lv_t = a.lv_t;
+            g.ok = a.replay ? (const int*)a.replay_mask : nullptr;     // (a replay's launches do nothing when the word is 0)
             launch_wide_gemm(g, st);
         };
         const int gx = 1024;
+        if (!a.replay) {                                           // (forward products: what the backward half reads stays in place)
         hipLaunchKernelGGL(vjf_wide_in_kernel, dim3(a.B < 2048 ? a.B : 2048), dim3(256), 0, st, P, w);
         hipLaunchKernelGGL(vjf_wide_rbf_kernel, dim3((P.n + 255) / 256, (a.B + 15) / 16), dim3(256), (size_t)16 * P.dxu * 4, st, P, w);
         int kin = P.din;
@@ -669,6 +678,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
         gemm(a.ACT + P.colA_xt, P.ldA, S + P.off[VJF_SLOT_DEC_W], P.dz, w.PY, P.dy, P.dy, P.dz, 1, WEPI_BIAS, S + P.off[VJF_SLOT_DEC_B]);
         gemm(a.E, P.ldE, S + P.off[VJF_SLOT_W_MEAN], P.dz, w.PM, P.dz, P.dz, P.n, 0, WEPI_ADD_SRC, nullptr, w.XU, P.dxu);
         gemm(a.E, P.ldE, S + P.off[VJF_SLOT_W_CHOL], P.n, w.Z, P.n, P.n, P.n, 0, WEPI_NONE);
+        }
         hipLaunchKernelGGL(vjf_wide_loss_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, P, w);
         // backward: dxt = dpy C into dmu / dlv; dh_L = dmu Wm + dlv Wl; da_l = (da_{l+1} W_{l+1}) (1 - h_l^2)
         gemm(a.DEL + P.colD_dpy, P.ldD, S + P.off[VJF_SLOT_DEC_W], P.dz, a.DEL + P.colD_dmu, P.ldD, P.dz, P.dy, 0, WEPI_SEED);
@@ -685,7 +695,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
 }
 
 // Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
-int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, int gen = 0) {
+int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, int gen = 0, const unsigned* run_if = nullptr) {
     const VjfPlan& P = c->plan;
     const int nsplit = split_for(B);
     VjfGramArgs g{};
@@ -694,11 +704,12 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     g.slabs = (float*)(c->ws + c->cv.slabs);
     g.B = B; g.nsplit = nsplit; g.job0 = job0;
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
+    g.run_if = run_if;
     hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(VJF_GRAM_THREADS), 0, st, P, g);
     VJF_HIP(hipGetLastError());
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial)); r.red = red;
-    r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask;
+    r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask; r.run_if = run_if;
     hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(VJF_REDUCE_THREADS), 0, st, P, r);
     VJF_HIP(hipGetLastError());
     return 0;
@@ -706,7 +717,8 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
 
 // which: 0 whole prep grid, 1 RLS operand rows only, 2 SGD + scalars only
 int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const float* red, int which, hipStream_t st,
-                const unsigned* run_word = nullptr, unsigned run_epoch = 0, const unsigned* start_count = nullptr, unsigned start_target = 0) {
+                const unsigned* run_word = nullptr, unsigned run_epoch = 0, const unsigned* start_count = nullptr, unsigned start_target = 0,
+                int replay = 0) {                               // replay: 1 first pass with a replay behind it, 2 the pass behind the replay
     const VjfPlan& P = c->plan;
     VjfPrepArgs p{};
     p.state = c->state; p.red = red; p.gbuf = (float*)(c->ws + c->cv.work);
@@ -715,6 +727,10 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
     p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
     p.n_sgdblk = (P.train_len + 1023) / 1024;
     p.run_word = run_word; p.run_epoch = run_epoch; p.start_count = start_count; p.start_target = start_target;
+    if (replay) {
+        p.replay_mask = (unsigned*)(c->ws + c->cv.flags) + kReplayMaskWord; p.replay_rho = (float*)(c->ws + c->cv.flags) + kReplayRhoWord;
+        p.replay_pass = replay == 2 ? 1 : 0;
+    }
     if (which != 2 && P.dz > 16) {                             // (the matrix-core operand kernel holds one 16-column tile of W)
         p.bid0 = 0;
         const int grid = which == 1 ? p.n_rowblk : p.n_rowblk + p.n_sgdblk + 1;
@@ -994,14 +1010,31 @@ int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, cons
     return launch_local(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags, false);
 }
 
-int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags) {
-    if (!c) return fail(-1, "vjf_filter_global: null context");
-    DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
-    if (B_total < 1) return fail(-20, "vjf_filter_global: B_total=%d", B_total);
+namespace {
+// After the SGD pass of a one-rank step: the backward half with the seeds of the dropped loss components at zero, the gradient
+// sums, and the SGD pass from them -- every launch returns at once unless the first pass found a non-finite component
+// (vjf/model.py:138-149; the one-launch route does the same inside its grid).
+int launch_replay(vjf_ctx* c, const VjfTrialArgs& a0, int32_t B_total, uint32_t flags, hipStream_t st) {
+    VjfTrialArgs a = a0;
+    a.replay = 1;
+    a.replay_mask = (const unsigned*)(c->ws + c->cv.flags) + kReplayMaskWord;
+    a.replay_rho = (const float*)(c->ws + c->cv.flags) + kReplayRhoWord;
+    int rc = launch_trial(c, a, 2, st);
+    if (rc) return rc;
+    float* red = (float*)(c->ws + c->cv.red);
+    if ((rc = launch_gram(c, a.B, c->n_ejobs, c->njobs - c->n_ejobs, 0u, red, st, 0, a.replay_mask))) return rc;
+    return launch_prep(c, B_total, nullptr, flags, red, 2, st, nullptr, 0, nullptr, 0, 2);
+}
+
+// the serial half of a step; `ta`: the trial-parallel half's arguments when this rank holds ALL trials (then a step with a non-finite
+// loss component is replayed as the reference defines it), else null
+int filter_global_impl(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const VjfTrialArgs* ta) {
+    const bool replay = ta && (flags & VJF_FLAG_SGD) && (c->fast_chol || c->plan.n > 32 * VJF_CHOL_MAXBLK);
     if (c->fast_chol) {
         const float* red = (const float*)(c->ws + c->cv.red);
-        int rc = launch_prep(c, B_total, loss4, flags, red, 0, c->stream);
+        int rc = launch_prep(c, B_total, loss4, flags, red, 0, c->stream, nullptr, 0, nullptr, 0, replay ? 1 : 0);
         if (rc) return rc;
+        if (replay && (rc = launch_replay(c, *ta, B_total, flags, c->stream))) return rc;
         return launch_rls(c, B_total, flags, red, c->stream, false);
     }
     if (c->plan.n > 32 * VJF_CHOL_MAXBLK) {
@@ -1009,8 +1042,9 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
         // chip-wide launches on the matrix in global memory (vjf_rlsb_kernels.h)
         const VjfPlan& P = c->plan;
         const float* red = (const float*)(c->ws + c->cv.red);
-        int rc = launch_prep(c, B_total, loss4, flags, red, 2, c->stream);
+        int rc = launch_prep(c, B_total, loss4, flags, red, 2, c->stream, nullptr, 0, nullptr, 0, replay ? 1 : 0);
         if (rc) return rc;
+        if (replay && (rc = launch_replay(c, *ta, B_total, flags, c->stream))) return rc;
         if (!(flags & VJF_FLAG_UPDATE)) return 0;
         hipStream_t st = c->stream;
         const int nbl = (P.n + 31) / 32;
@@ -1068,6 +1102,14 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
     VJF_HIP(hipGetLastError());
     return 0;
 }
+}  // namespace
+
+int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags) {
+    if (!c) return fail(-1, "vjf_filter_global: null context");
+    DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
+    if (B_total < 1) return fail(-20, "vjf_filter_global: B_total=%d", B_total);
+    return filter_global_impl(c, B_total, loss4, flags, nullptr);   // (the caller's ranks hold shards: no replay, see vjf_hip.h)
+}
 
 namespace {
 // single rank, the step as the reference runs it (model.py:206-216: gradient step and closed-form updates) on a plan the
@@ -1105,7 +1147,8 @@ int vjf_filter_step(vjf_ctx* c, int32_t B, const float* y, const float* u, const
     }
     int rc = vjf_filter_local(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags);
     if (rc) return rc;
-    return vjf_filter_global(c, B, loss4, flags);
+    const VjfTrialArgs ta = trial_args(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags);
+    return filter_global_impl(c, B, loss4, flags, c->world > 1 ? nullptr : &ta);
 }
 
 int vjf_route(vjf_ctx* c, uint32_t flags) {
@@ -1156,7 +1199,9 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
         int rc = launch_local(c, B, y + t * sy, u ? u + t * su : nullptr, ms, ls, eps + (size_t)t * 2 * sz,
                               eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags, fresh);
         if (rc) return rc;
-        rc = vjf_filter_global(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags);
+        const VjfTrialArgs ta = trial_args(c, B, y + t * sy, u ? u + t * su : nullptr, ms, ls, eps + (size_t)t * 2 * sz,
+                                           eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags);
+        rc = filter_global_impl(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags, &ta);
         if (rc) return rc;
         ms = mu + t * sz; ls = lv + t * sz;
         (void)P;

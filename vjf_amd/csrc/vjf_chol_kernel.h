@@ -43,6 +43,11 @@ struct VjfPrepArgs {
     const unsigned* run_word; unsigned run_epoch;
     const unsigned* start_count; unsigned start_target;
     unsigned* done_count;         // vjf_prepg_kernel: non-null -> += 1 per workgroup once its rows of P and g are in memory
+    // Non-finite loss component (vjf/model.py:138-149) on the one-stream route: the first pass leaves the parameters alone and
+    // writes the dropped components (bit 0 recon, 1 dynamics, 2 entropy; 0: nothing to replay) and the likelihood log-variance the
+    // step started with; the backward half and the gradient sums run again behind it (they return at once on 0), then the second
+    // pass (replay_pass) applies the step from the new sums.
+    unsigned* replay_mask; float* replay_rho; int replay_pass;
 };
 
 // logical grid = n_rowblk + n_sgdblk + 1
@@ -56,6 +61,9 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
     float l_recon = RSC[RS_LRECON] * invB, l_dyn = RSC[RS_LDYN] * invB, ent = RSC[RS_ENT] * invB;
     const bool ok_r = isfinite(l_recon), ok_d = isfinite(l_dyn), ok_h = isfinite(ent);
     const bool grad_ok = ok_r && ok_h && (warm || ok_d);       // see vjf_serial_kernel / DESIGN.md
+    // some, not all, of the components in the loss are non-finite: the reference steps along the gradient of the others
+    const bool partial = do_sgd && !grad_ok && (ok_r || ok_h || (!warm && ok_d));
+    const bool replay = A.replay_mask != nullptr && partial;
 
     if (bid < A.n_rowblk) {                                    // ---- RLS operands: one row of P per workgroup
         if (!do_upd || warm) return;
@@ -85,7 +93,8 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
         return;
     }
     if (bid < A.n_rowblk + A.n_sgdblk) {                       // ---- clip + SGD, tensor by tensor; transposed copies follow
-        if (!(do_sgd && grad_ok)) return;
+        if (A.replay_pass) { if (__hip_atomic_load(A.replay_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return; }
+        else if (!(do_sgd && grad_ok)) return;
         const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
         const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
         const int g0 = (bid - A.n_rowblk) * 256 + tid, gs = A.n_sgdblk * 256;
@@ -106,7 +115,12 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
         }
         return;
     }
+    if (A.replay_pass) return;                                 // (the scalars were settled by the first pass)
     if (tid == 0) {                                            // ---- scalars: loss, likelihood log-variance
+        if (A.replay_mask) {
+            __hip_atomic_store(A.replay_rho, S[P.off[VJF_SLOT_LIK_LOGVAR]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.replay_mask, replay ? ((ok_r ? 0u : 1u) | (ok_d ? 0u : 2u) | (ok_h ? 0u : 4u)) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (!ok_r) l_recon = 0.f;
         if (!ok_d) l_dyn = 0.f;
         if (!ok_h) ent = 0.f;
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
         if (P.lik == VJF_LIK_GAUSSIAN) {
             const float sse_y = RSC[RS_SSEY];
             float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
-            if (do_sgd && grad_ok) {
+            if (do_sgd && (grad_ok || (replay && ok_r))) {       // (its gradient comes from the reconstruction term alone)
                 float g = 0.5f * ((float)P.dy - expf(-rho) * sse_y * invB);
                 g = fminf(fmaxf(g, -1.f), 1.f);
                 rho -= SC[VJF_SC_LR_LIK] * g;

@@ -22,6 +22,7 @@ struct VjfGramArgs {
     int B, nsplit, rows_per_split;
     int job0;                // first job of this launch (the grid covers a contiguous job range)
     int high_prio;           // raise the wavefronts' issue priority (the statistics Gram that runs beside the trial kernel)
+    const unsigned* run_if;  // non-null: nothing is done when the word is 0 (the replay after a non-finite loss component)
 };
 
 #define VJF_GRAM_WAVES 4            // wavefronts per workgroup (8 was tried: 1.4 us/step slower at config B)
@@ -29,6 +30,7 @@ struct VjfGramArgs {
 __global__ __launch_bounds__(VJF_GRAM_THREADS) void vjf_gram_kernel(VjfPlan P, VjfGramArgs A) {
     constexpr int GW = VJF_GRAM_WAVES;
     __shared__ float s_acc[(GW - 1) * 1024];
+    if (A.run_if && __hip_atomic_load(A.run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     if (A.high_prio) __builtin_amdgcn_s_setprio(3);     // beside the trial kernel's older wavefronts: do not starve
     // linear id = job * nsplit + split: workgroups are dealt round-robin over the 8 XCDs, so with nsplit a
     // multiple of 8 every job of one trial range lands on the same XCD and re-reads its rows from that L2
@@ -94,6 +96,7 @@ struct VjfReduceArgs {
     int njobs, nsplit, nblocks_k1;
     int job0;                 // first job of this launch; njobs = jobs in this launch
     unsigned sc_mask;         // which of K1's loss sums the extra workgroup reduces (bit per RS_* index)
+    const unsigned* run_if;   // non-null: nothing is done when the word is 0
 };
 
 // grid = njobs + 1 workgroups of 1024 threads (one tile element each: all of a thread's slab loads are in flight at once);
@@ -101,6 +104,7 @@ struct VjfReduceArgs {
 #define VJF_REDUCE_THREADS 1024
 __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(VjfPlan P, VjfReduceArgs A) {
     const int tid = threadIdx.x;
+    if (A.run_if && __hip_atomic_load(A.run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     if ((int)blockIdx.x == A.njobs) {
         // RS_N scalars; 32 threads per scalar accumulate strided partials in double, then a fixed xor tree over the 32
         const int sc = (tid >> 5) & 7, l = tid & 31;

@@ -27,6 +27,10 @@ struct VjfTrialArgs {
     float* partial;        // (gridDim.x, RS_N)
     int B;
     unsigned flags;
+    // Replay of the backward half after a non-finite loss component (vjf/model.py:138-149): the SGD kernel left the parameters alone
+    // and published which components the reference drops (bit 0 recon, 1 dynamics, 2 entropy) and the likelihood log-variance the
+    // step started with; `replay` launches return at once when the word is 0, else form the seeds without the dropped components'.
+    const unsigned* replay_mask; const float* replay_rho; int replay;
 };
 
 // out[b][f] = sum_k X[b][k] * W[f][k]      W row-major (N,K): a torch Linear weight.

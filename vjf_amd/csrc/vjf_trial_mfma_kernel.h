@@ -119,6 +119,9 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     const bool warm = (A.flags & VJF_FLAG_WARM_UP) != 0;
     const bool tri = S[P.off[VJF_SLOT_SCALARS] + VJF_SC_TRI_CLEAN] != 0.f;   // w_chol known upper triangular
     const bool fwd = AA.part != 2, bwd = AA.part != 1;
+    const unsigned rbits = A.replay ? __hip_atomic_load(A.replay_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (A.replay && rbits == 0u) return;                        // (uniform: the usual step)
+    const bool m_r = !(rbits & 1u), m_d = !(rbits & 2u), m_h = !(rbits & 4u);   // loss components kept
     const bool handoff = AA.fwd_done != nullptr && !bwd;        // part 1 inside vjf_filter_seq
     constexpr int LD = VJF_LDT;
     constexpr int NW = VJF_K1M_WAVES;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     if (bwd) {
         constexpr int LPT = VJF_K1M_THREADS / 16;          // lanes per trial
         const int b = tid / LPT, s = tid % LPT;
-        const float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]];
+        const float rho = A.replay ? __hip_atomic_load(A.replay_rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S[P.off[VJF_SLOT_LIK_LOGVAR]];
         // (sigma may have been written while this kernel was already running: a load that bypasses L1 / the scalar cache)
         const float sig = __hip_atomic_load(S + P.off[VJF_SLOT_TR_LOGVAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float lrec = 0.f, ssey = 0.f;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
                 const float r = pv - yv, dsc = yv * p - pv * p;
                 lrec += 0.5f * (dsc * dsc + rho);
                 ssey = fmaf(r, r, ssey);
-                s_dpy[i * LD + b] = e * r;
+                s_dpy[i * LD + b] = m_r ? e * r : 0.f;
             }
         } else {                                                       // likelihood.py:51-62
             for (int i = s; i < dy; i += LPT) {
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
                 lrec += ex - yv * eta;
                 const float r = pv - yv;
                 ssey = fmaf(r, r, ssey);
-                s_dpy[i * LD + b] = (pv <= 10.f) ? (ex - yv) : 0.f;
+                s_dpy[i * LD + b] = (m_r && pv <= 10.f) ? (ex - yv) : 0.f;
             }
         }
         lrec = group_sum<LPT>(lrec);
@@ -407,8 +410,8 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
                 ent += 0.5f * lv;                                      // functional.py:25-29
                 const float dx = s_xt[j * LD + b] - s_xu[j * LD + b];
                 sdx2 = fmaf(dx, dx, sdx2);
-                float dmu = 0.f, dlv = -0.5f;
-                if (!warm) { dmu = -e * (mp - mu); dlv += 0.5f * tr; }
+                float dmu = 0.f, dlv = m_h ? -0.5f : 0.f;
+                if (!warm && m_d) { dmu = -e * (mp - mu); dlv += 0.5f * tr; }
                 s_dmu[j * LD + b] = dmu;
                 s_dlv[j * LD + b] = dlv;
             }
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
         }
     }
     __syncthreads();
-    if (bwd && tid < RS_N && (fwd || tid != RS_SDX2)) {   // (the forward half / part owns sum |dx|^2)
+    if (bwd && !A.replay && tid < RS_N && (fwd || tid != RS_SDX2)) {   // (the forward half / part owns sum |dx|^2; a replay leaves the sums alone)
         float v = 0.f;
         if (tid <= RS_SDX2) for (int b = 0; b < 16; ++b) v += s_sc[b * RS_N + tid];
         A.partial[(size_t)blockIdx.x * RS_N + tid] = v;

@@ -470,7 +470,11 @@ __global__ __launch_bounds__(256) void vjf_wide_loss_kernel(VjfPlan P, VjfWideAr
     const bool ok = b < A.B;
     const bool warm = (A.flags & VJF_FLAG_WARM_UP) != 0;
     const float* S = A.state;
-    const float rho = S[P.off[VJF_SLOT_LIK_LOGVAR]], sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
+    const unsigned rbits = A.replay ? __hip_atomic_load(A.replay_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (A.replay && rbits == 0u) return;                        // (uniform: the usual step)
+    const bool m_r = !(rbits & 1u), m_d = !(rbits & 2u), m_h = !(rbits & 4u);   // loss components kept (vjf_trial_kernel.h)
+    const float rho = A.replay ? __hip_atomic_load(A.replay_rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S[P.off[VJF_SLOT_LIK_LOGVAR]];
+    const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
     float lrec = 0.f, ssey = 0.f, ldyn = 0.f, ent = 0.f, sdx2 = 0.f;
     if (ok) {
         const float* yrow = A.ACT + (size_t)b * P.ldA;            // in = [y | ..]
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256) void vjf_wide_loss_kernel(VjfPlan P, VjfWideAr
                 const float r = pv - yv, dsc = yv * p - pv * p;
                 lrec += 0.5f * (dsc * dsc + rho);
                 ssey = fmaf(r, r, ssey);
-                drow[P.colD_dpy + i] = e * r;
+                drow[P.colD_dpy + i] = m_r ? e * r : 0.f;
             }
         } else {                                               // likelihood.py:51-62
             for (int i = lane; i < dy; i += 64) {
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(256) void vjf_wide_loss_kernel(VjfPlan P, VjfWideAr
                 lrec += ex - yv * eta;
                 const float r = pv - yv;
                 ssey = fmaf(r, r, ssey);
-                drow[P.colD_dpy + i] = (pv <= 10.f) ? (ex - yv) : 0.f;
+                drow[P.colD_dpy + i] = (m_r && pv <= 10.f) ? (ex - yv) : 0.f;
             }
         }
         float zz = 0.f;                                        // pt.logvar = log sum_j Z[b][j]^2 (module.py:76), fixed-order lane sums
@@ -508,8 +512,8 @@ __global__ __launch_bounds__(256) void vjf_wide_loss_kernel(VjfPlan P, VjfWideAr
             ent += 0.5f * lv;                                  // functional.py:25-29
             const float dx = A.E[(size_t)b * P.ldE + P.n + j];
             sdx2 = fmaf(dx, dx, sdx2);
-            float dmu = 0.f, dlv = -0.5f;
-            if (!warm) { dmu = -e * (mp - mu); dlv += 0.5f * tr; }
+            float dmu = 0.f, dlv = m_h ? -0.5f : 0.f;
+            if (!warm && m_d) { dmu = -e * (mp - mu); dlv += 0.5f * tr; }
             drow[P.colD_dmu + j] = dmu;                        // the decoder path is added by the dxt GEMM's epilogue
             drow[P.colD_dlv + j] = dlv;
         }
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(256) void vjf_wide_loss_kernel(VjfPlan P, VjfWideAr
         s_sc[w][RS_SSEY] = ok ? ssey : 0.f; s_sc[w][RS_SDX2] = ok ? sdx2 : 0.f;
     }
     __syncthreads();
-    if (threadIdx.x < RS_N) {
+    if (threadIdx.x < RS_N && !A.replay) {                         // (a replay leaves the loss sums alone)
         float v = 0.f;
         if (threadIdx.x <= RS_SDX2) v = ((s_sc[0][threadIdx.x] + s_sc[1][threadIdx.x]) + s_sc[2][threadIdx.x]) + s_sc[3][threadIdx.x];
         A.partial[(size_t)blockIdx.x * RS_N + threadIdx.x] = v;
