@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <atomic>
 #include <new>
 #include <string>
 #include <vector>
@@ -1216,20 +1217,24 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
 // ------------------------------------------------------------------------------------------------
 namespace {
 inline dim3 grid1d(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+// slot of the loss kernels' partial-sum table for this call (handed out in turn: VJF_LOSS_SLOTS calls may be in flight)
+inline int loss_slot() { static std::atomic<unsigned> next{0}; return (int)(next.fetch_add(1u, std::memory_order_relaxed) % VJF_LOSS_SLOTS); }
 
 struct VjfPredArgs {
     const float* x; const float* c; const float* logw; const float* w_mean; const float* w_chol;
     float* mean; float* logvar; int B, n, d, dout;
 };
-// 8 trials per workgroup: features in LDS, then Phi W (mean) and the row norm of Phi w_chol (logvar).
+// 16 trials per workgroup: features feature-major in LDS ([feature][17], as the fused kernels hold them), then Phi W (mean)
+// and the row norm of Phi w_chol (logvar) as 16 x 16 output tiles on v_mfma_f32_16x16x4_f32 (mma_tile: the matrices are k-major
+// for these products), one tile per wavefront and round.
 __global__ __launch_bounds__(VJF_K1_THREADS) void vjf_blr_predict_kernel(VjfPredArgs A) {
-    constexpr int TB = 8;
+    constexpr int TB = 16, LD = VJF_LDT, NW = VJF_K1_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_phi = smem;                 // TB x n
-    float* s_red = s_phi + TB * A.n;     // 4 x TB
-    const int tid = threadIdx.x, b0 = blockIdx.x * TB, nb = min(TB, A.B - b0);
+    float* s_phi = smem;                 // n x LD
+    float* s_red = s_phi + A.n * LD;     // NW x TB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b0 = blockIdx.x * TB, nb = min(TB, A.B - b0);
     for (int i = tid; i < TB * A.n; i += VJF_K1_THREADS) {
-        const int b = i / A.n, k = i - b * A.n;
+        const int k = i / TB, b = i - k * TB;
         float ph = 0.f;
         if (b < nb) {
             float d2 = 0.f;
@@ -1237,33 +1242,37 @@ __global__ __launch_bounds__(VJF_K1_THREADS) void vjf_blr_predict_kernel(VjfPred
             const float w = expf(A.logw[k]);
             ph = expf(-0.5f * d2 / (w * w));
         }
-        s_phi[i] = ph;
+        s_phi[k * LD + b] = ph;
     }
     __syncthreads();
+    const int col = lane & 15, r4 = 4 * (lane >> 4);     // accumulator: row = r4 + r (output), column = trial
     if (A.mean)
-        dense_nn<TB>(A.w_mean, A.n, A.dout, s_phi, A.n, [&](int j, const float* acc) {
+        for (int t = wave; t * 16 < A.dout; t += NW) {
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile(acc, A.w_mean, A.dout, A.dout, t * 16, s_phi, A.n, lane);
 #pragma unroll
-            for (int b = 0; b < TB; ++b) if (b < nb) A.mean[(size_t)(b0 + b) * A.dout + j] = acc[b];
-        });
+            for (int r = 0; r < 4; ++r) {
+                const int j = t * 16 + r4 + r;
+                if (j < A.dout && col < nb) A.mean[(size_t)(b0 + col) * A.dout + j] = acc[r];
+            }
+        }
     if (!A.logvar) return;
-    float v2[TB];
+    float v2 = 0.f;                                      // this lane's share of sum_j Z[trial col][j]^2
+    for (int t = wave; t * 16 < A.n; t += NW) {
+        vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mma_tile(acc, A.w_chol, A.n, A.n, t * 16, s_phi, A.n, lane);
 #pragma unroll
-    for (int b = 0; b < TB; ++b) v2[b] = 0.f;
-    dense_nn<TB>(A.w_chol, A.n, A.n, s_phi, A.n, [&](int, const float* acc) {
-#pragma unroll
-        for (int b = 0; b < TB; ++b) v2[b] = fmaf(acc[b], acc[b], v2[b]);
-    });
-#pragma unroll
-    for (int b = 0; b < TB; ++b) {
-        float v = v2[b];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if ((tid & 63) == 0) s_red[(tid >> 6) * TB + b] = v;
+        for (int r = 0; r < 4; ++r) v2 = fmaf(acc[r], acc[r], v2);      // (rows beyond n are exact zeros)
     }
+    v2 += __shfl_xor(v2, 16, 64);                        // the four row groups of a column, fixed order
+    v2 += __shfl_xor(v2, 32, 64);
+    if (lane < 16) s_red[wave * TB + lane] = v2;
     __syncthreads();
     for (int i = tid; i < nb * A.dout; i += VJF_K1_THREADS) {
         const int b = i / A.dout;
-        A.logvar[(size_t)(b0 + b) * A.dout + (i - b * A.dout)] = logf(((s_red[b] + s_red[TB + b]) + s_red[2 * TB + b]) + s_red[3 * TB + b]);
+        float v = s_red[b];
+        for (int w = 1; w < NW; ++w) v += s_red[w * TB + b];
+        A.logvar[(size_t)(b0 + b) * A.dout + (i - b * A.dout)] = logf(v);
     }
 }
 
@@ -1274,15 +1283,16 @@ struct VjfRecArgs {
     float* mu_t; float* lv_t;
     int B, dy, du, dz, L; int h[VJF_MAX_HIDDEN];
 };
-// Recognition.forward for 8 trials per workgroup, activations ping-pong in LDS.
+// Recognition.forward for 16 trials per workgroup: activations feature-major in LDS (ping-pong), every layer as 16 x 16 output
+// tiles on v_mfma_f32_16x16x4_f32 with the weights read as torch stores them (mma_tile<true>).
 __global__ __launch_bounds__(VJF_K1_THREADS) void vjf_recognition_kernel(VjfRecArgs A, int hmax) {
-    constexpr int TB = 8;
+    constexpr int TB = 16, LD = VJF_LDT, NW = VJF_K1_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int din = A.dy + A.du + 2 * A.dz;
-    float* s_in = smem;                  // TB x din
-    float* s_a = s_in + TB * din;        // TB x hmax
-    float* s_b = s_a + TB * hmax;        // TB x hmax
-    const int tid = threadIdx.x, b0 = blockIdx.x * TB, nb = min(TB, A.B - b0);
+    float* s_in = smem;                  // din x LD
+    float* s_a = s_in + din * LD;        // hmax x LD
+    float* s_b = s_a + hmax * LD;        // hmax x LD
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b0 = blockIdx.x * TB, nb = min(TB, A.B - b0);
     for (int i = tid; i < TB * din; i += VJF_K1_THREADS) {
         const int b = i / din, c = i - b * din;
         float v = 0.f;
@@ -1293,32 +1303,43 @@ __global__ __launch_bounds__(VJF_K1_THREADS) void vjf_recognition_kernel(VjfRecA
             else if (c < A.dy + A.du + A.dz) v = A.mu_s[g * A.dz + c - A.dy - A.du];
             else v = A.lv_s[g * A.dz + c - A.dy - A.du - A.dz];
         }
-        s_in[i] = v;
+        s_in[c * LD + b] = v;
     }
     __syncthreads();
+    const int col = lane & 15, r4 = 4 * (lane >> 4);     // accumulator: row = r4 + r (output unit), column = trial
     const float* xin = s_in; int kin = din;
     float* cur = s_a; float* nxt = s_b;
     for (int l = 0; l < A.L; ++l) {
         const int hl = A.h[l];
         const float* bias = A.b[l];
-        dense_nt<TB>(A.W[l], hl, kin, xin, kin, [&](int f, const float* acc) {
-            const float bf = bias[f];
+        for (int t = wave; t * 16 < hl; t += NW) {
+            vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mma_tile<true>(acc, A.W[l], kin, hl, t * 16, xin, kin, lane);
 #pragma unroll
-            for (int b = 0; b < TB; ++b) cur[b * hl + f] = tanhf(acc[b] + bf);
-        });
+            for (int r = 0; r < 4; ++r) {
+                const int f = t * 16 + r4 + r;
+                if (f < hl) cur[f * LD + col] = tanhf(acc[r] + bias[f]);
+            }
+        }
         __syncthreads();
         xin = cur; kin = hl;
         float* t = cur; cur = nxt; nxt = t;
     }
-    dense_nt<TB>(A.mean_W, A.dz, kin, xin, kin, [&](int f, const float* acc) {
+    const int nt = (A.dz + 15) / 16;                         // tiles per head; the wavefronts take mean tiles, then log-variance tiles
+    for (int t = wave; t < 2 * nt; t += NW) {
+        const bool lvh = t >= nt;
+        const int f0 = (lvh ? t - nt : t) * 16;
+        vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mma_tile<true>(acc, lvh ? A.lv_W : A.mean_W, kin, A.dz, f0, xin, kin, lane);
 #pragma unroll
-        for (int b = 0; b < TB; ++b) if (b < nb) A.mu_t[(size_t)(b0 + b) * A.dz + f] = acc[b];
-    });
-    dense_nt<TB>(A.lv_W, A.dz, kin, xin, kin, [&](int f, const float* acc) {
-        const float bf = A.lv_b[f];
-#pragma unroll
-        for (int b = 0; b < TB; ++b) if (b < nb) A.lv_t[(size_t)(b0 + b) * A.dz + f] = acc[b] + bf;
-    });
+        for (int r = 0; r < 4; ++r) {
+            const int f = f0 + r4 + r;
+            if (f < A.dz && col < nb) {
+                if (lvh) A.lv_t[(size_t)(b0 + col) * A.dz + f] = acc[r] + A.lv_b[f];
+                else A.mu_t[(size_t)(b0 + col) * A.dz + f] = acc[r];
+            }
+        }
+    }
 }
 
 // features + target rows of the stand-alone RLS:  E[b] = [Phi(x_b) | target_b | 0]
@@ -1377,7 +1398,10 @@ int vjf_rbf_forward(const float* x, const float* centroid, const float* logwidth
                     void* stream) {
     if (!x || !centroid || !logwidth || !out) return fail(-1, "vjf_rbf_forward: null tensor");
     if (B < 1 || n < 1 || d < 1) return fail(-20, "vjf_rbf_forward: bad shape");
-    hipLaunchKernelGGL(vjf_rbf_kernel, grid1d((size_t)B * n), dim3(256), 0, (hipStream_t)stream, x, centroid, logwidth, out, B, n, d);
+    const size_t lds = (size_t)16 * d * 4;
+    if (lds > kMaxLds - 1024) return fail(-11, "vjf_rbf_forward: d=%d too large", d);
+    allow_lds(vjf_rbf_kernel, lds);
+    hipLaunchKernelGGL(vjf_rbf_kernel, dim3((n + 255) / 256, (B + 15) / 16), dim3(256), lds, (hipStream_t)stream, x, centroid, logwidth, out, B, n, d);
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -1386,11 +1410,11 @@ int vjf_blr_predict(const float* x, const float* centroid, const float* logwidth
                     float* mean, float* logvar, int32_t B, int32_t n, int32_t d, int32_t dout, void* stream) {
     if (!x || !centroid || !logwidth || !w_mean || !w_chol) return fail(-1, "vjf_blr_predict: null tensor");
     if (B < 1 || n < 1 || d < 1 || dout < 1) return fail(-20, "vjf_blr_predict: bad shape");
-    const size_t lds = (size_t)(8 * n + 32) * 4;
+    const size_t lds = ((size_t)n * VJF_LDT + 64) * 4;
     if (lds > kMaxLds - 1024) return fail(-11, "vjf_blr_predict: n=%d too large", n);
     allow_lds(vjf_blr_predict_kernel, lds);
     VjfPredArgs a{x, centroid, logwidth, w_mean, w_chol, mean, logvar, B, n, d, dout};
-    hipLaunchKernelGGL(vjf_blr_predict_kernel, dim3((B + 7) / 8), dim3(VJF_K1_THREADS), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(vjf_blr_predict_kernel, dim3((B + 15) / 16), dim3(VJF_K1_THREADS), lds, (hipStream_t)stream, a);
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -1401,13 +1425,18 @@ int vjf_blr_sample(const float* x, const float* centroid, const float* logwidth,
     if (B < 1 || n < 1 || d < 1 || dout < 1) return fail(-20, "vjf_blr_sample: bad shape");
     hipStream_t s = (hipStream_t)stream;
     // w = w_mean + w_chol @ noise   (module.py:71)
-    hipLaunchKernelGGL(vjf_matmul_nn_kernel, grid1d((size_t)n * dout), dim3(256), 0, s, w_chol, noise, w_mean, w_scratch, n, n, dout);
+    {
+        VjfWideGemm g{};
+        g.A = w_chol; g.lda = n; g.Bm = noise; g.ldb = dout; g.C = w_scratch; g.ldc = dout; g.M = n; g.N = dout; g.K = n;
+        g.epi = WEPI_ADD_SRC; g.src = w_mean; g.lds = dout; g.src_scale = 1.f;
+        launch_wide_gemm(g, s);
+    }
     VJF_HIP(hipGetLastError());
-    const size_t lds = (size_t)(8 * n + 32) * 4;
+    const size_t lds = ((size_t)n * VJF_LDT + 64) * 4;
     if (lds > kMaxLds - 1024) return fail(-11, "vjf_blr_sample: n=%d too large", n);
     allow_lds(vjf_blr_predict_kernel, lds);
     VjfPredArgs a{x, centroid, logwidth, w_scratch, w_chol, out, nullptr, B, n, d, dout};
-    hipLaunchKernelGGL(vjf_blr_predict_kernel, dim3((B + 7) / 8), dim3(VJF_K1_THREADS), lds, s, a);
+    hipLaunchKernelGGL(vjf_blr_predict_kernel, dim3((B + 15) / 16), dim3(VJF_K1_THREADS), lds, s, a);
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -1519,10 +1548,10 @@ int vjf_recognition_forward(const float* y, const float* u, const float* mu_s, c
     a.B = B; a.dy = ydim; a.du = udim; a.dz = xdim; a.L = n_hidden;
     int hmax = 0;
     for (int l = 0; l < n_hidden; ++l) { a.W[l] = rec_W[l]; a.b[l] = rec_b[l]; a.h[l] = hidden[l]; if (hidden[l] > hmax) hmax = hidden[l]; }
-    const size_t lds = (size_t)8 * (ydim + udim + 2 * xdim + 2 * hmax) * 4;
+    const size_t lds = (size_t)VJF_LDT * (ydim + udim + 2 * xdim + 2 * hmax) * 4;
     if (lds > kMaxLds - 1024) return fail(-10, "vjf_recognition_forward: layer widths do not fit LDS");
     allow_lds(vjf_recognition_kernel, lds);
-    hipLaunchKernelGGL(vjf_recognition_kernel, dim3((B + 7) / 8), dim3(VJF_K1_THREADS), lds, (hipStream_t)stream, a, hmax);
+    hipLaunchKernelGGL(vjf_recognition_kernel, dim3((B + 15) / 16), dim3(VJF_K1_THREADS), lds, (hipStream_t)stream, a, hmax);
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -1531,7 +1560,7 @@ int vjf_gaussian_loss(const float* m1, const float* lv1, const float* m2, const 
                       int32_t B, int32_t d, void* stream) {
     if (!m1 || !m2 || !logvar || !out) return fail(-1, "vjf_gaussian_loss: null tensor");
     if (B < 1 || d < 1) return fail(-20, "vjf_gaussian_loss: bad shape");
-    hipLaunchKernelGGL(vjf_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, 0, m1, lv1, m2, lv2, logvar, out, B, d);
+    hipLaunchKernelGGL(vjf_loss_kernel, dim3(VJF_LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, 0, m1, lv1, m2, lv2, logvar, out, B, d, loss_slot());
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -1539,8 +1568,8 @@ int vjf_gaussian_loss(const float* m1, const float* lv1, const float* m2, const 
 int vjf_gaussian_entropy(const float* lv, float* out, int32_t B, int32_t d, void* stream) {
     if (!lv || !out) return fail(-1, "vjf_gaussian_entropy: null tensor");
     if (B < 1 || d < 1) return fail(-20, "vjf_gaussian_entropy: bad shape");
-    hipLaunchKernelGGL(vjf_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, 1, lv, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, out, B, d);
+    hipLaunchKernelGGL(vjf_loss_kernel, dim3(VJF_LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, 1, lv, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, out, B, d, loss_slot());
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -1548,8 +1577,8 @@ int vjf_gaussian_entropy(const float* lv, float* out, int32_t B, int32_t d, void
 int vjf_poisson_loss(const float* eta, const float* target, float* out, int32_t B, int32_t d, void* stream) {
     if (!eta || !target || !out) return fail(-1, "vjf_poisson_loss: null tensor");
     if (B < 1 || d < 1) return fail(-20, "vjf_poisson_loss: bad shape");
-    hipLaunchKernelGGL(vjf_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, 2, eta, (const float*)nullptr, target,
-                       (const float*)nullptr, (const float*)nullptr, out, B, d);
+    hipLaunchKernelGGL(vjf_loss_kernel, dim3(VJF_LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, 2, eta, (const float*)nullptr, target,
+                       (const float*)nullptr, (const float*)nullptr, out, B, d, loss_slot());
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -1557,7 +1586,10 @@ int vjf_poisson_loss(const float* eta, const float* target, float* out, int32_t 
 int vjf_linear_forward(const float* x, const float* W, const float* b, float* out, int32_t B, int32_t din, int32_t dout, void* stream) {
     if (!x || !W || !out) return fail(-1, "vjf_linear_forward: null tensor");
     if (B < 1 || din < 1 || dout < 1) return fail(-20, "vjf_linear_forward: bad shape");
-    hipLaunchKernelGGL(vjf_linear_kernel, grid1d((size_t)B * dout), dim3(256), 0, (hipStream_t)stream, x, din, W, b, out, B, din, dout, 0);
+    VjfWideGemm g{};                                       // out = x W^T + b on the matrix cores (vjf_trial_wide.h)
+    g.A = x; g.lda = din; g.Bm = W; g.ldb = din; g.nt = 1; g.C = out; g.ldc = dout; g.M = B; g.N = dout; g.K = din;
+    g.epi = b ? WEPI_BIAS : WEPI_NONE; g.bias = b;
+    launch_wide_gemm(g, (hipStream_t)stream);
     VJF_HIP(hipGetLastError());
     return 0;
 }

@@ -23,41 +23,46 @@ typedef float vjf_f32x4 __attribute__((ext_vector_type(4)));
 
 // acc(row = 4*(lane>>4)+r, col = lane&15) += sum_{k<K} Ag[k*lda + m0 + row] * Xs[k*17 + col]
 // rows m0+i >= M contribute 0.
-__device__ __forceinline__ void mma_tile(vjf_f32x4& acc, const float* __restrict__ Ag, int lda, int M, int m0,
+// (NT: the matrix as torch stores a Linear weight, A[m][k] = Ag[m * lda + k], instead of k-major -- the stand-alone operators)
+template <bool NT = false>
+__device__ __forceinline__ void mma_tile(vjf_f32x4& acc, const float* __restrict__ Ag, int lda_, int M, int m0,
                                          const float* Xs, int K, int lane) {
     const int i = lane & 15, kk = lane >> 4;
     const bool rv = (m0 + i) < M;
-    const float* ap = Ag + m0 + i + (size_t)kk * lda;
+    const size_t lda = NT ? 1 : (size_t)lda_;            // distance of two k
+    // (rows beyond M: read from a valid address and masked where the value is USED -- a select right behind a load makes the
+    //  compiler wait for the load there, and the next batch would not be in flight beside this batch's MFMAs)
+    const float* ap = Ag + (size_t)(rv ? m0 + i : 0) * (NT ? (size_t)lda_ : 1) + (size_t)kk * lda;
     const float* xp = Xs + kk * VJF_LDT + i;
     const int K32 = K & ~31;
     int k0 = 0;
     if (K32 > 0) {                                     // batches of 8 steps, the next batch's 16 operand loads in flight
         float a0[8], x0[8], a1[8], x1[8];              // while the current batch's MFMAs issue
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { a0[q] = rv ? ap[(size_t)(4 * q) * lda] : 0.f; x0[q] = xp[(4 * q) * VJF_LDT]; }
+        for (int q = 0; q < 8; ++q) { a0[q] = ap[(size_t)(4 * q) * lda]; x0[q] = xp[(4 * q) * VJF_LDT]; }
         for (; k0 < K32; k0 += 64) {
             const bool more1 = k0 + 32 < K32;
             if (more1) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { a1[q] = rv ? ap[(size_t)(k0 + 32 + 4 * q) * lda] : 0.f; x1[q] = xp[(k0 + 32 + 4 * q) * VJF_LDT]; }
+                for (int q = 0; q < 8; ++q) { a1[q] = ap[(size_t)(k0 + 32 + 4 * q) * lda]; x1[q] = xp[(k0 + 32 + 4 * q) * VJF_LDT]; }
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], x0[q], acc, 0, 0, 0);
+            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rv ? a0[q] : 0.f, x0[q], acc, 0, 0, 0);
             if (!more1) { k0 += 32; break; }
             const bool more0 = k0 + 64 < K32;
             if (more0) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { a0[q] = rv ? ap[(size_t)(k0 + 64 + 4 * q) * lda] : 0.f; x0[q] = xp[(k0 + 64 + 4 * q) * VJF_LDT]; }
+                for (int q = 0; q < 8; ++q) { a0[q] = ap[(size_t)(k0 + 64 + 4 * q) * lda]; x0[q] = xp[(k0 + 64 + 4 * q) * VJF_LDT]; }
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], x1[q], acc, 0, 0, 0);
+            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rv ? a1[q] : 0.f, x1[q], acc, 0, 0, 0);
             if (!more0) { k0 += 64; break; }
         }
     }
     // remainder (< 32 rows): its up to 8 steps' operands in flight together (clamped addresses, masked at use), then the same
     // MFMA steps in the same order as a step-by-step loop would issue them
     if (k0 < K) {
-        const float* apc = Ag + (rv ? m0 + i : 0) + (size_t)kk * lda;   // (rows beyond M: a valid address, masked below)
+        const float* apc = ap;                                          // (rows beyond M: a valid address, masked below)
         float ar[8], xr[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
