@@ -675,3 +675,29 @@ def test_results_do_not_depend_on_workspace_contents(vjf, monkeypatch, overlap):
     for a, b in zip(outs[0], outs[1]):
         assert np.isfinite(a).all()
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_gemm_dispatcher_shapes_against_fp64(vjf):
+    """The GEMM kernels of the wide route behind `vjf_linear_forward` (out = x W^T + b through the C ABI), over the shapes that
+    pick each of them and their edges: narrow outputs (K-split 32 x 32 tiles), 128 x 64 and 128 x 128 tiles with two LDS images,
+    the 64 x 64 kernel for small / unaligned operands; M, N, K off the tile sizes; K not a multiple of 4 (float-by-float path)."""
+    from vjf_amd import _native as N
+    from vjf_amd.util import stream_ptr
+    g = torch.Generator().manual_seed(123)
+    shapes = [(300, 640, 512), (257, 96, 65), (4096, 64, 512), (1000, 1000, 64), (1024, 1000, 1000), (513, 200, 300),
+              (33, 7, 5), (100, 37, 64), (256, 130, 256), (2000, 33, 129), (16, 512, 512), (384, 1000, 40), (4096, 10, 50)]
+    for (B, din, dout) in shapes:
+        x = torch.randn(B, din, generator=g)
+        W = torch.randn(dout, din, generator=g) / din ** 0.5
+        b = torch.randn(dout, generator=g)
+        xd, Wd, bd = x.cuda(), W.cuda(), b.cuda()
+        out = torch.empty(B, dout, device="cuda")
+        N.check(N.lib().vjf_linear_forward(N.ptr(xd), N.ptr(Wd), N.ptr(bd), N.ptr(out), B, din, dout, stream_ptr()), "vjf_linear_forward")
+        ref = (x.double() @ W.double().T + b.double())
+        err = (out.cpu().double() - ref).abs().max().item()
+        scale = (x.double().abs() @ W.double().abs().T).max().item()
+        assert err <= 4e-7 * scale + 1e-6, (B, din, dout, err, scale)
+        out2 = torch.empty(B, dout, device="cuda")                         # no bias
+        N.check(N.lib().vjf_linear_forward(N.ptr(xd), N.ptr(Wd), None, N.ptr(out2), B, din, dout, stream_ptr()), "vjf_linear_forward")
+        assert ((out2.cpu().double() - (ref - b.double())).abs().max().item()) <= 4e-7 * scale + 1e-6, (B, din, dout)
