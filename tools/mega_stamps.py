@@ -7,9 +7,10 @@ from vjf_amd import _native as N
 torch.manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-dz, dy, n = 10, 50, 200
-m = vjf_amd.VJF.make_model(dy, dz, 0, n, [128], likelihood="gaussian", noise="device")
-y = torch.randn(T + 8, B, dy, device="cuda")
+cfgC = os.environ.get("CFG", "B") == "C"                   # CFG=C: BASELINE configs[2] (Poisson, d_y = 200)
+dz, dy, n = (10, 200, 200) if cfgC else (10, 50, 200)
+m = vjf_amd.VJF.make_model(dy, dz, 0, n, [128], likelihood="poisson" if cfgC else "gaussian", noise="device")
+y = torch.poisson(torch.rand(T + 8, B, dy, device="cuda")) if cfgC else torch.randn(T + 8, B, dy, device="cuda")
 m.filter_sequence(y[:8])
 N.check(m._backend().vjf_debug_stamps(m._ctx, 2, None))
 m.filter_sequence(y[8:])
@@ -34,7 +35,8 @@ for t in range(max(0, T - 6), T):
     o = (ctypes.c_uint64 * 32)()
     N.check(m._backend().vjf_debug_stamps(m._ctx, 16 + ((t + 1) & 7), o))      # RLS loops: ring entry = epoch % 8, epoch = step + 1
     R = list(o)
-    for nm, i in (("chol: step start (stat wait)", 0), ("chol: operands + sigma there, chain starts", 1), ("chol: factor done", 2),
+    for nm, i in (("chol: step start (stat wait)", 0), ("chol: operands + sigma there, chain starts", 1), ("chol: factor done", 2), ("chol: column 0 panel done (before the barrier)", 8), ("chol: column 0 panel barrier passed", 3),
+                  ("chol: column 0, block (1,1) updated", 4), ("chol: column 0, chain of block (1,1) done", 5),
                   ("y/W: first column staged", 17), ("y/W: forward done, factor good, trial readers done", 18), ("y/W: backward done", 19),
                   ("y/W: W stored", 20), ("y/W: sigma stored", 21), ("inverse loops: LAST one done", 22)):
         if R[i]:

@@ -631,9 +631,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         //      All loads of a thread are issued before its first LDS store.
         auto diag_chain = [&](int k) {                                  // L_kk and L_kk^-1 in one chain (one wavefront)
             float* dk = s_blk + (size_t)vtri(k, k) * 1024;
-            __builtin_amdgcn_s_setprio(3);                              // the serial chain wins issue slots over the wavefront it shares a SIMD with
             if (!potrf_inv_chain2(dk, s_aux + (size_t)k * 1024, lane) && lane == 0) s_flag[0] = 0;
-            __builtin_amdgcn_s_setprio(0);
         };
         auto pad4 = [](int gi, int gj) {                                // identity padding outside the matrix
             return make_float4(gi == gj ? 1.f : 0.f, gi == gj + 1 ? 1.f : 0.f, gi == gj + 2 ? 1.f : 0.f, gi == gj + 3 ? 1.f : 0.f);

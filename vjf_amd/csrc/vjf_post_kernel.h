@@ -217,6 +217,27 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
     __syncthreads();
 
     float gpre[4][16], fpre[8];
+    // weights of this lane's tile entries in tr(W^T G W) = sum_ij G_ij (W W^T)_ij over the lower triangle: 2 below the diagonal,
+    // 1 on it, 0 above it and outside the matrix -- two bits per entry, formed here (nothing waits on this workgroup yet) and
+    // not in the tail behind W, where every instruction is on the path to the next step's factorisation
+    unsigned wbits[4];
+    {
+        const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = wave + 8 * q;
+            unsigned wq = 0u;
+            if (solve && t < ntri) {
+                const int code = s_tab[32 + t], bi = code >> 8, bj = code & 255;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gi = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, gj = bj * 32 + c;
+                    wq |= ((gi >= n || gj > gi) ? 0u : (gj == gi ? 1u : 2u)) << (2 * r);
+                }
+            }
+            wbits[q] = wq;
+        }
+    }
     // the tail's operands, fetched early so that it does not wait for them: the tiles of G once the Cholesky loop has started on
     // this step (its first column flag: the Gram role's sums were complete before it began) ...
     auto prefetch_G = [&]() {
@@ -482,16 +503,14 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
                     wa[k] = s_x[(bi * 32 + c) * LX + 2 * k + h];
                     wb[k] = s_x[(bj * 32 + c) * LX + 2 * k + h];
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (2 * k < dz) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[k], wb[k], acc, 0, 0, 0);   // (uniform branch)
                 double tp = 0.0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {                 // accumulator: row = (r&3) + 8*(r>>2) + 4*h, column = c
-                    const int gi = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, gj = bj * 32 + c;
-                    const float wgt = (gi >= n || gj > gi) ? 0.f : (gj == gi ? 1.f : 2.f);
-                    tp += (double)(wgt * gpre[q][r]) * (double)acc[r];
+                    const float wgt = (float)((wbits[q] >> (2 * r)) & 3u);
+                    tp += (double)((wgt * gpre[q][r]) * acc[r]);   // (one fp32 rounding per product; the SUMS are fp64)
                 }
                 part += tp;
             }
@@ -501,6 +520,7 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
             const int e = tid + q * VJF_POST_THREADS, r = e >> 4, cc = e & 15;
             if (r < n && cc < dz) part -= 2.0 * (double)s_x[r * LX + cc] * (double)fpre[q];
         }
+
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
         if (lane == 0) s_p[wave] = part;
