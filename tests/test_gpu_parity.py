@@ -212,6 +212,8 @@ CASES = [
     dict(B=32, dz=20, dy=30, du=0, n=96, hidden=[32], lik="gaussian", T=3),          # 16 < dz <= 32: LDS Cholesky kernel with its own inverse / solve
     dict(B=24, dz=40, dy=16, du=0, n=64, hidden=[16], lik="gaussian", T=2),          # dz > 32, small n: single-workgroup serial kernel
     dict(B=20, dz=40, dy=16, du=2, n=260, hidden=[16], lik="poisson", T=2),          # dz > 32, n > 224: multi-launch RLS, wide latent
+    dict(B=52, dz=7, dy=11, du=1, n=250, hidden=[20], lik="gaussian", T=3),          # multi-launch RLS with n % 4 != 0: float-by-float operand paths, K tails
+    dict(B=300, dz=9, dy=301, du=0, n=1210, hidden=[401], lik="gaussian", T=2),      # GEMM-per-layer trial path, every extent off the tile sizes, unaligned rows
 ]
 
 
