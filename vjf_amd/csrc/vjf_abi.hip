@@ -171,9 +171,7 @@ bool mega_plan_ok(const VjfPlan& P) {
 
 bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
     // one workgroup per compute unit: the RLS loops and the operand role have fixed sizes; the trial role gets 128 / 227 of the
-    // rest (one 32-trial tile per workgroup at 256 CUs and 4096 trials), the SGD role one 8-lane group per quad of parameters when
-    // what is left allows it beside a Gram role that takes its rows in one pass of 96 (a single round of slab loads per step), the
-    // Gram role whatever remains
+    // rest (one 32-trial tile per workgroup at 256 CUs and 4096 trials), then the SGD role (below), the Gram role whatever remains
     const int nbl = (P.n + 31) / 32;
     m->n_rls = 2 + 2 * nbl;
     m->n_prep = (P.n + 15) / 16;
@@ -185,12 +183,19 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
     if (cap_t > kMegaMaxTrialWg) cap_t = kMegaMaxTrialWg;
     m->n_trial = m->ntiles < cap_t ? m->ntiles : cap_t;
     const int left = rest - m->n_trial;                                               // >= 2
-    int gram_min = (B + VJF_MG_GROWS - 1) / VJF_MG_GROWS;                              // (one pass of rows per Gram workgroup)
-    if (gram_min > left / 2) gram_min = left / 2;
-    if (gram_min < 1) gram_min = 1;
-    m->n_sgd = ((vjf_mega_slab_layout(P).len / 4) * 8 + VJF_MG_THREADS - 1) / VJF_MG_THREADS;   // 8 lanes per quad of the late slab
-    if (m->n_sgd > left - gram_min) m->n_sgd = left - gram_min;
-    if (m->n_sgd > 64) m->n_sgd = 64;
+    // SGD role: one 8-lane group per quad of the late slab and ROUND of slab loads; its time is the bytes of the slabs over the
+    // compute units it has (a unit takes in ~33 GB/s of slabs written on other XCDs), so the fewest rounds win.  The Gram role
+    // runs a step ahead with slack: if a second pass of rows per Gram workgroup (fewer of them) saves the SGD role a round, take
+    // it; the SGD role then gets just the workgroups that round count needs, the Gram role the rest.
+    const int quads = vjf_mega_slab_layout(P).len / 4, gpw = VJF_MG_THREADS / 8;          // lane groups per workgroup
+    auto rounds = [&](int nwg) { return (quads + gpw * nwg - 1) / (gpw * nwg); };
+    auto clampg = [&](int g) { if (g > left / 2) g = left / 2; return g < 1 ? 1 : g; };
+    const int want = (quads + gpw - 1) / gpw;
+    const int g1 = clampg((B + VJF_MG_GROWS - 1) / VJF_MG_GROWS), g2 = clampg((B + 2 * VJF_MG_GROWS - 1) / (2 * VJF_MG_GROWS));
+    const int n1 = want < left - g1 ? want : left - g1, n2 = want < left - g2 ? want : left - g2;
+    const int r = rounds(n2 < 1 ? 1 : n2) < rounds(n1 < 1 ? 1 : n1) ? rounds(n2 < 1 ? 1 : n2) : rounds(n1 < 1 ? 1 : n1);
+    m->n_sgd = (quads + gpw * r - 1) / (gpw * r);                                         // the fewest workgroups with that many rounds
+    if (m->n_sgd > left - g2) m->n_sgd = left - g2;
     if (m->n_sgd < 1) m->n_sgd = 1;
     m->n_gram = (B + 63) / 64;
     if (m->n_gram > left - m->n_sgd) m->n_gram = left - m->n_sgd;
