@@ -669,7 +669,8 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
             launch_wide_gemm(g, st);
         };
         const int gx = 1024;
-        if (!a.replay) {                                           // (forward products: what the backward half reads stays in place)
+        // part 1: everything up to the decoder (no use of W, w_chol, sigma); part 2: predictive moments, losses, backward; 0: both
+        if (!a.replay && part != 2) {                              // (a replay: what the backward half reads stays in place)
         hipLaunchKernelGGL(vjf_wide_in_kernel, dim3(a.B < 2048 ? a.B : 2048), dim3(256), 0, st, P, w);
         hipLaunchKernelGGL(vjf_wide_rbf_kernel, dim3((P.n + 255) / 256, (a.B + 15) / 16), dim3(256), (size_t)16 * P.dxu * 4, st, P, w);
         int kin = P.din;
@@ -682,6 +683,9 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
         gemm(a.ACT + P.colA_act[P.L], P.ldA, S + P.off[VJF_SLOT_LV_W], kin, a.lv_t, P.dz, P.dz, kin, 1, WEPI_BIAS, S + P.off[VJF_SLOT_LV_B]);
         hipLaunchKernelGGL(vjf_wide_mid_kernel, dim3(gx), dim3(256), 0, st, P, w);
         gemm(a.ACT + P.colA_xt, P.ldA, S + P.off[VJF_SLOT_DEC_W], P.dz, w.PY, P.dy, P.dy, P.dz, 1, WEPI_BIAS, S + P.off[VJF_SLOT_DEC_B]);
+        }
+        if (part == 1) { VJF_HIP(hipGetLastError()); return 0; }
+        if (!a.replay) {
         gemm(a.E, P.ldE, S + P.off[VJF_SLOT_W_MEAN], P.dz, w.PM, P.dz, P.dz, P.n, 0, WEPI_ADD_SRC, nullptr, w.XU, P.dxu);
         gemm(a.E, P.ldE, S + P.off[VJF_SLOT_W_CHOL], P.n, w.Z, P.n, P.n, P.n, 0, WEPI_NONE);
         }
@@ -1017,6 +1021,58 @@ int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, cons
 }
 
 namespace {
+// The RLS update for feature counts beyond one compute unit's LDS (vjf_rlsb_kernels.h) and the state-noise update, on stream `st`
+int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st) {
+    const VjfPlan& P = c->plan;
+    const int nbl = (P.n + 31) / 32;
+    float* work = (float*)(c->ws + c->cv.work);
+    VjfRlsbArgs a{};
+    a.state = c->state; a.red = red; a.Lw = (float*)(c->ws + c->cv.lscr);
+    a.X = work; a.gbuf = work + (size_t)P.n * P.n; a.ybuf = a.gbuf + (size_t)P.n * P.dz;
+    a.Dinv = (float*)(c->ws + c->cv.post);
+    a.Ld = (float*)(c->ws + c->cv.tbig);
+    a.Pacc = a.Ld + (size_t)nbl * 1024;
+    a.ok = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
+    const bool rls = !(flags & VJF_FLAG_WARM_UP);
+    if (rls) {
+        const int gx = 512;
+        auto gemm = [&](const float* A_, int lda, int ta, const float* Bm, int ldb, float* C_, int ldc, int M, int N, int K, const int* ok) {
+            VjfWideGemm g{};
+            g.A = A_; g.lda = lda; g.ta = ta; g.Bm = Bm; g.ldb = ldb; g.C = C_; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.nt = 0;
+            g.epi = WEPI_NONE; g.ok = ok;
+            launch_wide_gemm(g, st);
+        };
+        const float* Sx = c->state;
+        gemm(Sx + P.off[VJF_SLOT_W_PREC], P.n, 0, Sx + P.off[VJF_SLOT_W_MEAN], P.dz, a.gbuf, P.dz, P.n, P.dz, P.n, nullptr);   // P W
+        hipLaunchKernelGGL(vjf_rlsb_prep_kernel, dim3(gx), dim3(256), 0, st, P, a);
+        // block column k of L and block row k - 1 of X = L^-1 per launch (the block-upper part of X stays zero: the solves
+        // below read all of it)
+        VJF_HIP(hipMemsetAsync(a.X, 0, (size_t)P.n * P.n * 4, st));
+        for (int k = 0; k <= nbl; ++k) {
+            a.k = k;
+            const int ncol = nbl - k, grid = ncol + (ncol > 1 ? ncol - 1 : 0) + (k > 1 ? k - 1 : 0);
+            hipLaunchKernelGGL(vjf_rlsc_col_kernel, dim3(grid), dim3(VJF_RLSC_THREADS), 0, st, P, a);
+        }
+        gemm(a.X, P.n, 0, a.gbuf, P.dz, a.ybuf, P.dz, P.n, P.dz, P.n, a.ok);                                      // y = X g
+        gemm(a.X, P.n, 1, a.ybuf, P.dz, c->state + P.off[VJF_SLOT_W_MEAN], P.dz, P.n, P.dz, P.n, a.ok);          // W = X^T y
+        hipLaunchKernelGGL(vjf_rlsb_final_kernel, dim3(gx), dim3(256), 0, st, P, a);
+        VJF_HIP(hipGetLastError());
+    }
+    VjfResidArgs ra{};
+    ra.state = c->state; ra.red = red; ra.partial = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
+    ra.B_total = B_total; ra.flags = flags;
+    {   // state-noise update (model.py:373-377): T = G W with the GEMM kernel (y's buffer is free again), contraction in fp64
+        VjfWideGemm g{};
+        g.A = red + P.red_G; g.lda = P.n; g.Bm = c->state + P.off[VJF_SLOT_W_MEAN]; g.ldb = P.dz; g.C = a.ybuf; g.ldc = P.dz;
+        g.M = P.n; g.N = P.dz; g.K = P.n; g.epi = WEPI_NONE;
+        launch_wide_gemm(g, st);
+        hipLaunchKernelGGL(vjf_resid_dot_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra, (const float*)a.ybuf);
+    }
+    hipLaunchKernelGGL(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, P, ra, (const int*)nullptr);
+    VJF_HIP(hipGetLastError());
+    return 0;
+}
+
 // After the SGD pass of a one-rank step: the backward half with the seeds of the dropped loss components at zero, the gradient
 // sums, and the SGD pass from them -- every launch returns at once unless the first pass found a non-finite component
 // (vjf/model.py:138-149; the one-launch route does the same inside its grid).
@@ -1052,54 +1108,7 @@ int filter_global_impl(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags
         if (rc) return rc;
         if (replay && (rc = launch_replay(c, *ta, B_total, flags, c->stream))) return rc;
         if (!(flags & VJF_FLAG_UPDATE)) return 0;
-        hipStream_t st = c->stream;
-        const int nbl = (P.n + 31) / 32;
-        float* work = (float*)(c->ws + c->cv.work);
-        VjfRlsbArgs a{};
-        a.state = c->state; a.red = red; a.Lw = (float*)(c->ws + c->cv.lscr);
-        a.X = work; a.gbuf = work + (size_t)P.n * P.n; a.ybuf = a.gbuf + (size_t)P.n * P.dz;
-        a.Dinv = (float*)(c->ws + c->cv.post);
-        a.Ld = (float*)(c->ws + c->cv.tbig);
-        a.Pacc = a.Ld + (size_t)nbl * 1024;
-        a.ok = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
-        const bool rls = !(flags & VJF_FLAG_WARM_UP);
-        if (rls) {
-            const int gx = 512;
-            auto gemm = [&](const float* A_, int lda, int ta, const float* Bm, int ldb, float* C_, int ldc, int M, int N, int K, const int* ok) {
-                VjfWideGemm g{};
-                g.A = A_; g.lda = lda; g.ta = ta; g.Bm = Bm; g.ldb = ldb; g.C = C_; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.nt = 0;
-                g.epi = WEPI_NONE; g.ok = ok;
-                launch_wide_gemm(g, st);
-            };
-            const float* Sx = c->state;
-            gemm(Sx + P.off[VJF_SLOT_W_PREC], P.n, 0, Sx + P.off[VJF_SLOT_W_MEAN], P.dz, a.gbuf, P.dz, P.n, P.dz, P.n, nullptr);   // P W
-            hipLaunchKernelGGL(vjf_rlsb_prep_kernel, dim3(gx), dim3(256), 0, st, P, a);
-            // block column k of L and block row k - 1 of X = L^-1 per launch (the block-upper part of X stays zero: the solves
-            // below read all of it)
-            VJF_HIP(hipMemsetAsync(a.X, 0, (size_t)P.n * P.n * 4, st));
-            for (int k = 0; k <= nbl; ++k) {
-                a.k = k;
-                const int ncol = nbl - k, grid = ncol + (ncol > 1 ? ncol - 1 : 0) + (k > 1 ? k - 1 : 0);
-                hipLaunchKernelGGL(vjf_rlsc_col_kernel, dim3(grid), dim3(VJF_RLSC_THREADS), 0, st, P, a);
-            }
-            gemm(a.X, P.n, 0, a.gbuf, P.dz, a.ybuf, P.dz, P.n, P.dz, P.n, a.ok);                                      // y = X g
-            gemm(a.X, P.n, 1, a.ybuf, P.dz, c->state + P.off[VJF_SLOT_W_MEAN], P.dz, P.n, P.dz, P.n, a.ok);          // W = X^T y
-            hipLaunchKernelGGL(vjf_rlsb_final_kernel, dim3(gx), dim3(256), 0, st, P, a);
-            VJF_HIP(hipGetLastError());
-        }
-        VjfResidArgs ra{};
-        ra.state = c->state; ra.red = red; ra.partial = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
-        ra.B_total = B_total; ra.flags = flags;
-        {   // state-noise update (model.py:373-377): T = G W with the GEMM kernel (y's buffer is free again), contraction in fp64
-            VjfWideGemm g{};
-            g.A = red + P.red_G; g.lda = P.n; g.Bm = c->state + P.off[VJF_SLOT_W_MEAN]; g.ldb = P.dz; g.C = a.ybuf; g.ldc = P.dz;
-            g.M = P.n; g.N = P.dz; g.K = P.n; g.epi = WEPI_NONE;
-            launch_wide_gemm(g, st);
-            hipLaunchKernelGGL(vjf_resid_dot_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra, (const float*)a.ybuf);
-        }
-        hipLaunchKernelGGL(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, P, ra, (const int*)nullptr);
-        VJF_HIP(hipGetLastError());
-        return 0;
+        return launch_rlsb(c, B_total, flags, red, c->stream);
     }
     VjfSerialArgs s{};
     s.state = c->state; s.red = (const float*)(c->ws + c->cv.red); s.work = (float*)(c->ws + c->cv.work);
