@@ -703,3 +703,39 @@ def test_gemm_dispatcher_shapes_against_fp64(vjf):
         out2 = torch.empty(B, dout, device="cuda")                         # no bias
         N.check(N.lib().vjf_linear_forward(N.ptr(xd), N.ptr(Wd), None, N.ptr(out2), B, din, dout, stream_ptr()), "vjf_linear_forward")
         assert ((out2.cpu().double() - (ref - b.double())).abs().max().item()) <= 4e-7 * scale + 1e-6, (B, din, dout)
+
+
+@pytest.mark.gpu
+def test_operator_kernels_odd_shapes_against_fp64(vjf):
+    """The matrix-core operator kernels behind `Recognition.forward` and `LinearRegression.forward` (prediction and sampling) and
+    the tiled `functional.rbf`, on shapes off every tile size (batch not a multiple of 16, widths not multiples of 16 / 4,
+    three layers, latent width beyond one tile), against fp64 torch."""
+    g = torch.Generator().manual_seed(321)
+    for (B, dy, du, dz, hidden) in [(37, 11, 2, 5, [19, 7, 33]), (16, 64, 0, 20, [48]), (1, 3, 1, 2, [5]), (130, 200, 0, 10, [128])]:
+        torch.manual_seed(B)
+        rec = vjf.recognition.Recognition(dy, dz, du, hidden)
+        y, u = torch.randn(B, dy, generator=g), torch.randn(B, du, generator=g) if du else None
+        mu, lv = torch.randn(B, dz, generator=g), torch.randn(B, dz, generator=g)
+        q = rec(y, vjf.Gaussian(mu, lv), u)
+        h = torch.cat([t for t in (y, u, mu, lv) if t is not None], -1).double()
+        for lin in rec.linears():
+            h = torch.tanh(h @ lin.weight.cpu().double().T + lin.bias.cpu().double())
+        close(q.mean, (h @ rec.mean.weight.cpu().double().T).float(), rtol=2e-5, atol=2e-6)
+        close(q.logvar, (h @ rec.logvar.weight.cpu().double().T + rec.logvar.bias.cpu().double()).float(), rtol=2e-5, atol=2e-6)
+    for (B, d, n, dout) in [(37, 5, 50, 3), (16, 12, 200, 10), (3, 2, 7, 1), (100, 7, 333, 64)]:    # (larger d: the fp32 features underflow)
+        torch.manual_seed(n)
+        blr = vjf.module.LinearRegression(vjf.module.RBF(d, n), dout)
+        blr.w_mean.copy_(torch.randn(n, dout, generator=g) * 0.3)
+        blr.w_chol.copy_(torch.triu(torch.randn(n, n, generator=g)) * 0.1)
+        x = torch.randn(B, d, generator=g)
+        c, lw = blr.feature.centroid.cpu().double(), blr.feature.logwidth.cpu().double()
+        phi = torch.exp(-0.5 * ((x.double()[:, None, :] - c[None]) ** 2).sum(-1) / torch.exp(lw).reshape(1, -1) ** 2)
+        close(vjf.functional.rbf(x, blr.feature.centroid, torch.exp(blr.feature.logwidth)), phi.float(), rtol=2e-5, atol=1e-7)   # (takes the WIDTH)
+        p = blr(x, sampling=False)
+        close(p.mean, (phi @ blr.w_mean.cpu().double()).float(), rtol=2e-5, atol=2e-6)
+        z = phi @ blr.w_chol.cpu().double()
+        close(p.logvar, torch.log((z * z).sum(-1, keepdim=True)).expand(B, dout).float(), rtol=5e-5, atol=5e-5)
+        noise = torch.randn(n, dout, generator=g)
+        smp = blr(x, sampling=True, noise=noise)
+        w = blr.w_mean.cpu().double() + blr.w_chol.cpu().double() @ noise.double()
+        close(smp, (phi @ w).float(), rtol=5e-5, atol=5e-6)
