@@ -1102,7 +1102,6 @@ int filter_global_impl(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags
     if (c->plan.n > 32 * VJF_CHOL_MAXBLK) {
         // feature counts beyond one CU's LDS: clip + SGD and scalars in the prep kernel, then the RLS update as a sequence of
         // chip-wide launches on the matrix in global memory (vjf_rlsb_kernels.h)
-        const VjfPlan& P = c->plan;
         const float* red = (const float*)(c->ws + c->cv.red);
         int rc = launch_prep(c, B_total, loss4, flags, red, 2, c->stream, nullptr, 0, nullptr, 0, replay ? 1 : 0);
         if (rc) return rc;
