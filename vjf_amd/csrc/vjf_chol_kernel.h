@@ -370,7 +370,10 @@ __device__ __forceinline__ float vlo2both(float v) {            // lanes 0..31 o
     const unsigned u = __float_as_uint(v);
     return __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[0]);
 }
-__device__ __forceinline__ bool potrf_inv_chain2(float* dk, float* inv, int lane) {
+// `nvalid`: rows / columns of the tile inside the matrix (the rest is the identity padding of the last block): a round whose two
+// pivots are padding would scale by 1 and update by 0 -- it is skipped (a uniform branch around the round: the loop stays fully
+// unrolled, every register index static), the result is the same bits.
+__device__ __forceinline__ bool potrf_inv_chain2(float* dk, float* inv, int lane, int nvalid = 32) {
     const int c = lane & 31, h = lane >> 5;
     const int lc = 2 * ((c & 3) + 4 * (c >> 3)) + ((c >> 2) & 1);   // logical column held by this lane
     vjf_f32x16 acc, racc;
@@ -382,8 +385,11 @@ __device__ __forceinline__ bool potrf_inv_chain2(float* dk, float* inv, int lane
     }
     float vcol[16], xcol[16];
     float dmin = 3.0e38f, slast = 1.f;
+    const int rounds = (nvalid + 1) >> 1;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
+        vcol[m] = xcol[m] = (lc == 2 * m + h) ? 1.f : 0.f;          // (what a skipped round leaves: the identity)
+        if (m < rounds) {                                           // (uniform)
         const int p1 = (m & 3) + 8 * (m >> 2), p2 = p1 + 4;         // physical columns of logical 2m and 2m + 1
         const float d1 = vrl(acc[m], p1);                           // T[2m][2m]
         const float q2 = vrl(acc[m], 32 + p2);                      // T[2m+1][2m+1], before column 2m is eliminated
@@ -404,6 +410,7 @@ __device__ __forceinline__ bool potrf_inv_chain2(float* dk, float* inv, int lane
         xcol[m] = b;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nv, v, acc, 0, 0, 0);
         racc = __builtin_amdgcn_mfma_f32_32x32x2f32(nv, b, racc, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -631,7 +638,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         //      All loads of a thread are issued before its first LDS store.
         auto diag_chain = [&](int k) {                                  // L_kk and L_kk^-1 in one chain (one wavefront)
             float* dk = s_blk + (size_t)vtri(k, k) * 1024;
-            if (!potrf_inv_chain2(dk, s_aux + (size_t)k * 1024, lane) && lane == 0) s_flag[0] = 0;
+            if (!potrf_inv_chain2(dk, s_aux + (size_t)k * 1024, lane, min(32, n - 32 * k)) && lane == 0) s_flag[0] = 0;
         };
         auto pad4 = [](int gi, int gj) {                                // identity padding outside the matrix
             return make_float4(gi == gj ? 1.f : 0.f, gi == gj + 1 ? 1.f : 0.f, gi == gj + 2 ? 1.f : 0.f, gi == gj + 3 ? 1.f : 0.f);

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_col_kernel(VjfPlan 
         }
         __syncthreads();
         if (wave == 0) {
-            const bool good = potrf_inv_chain2(s_d, s_i, lane);
+            const bool good = potrf_inv_chain2(s_d, s_i, lane, min(32, n - 32 * k));
             if (lane == 0) s_good = good ? 1 : 0;
         }
         __syncthreads();
