@@ -963,10 +963,15 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         // an all-reduce, and an all-reduce waits for the slowest rank -- one that is late with this CALL by more than the bound
         // (data loading, a first call) must not run its peers' waits out.  One tiny all-reduce and a host synchronisation per
         // call; inside the sequence the per-step collectives keep the ranks in step.
-        float* tok = (float*)(c->ws + c->cv.flags) + 60;                    // (a word of the flag block no hand-off uses)
-        VJF_HIP(hipMemsetAsync(tok, 0, 4, sa));
+        // (Both communicators: the first collective on one sets its channels up, which can take longer than the bound.)
+        float* tok = (float*)(c->ws + c->cv.flags) + 60;                    // (words of the flag block no hand-off uses)
+        VJF_HIP(hipMemsetAsync(tok, 0, 8, sa));
         VJF_NCCL(nccl().all_reduce(tok, tok, 1, kNcclFloat, kNcclSum, c->comm_a, sa));
         VJF_HIP(hipStreamSynchronize(sa));
+        if (c->comm_b) {
+            VJF_NCCL(nccl().all_reduce(tok + 1, tok + 1, 1, kNcclFloat, kNcclSum, c->comm_b, sb));
+            VJF_HIP(hipStreamSynchronize(sb));
+        }
     }
     rc = refresh_aux(c);
     if (rc) return rc;
