@@ -219,3 +219,32 @@ def test_replay_with_several_tiles_per_workgroup(vjf):
             close(mu[t - 1], o.mu_t, rtol=2e-4, atol=2e-4)
             close(loss[t - 1], [o.loss, o.recon, o.dyn, o.entropy], rtol=2e-4, atol=2e-4)
         state_close(m, s, rtol=2e-3, atol=2e-4, rls_rtol=2e-2, rls_atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_bench_line_contract():
+    """`bench.py` as the round driver runs it (fewer steps): ONE JSON line with the contract's fields, the roofline and cpu_baseline
+    objects, the ELBO of the timed steps checked against the oracle inside the run, status clean."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "3", "--repeats", "2"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "trial-timesteps/sec" and d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(d["value"] - 4096 * 12 / (d["ms_per_step"] * 1e-3 * 12)) / d["value"] < 1e-6
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert d["elbo_check"]["ok"] and d["status_bits"] == 0
