@@ -608,7 +608,7 @@ VjfTrialArgs trial_args(vjf_ctx* c, int32_t B, const float* y, const float* u, c
 
 int trial_blocks(const vjf_ctx* c, int B) { return c->mfma_trial ? (B + 15) / 16 : (B + 3) / 4; }   // (wide path: 4 trials per loss workgroup)
 
-// one GEMM of the wide routes: a narrow output (N <= 64) splits K over the wavefronts of 32-row workgroups; else 128 x 128 or
+// one GEMM of the wide routes: a narrow output (N <= 128) splits K over the wavefronts of 32 x 32-tile workgroups; else 128 x 128 or
 // 128 x 64 tiles when the shape fills the chip with them, else the 64 x 64 kernel
 void launch_wide_gemm(const VjfWideGemm& g0, hipStream_t st) {
     VjfWideGemm g = g0;
@@ -617,7 +617,7 @@ void launch_wide_gemm(const VjfWideGemm& g0, hipStream_t st) {
     g.va = (g.lda % 4 == 0) && al16(g.A) && ((g.ta ? g.M : g.K) % 4 == 0);
     g.vb = (g.ldb % 4 == 0) && al16(g.Bm) && ((g.nt ? g.K : g.N) % 4 == 0);
     const int tm = (g.M + 127) / 128;
-    if (g.N <= 64)
+    if (g.N <= 128)
         hipLaunchKernelGGL(vjf_skinny_gemm_kernel<8>, dim3((g.M + 31) / 32, (g.N + 31) / 32), dim3(512), 0, st, g);
     else if (!g.ta && g.va && g.vb && g.M >= 256 && g.N >= 256 && tm * ((g.N + 127) / 128) >= 192) {
         const dim3 grid((g.N + 127) / 128, tm);
@@ -679,8 +679,15 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
                  WEPI_TANH_BIAS, S + P.off[VJF_SLOT_REC_B0 + 2 * l]);
             kin = P.h[l];
         }
+        if (P.off[VJF_SLOT_LV_W] == P.off[VJF_SLOT_MEAN_W] + P.dz * kin) {   // the heads' weights lie one behind the other: ONE product, N = 2 dz
+            VjfWideGemm g{};
+            g.A = a.ACT + P.colA_act[P.L]; g.lda = P.ldA; g.Bm = S + P.off[VJF_SLOT_MEAN_W]; g.ldb = kin; g.C = a.mu_t; g.C2 = a.lv_t; g.ldc = P.dz;
+            g.M = a.B; g.N = 2 * P.dz; g.K = kin; g.nt = 1; g.epi = WEPI_HEADS; g.bias = S + P.off[VJF_SLOT_LV_B];
+            launch_wide_gemm(g, st);
+        } else {
         gemm(a.ACT + P.colA_act[P.L], P.ldA, S + P.off[VJF_SLOT_MEAN_W], kin, a.mu_t, P.dz, P.dz, kin, 1, WEPI_NONE);
         gemm(a.ACT + P.colA_act[P.L], P.ldA, S + P.off[VJF_SLOT_LV_W], kin, a.lv_t, P.dz, P.dz, kin, 1, WEPI_BIAS, S + P.off[VJF_SLOT_LV_B]);
+        }
         hipLaunchKernelGGL(vjf_wide_mid_kernel, dim3(gx), dim3(256), 0, st, P, w);
         gemm(a.ACT + P.colA_xt, P.ldA, S + P.off[VJF_SLOT_DEC_W], P.dz, w.PY, P.dy, P.dy, P.dz, 1, WEPI_BIAS, S + P.off[VJF_SLOT_DEC_B]);
         }
@@ -693,9 +700,15 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
         // backward: dxt = dpy C into dmu / dlv; dh_L = dmu Wm + dlv Wl; da_l = (da_{l+1} W_{l+1}) (1 - h_l^2)
         gemm(a.DEL + P.colD_dpy, P.ldD, S + P.off[VJF_SLOT_DEC_W], P.dz, a.DEL + P.colD_dmu, P.ldD, P.dz, P.dy, 0, WEPI_SEED);
         const int hL = P.h[P.L - 1];
+        if (P.off[VJF_SLOT_LV_W] == P.off[VJF_SLOT_MEAN_W] + P.dz * hL && P.colD_dlv == P.colD_dmu + P.dz)
+            // the two heads' weights lie one behind the other in the state, their seeds side by side in DEL: ONE product with K = 2 dz
+            gemm(a.DEL + P.colD_dmu, P.ldD, S + P.off[VJF_SLOT_MEAN_W], hL, a.DEL + P.colD_da[P.L - 1], P.ldD, hL, 2 * P.dz, 0, WEPI_DTANH, nullptr,
+                 a.ACT + P.colA_act[P.L], P.ldA);
+        else {
         gemm(a.DEL + P.colD_dmu, P.ldD, S + P.off[VJF_SLOT_MEAN_W], hL, a.DEL + P.colD_da[P.L - 1], P.ldD, hL, P.dz, 0, WEPI_NONE);
         gemm(a.DEL + P.colD_dlv, P.ldD, S + P.off[VJF_SLOT_LV_W], hL, a.DEL + P.colD_da[P.L - 1], P.ldD, hL, P.dz, 0, WEPI_ADDC_DTANH, nullptr,
              a.ACT + P.colA_act[P.L], P.ldA);
+        }
         for (int l = P.L - 1; l >= 1; --l)
             gemm(a.DEL + P.colD_da[l], P.ldD, S + P.off[VJF_SLOT_REC_W0 + 2 * l], P.h[l - 1], a.DEL + P.colD_da[l - 1], P.ldD, P.h[l - 1], P.h[l], 0,
                  WEPI_DTANH, nullptr, a.ACT + P.colA_act[l], P.ldA);

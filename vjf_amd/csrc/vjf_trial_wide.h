@@ -12,7 +12,7 @@
 #include "vjf_plan.h"
 #include "vjf_trial_kernel.h"  // VjfTrialArgs
 
-enum { WEPI_NONE = 0, WEPI_BIAS = 1, WEPI_TANH_BIAS = 2, WEPI_ADD_SRC = 3, WEPI_DTANH = 4, WEPI_ADDC_DTANH = 5, WEPI_SEED = 6 };
+enum { WEPI_NONE = 0, WEPI_BIAS = 1, WEPI_TANH_BIAS = 2, WEPI_ADD_SRC = 3, WEPI_DTANH = 4, WEPI_ADDC_DTANH = 5, WEPI_SEED = 6, WEPI_HEADS = 7 };
 
 struct VjfWideGemm {
     const float* A; int lda;       // (M, K) row-major
@@ -25,12 +25,20 @@ struct VjfWideGemm {
     const float* src; int lds;     // WEPI_ADD_SRC: added;  WEPI_DTANH / WEPI_ADDC_DTANH: h of (1 - h^2)
     // WEPI_SEED (dxt = dpy C):  dmu += dxt;  dlv += dxt * eps_t * exp(lv_t / 2) / 2   (C -> dmu, C + N -> dlv; ldc = ldD)
     const float* eps_t; const float* lv_t;
+    float* C2;                     // WEPI_HEADS (both recognition heads in one product, N = 2 dz): columns < dz -> C (mean, no bias), the
+                                   // others + bias[n - dz] -> C2 (log-variance); both (M, dz) with ldc
     const int* ok;                 // non-null: nothing is done when ok[0] == 0 (the RLS path after a failed factorisation)
     int va, vb;                    // vjf_wide_gemm2_kernel: A / B can be read 16 bytes at a time (set by the launcher)
 };
 
 // the fused epilogues of the wide GEMM kernels: C[m][n] <- f(v)
 __device__ __forceinline__ void vjf_wide_epilogue(const VjfWideGemm& g, int m, int n, float v) {
+    if (g.epi == WEPI_HEADS) {
+        const int dz = g.N >> 1;
+        if (n < dz) g.C[(size_t)m * g.ldc + n] = v;
+        else g.C2[(size_t)m * g.ldc + n - dz] = v + g.bias[n - dz];
+        return;
+    }
     float* c = g.C + (size_t)m * g.ldc + n;
     switch (g.epi) {
         case WEPI_BIAS: v += g.bias[n]; break;
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(4))) 
         }
 }
 
-// C = A B for the products with a narrow output (N <= 64: heads, pt.mean, dxt, the RLS solves) -- a 128 x 64 tile grid would
+// C = A B for the products with a narrow output (N <= 128: the two heads in one product, pt.mean, dxt, the RLS solves) -- a 128 x 64 tile grid would
 // leave most of the chip idle behind a serial K loop.  Workgroup = one 32 x 32 tile of C; its NW wavefronts split K (contiguous
 // ranges), every wavefront reads its operands from global memory straight into the MFMA operand layout -- the order of the
 // k indices inside a group of 8 is free as long as A and B agree: lane (row, half) takes k = k0 + 4 half + {0..3}, four
