@@ -421,6 +421,8 @@ __device__ __forceinline__ bool potrf_inv_chain2(float* dk, float* inv, int lane
     return (dmin > 0.f) && (slast == slast) && (fabsf(slast) < 3.0e38f);
 }
 
+// (Not on the product path: kept for `tools/potrf_chain_bench3.hip`, which times the alternatives the rank-2 chain above was chosen
+//  against -- potrf alone 5088 cycles, inverse 4868, panel solve 4112, rank-2 chain with the inverse 5292.)
 // The same column chain split in three, so that each is a pure one-MFMA-per-step dependent chain (the merged chain
 // above pays the compiler's MFMA->VALU wait states twice per step: ~290 cycles/step against ~127 + ~94 + ~94 here)
 // and the inverse / the panel solves run on other wavefronts beside it.
