@@ -658,6 +658,32 @@ def test_fit_harness_golden(vjf):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,hidden,dy", [(300, [40], 20), (1150, [400], 300)], ids=["rls_launches", "wide"])
+def test_state_noise_when_the_weights_nearly_interpolate(vjf, n, hidden, dy):
+    """B << n: the RLS weights reproduce dx almost exactly, so the residual of vjf/model.py:373-374 is a small difference of large
+    terms.  A rank that holds every trial forms it as the reference does (dx - Phi W, then the mean of squares): the state-noise
+    log-variance stays at fp32 rounding of the fp64 oracle (the quadratic form of the reduced statistics, which ranks holding
+    shards use, is at 1.5e-5 here)."""
+    import warnings
+    B, dz, T = 4, 3, 3
+    torch.manual_seed(5)
+    m = vjf.VJF.make_model(dy, dz, 0, n, hidden, likelihood="gaussian", lr=1e-3)
+    s = load_oracle_state(m, np.float64)
+    g = torch.Generator().manual_seed(6)
+    y = torch.randn(T, B, dy, generator=g)
+    eps = torch.randn(T, 2, B, dz, generator=g)
+    q = mu = lv = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in range(T):
+            o = orc.filter_step(s, y[t].numpy(), None, mu, lv, eps[t, 0].numpy(), eps[t, 1].numpy())
+            mu, lv = o.mu_t, o.lv_t
+            q, _ = m.filter(y[t], None, q, eps=(eps[t, 0], eps[t, 1]))
+            assert abs(float(m.transition.logvar) - float(s.tr_logvar)) < 4e-6, t
+    assert m.status() == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("overlap", [1, 0, 3], ids=["one_launch", "one_stream", "three_streams"])
 def test_results_do_not_depend_on_workspace_contents(vjf, monkeypatch, overlap):
     """The caller's workspace arrives uninitialised (torch.empty).  A workspace of NaNs (every byte 0xFF, also in every counter

@@ -830,7 +830,7 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
         VjfResidArgs ra{};
         ra.state = c->state; ra.red = red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
         hipLaunchKernelGGL(vjf_resid_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra);
-        VJF_LAUNCH(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, stop, P, ra, (const int*)nullptr);
+        VJF_LAUNCH(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, stop, P, ra, (const int*)nullptr, 0);
         VJF_HIP(hipGetLastError());
     }
     return 0;
@@ -1040,7 +1040,8 @@ int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, cons
 
 namespace {
 // The RLS update for feature counts beyond one compute unit's LDS (vjf_rlsb_kernels.h) and the state-noise update, on stream `st`
-int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st) {
+// `ta`: the trial-parallel half's arguments when this rank holds every trial, else null
+int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, const VjfTrialArgs* ta = nullptr) {
     const VjfPlan& P = c->plan;
     const int nbl = (P.n + 31) / 32;
     float* work = (float*)(c->ws + c->cv.work);
@@ -1079,14 +1080,25 @@ int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, h
     VjfResidArgs ra{};
     ra.state = c->state; ra.red = red; ra.partial = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
     ra.B_total = B_total; ra.flags = flags;
-    {   // state-noise update (model.py:373-377): T = G W with the GEMM kernel (y's buffer is free again), contraction in fp64
+    if (ta) {
+        // state-noise update (model.py:373-377) from the residual itself: R = Phi W with the GEMM kernel into the DEL buffer (free
+        // once the gradient sums -- and a replay's -- are formed), then sum (dx - R)^2
+        VjfWideGemm g{};
+        float* R = ta->DEL;
+        g.A = ta->E; g.lda = P.ldE; g.Bm = c->state + P.off[VJF_SLOT_W_MEAN]; g.ldb = P.dz; g.C = R; g.ldc = P.dz;
+        g.M = ta->B; g.N = P.dz; g.K = P.n; g.epi = WEPI_NONE;
+        launch_wide_gemm(g, st);
+        hipLaunchKernelGGL(vjf_resid_direct_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra, (const float*)ta->E, (const float*)R, ta->B);
+    } else {
+        // ranks holding shards: the same sum as the quadratic form of the reduced statistics, T = G W with the GEMM kernel (y's
+        // buffer is free again), contraction in fp64
         VjfWideGemm g{};
         g.A = red + P.red_G; g.lda = P.n; g.Bm = c->state + P.off[VJF_SLOT_W_MEAN]; g.ldb = P.dz; g.C = a.ybuf; g.ldc = P.dz;
         g.M = P.n; g.N = P.dz; g.K = P.n; g.epi = WEPI_NONE;
         launch_wide_gemm(g, st);
         hipLaunchKernelGGL(vjf_resid_dot_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra, (const float*)a.ybuf);
     }
-    hipLaunchKernelGGL(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, P, ra, (const int*)nullptr);
+    hipLaunchKernelGGL(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, P, ra, (const int*)nullptr, ta ? 1 : 0);
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -1125,7 +1137,7 @@ int filter_global_impl(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags
         if (rc) return rc;
         if (replay && (rc = launch_replay(c, *ta, B_total, flags, c->stream))) return rc;
         if (!(flags & VJF_FLAG_UPDATE)) return 0;
-        return launch_rlsb(c, B_total, flags, red, c->stream);
+        return launch_rlsb(c, B_total, flags, red, c->stream, ta);
     }
     VjfSerialArgs s{};
     s.state = c->state; s.red = (const float*)(c->ws + c->cv.red); s.work = (float*)(c->ws + c->cv.work);

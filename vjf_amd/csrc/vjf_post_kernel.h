@@ -677,7 +677,26 @@ __global__ __launch_bounds__(256) void vjf_resid_dot_kernel(VjfPlan P, VjfResidA
     if (tid == 0) A.partial[blockIdx.x] = ((s_d[0] + s_d[1]) + s_d[2]) + s_d[3];
 }
 
-__global__ __launch_bounds__(64) void vjf_sigma_kernel(VjfPlan P, VjfResidArgs A, const int* ok) {
+// the sum of squares of the residual itself, dx - Phi W (vjf/model.py:373-374), for a rank that holds every trial: R = Phi W comes from
+// the GEMM kernel; the difference in fp32 as the reference forms it, the sum in fp64.  Unlike the quadratic form above it does not
+// lose the residual under the rounding of G and FDX when the weights reproduce dx almost exactly (B << n).
+__global__ __launch_bounds__(256) void vjf_resid_direct_kernel(VjfPlan P, VjfResidArgs A, const float* E, const float* R, int B) {
+    __shared__ double s_d[4];
+    const int tid = threadIdx.x, dz = P.dz, tot = B * dz;
+    double part = 0.0;
+    for (int e = blockIdx.x * 256 + tid; e < tot; e += VJF_RESID_BLOCKS * 256) {
+        const int b = e / dz, cc = e - b * dz;
+        const float r = E[(size_t)b * P.ldE + P.n + cc] - R[e];
+        part += (double)r * (double)r;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((tid & 63) == 0) s_d[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) A.partial[blockIdx.x] = ((s_d[0] + s_d[1]) + s_d[2]) + s_d[3];
+}
+
+__global__ __launch_bounds__(64) void vjf_sigma_kernel(VjfPlan P, VjfResidArgs A, const int* ok, int direct = 0) {
     // one wavefront: lane b holds partial b (VJF_RESID_BLOCKS == 64), fixed-order xor tree
     double t = A.partial[threadIdx.x];
 #pragma unroll
@@ -685,7 +704,7 @@ __global__ __launch_bounds__(64) void vjf_sigma_kernel(VjfPlan P, VjfResidArgs A
     if (threadIdx.x != 0) return;
     float* S = A.state;
     float* SC = S + P.off[VJF_SLOT_SCALARS];
-    t += (double)A.red[P.red_SC + RS_SDX2];
+    if (!direct) t += (double)A.red[P.red_SC + RS_SDX2];      // (quadratic form: the partials hold -2 tr(W^T FDX) + tr(W^T G W))
     if (t < 0.0) t = 0.0;
     const float Bf = (float)A.B_total;
     const float sig = S[P.off[VJF_SLOT_TR_LOGVAR]];
