@@ -684,6 +684,44 @@ def test_state_noise_when_the_weights_nearly_interpolate(vjf, n, hidden, dy):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,hidden,dy", [(300, [40], 20), (1150, [400], 300)], ids=["rls_launches", "wide"])
+def test_split_entry_points_on_the_multi_launch_rls_routes(vjf, monkeypatch, n, hidden, dy):
+    """vjf_filter_local / vjf_filter_global as a rank holding a shard calls them (here: the only rank, the sum over ranks is the
+    identity), on the plans whose RLS update is a sequence of launches: the state-noise update then comes from the reduced
+    statistics (the quadratic form), everything else from the same kernels as the step entry point."""
+    import warnings
+    B, dz, T = 48, 4, 3
+    torch.manual_seed(7)
+    m = vjf.VJF.make_model(dy, dz, 0, n, hidden, likelihood="gaussian", lr=1e-3)
+    m2 = vjf.VJF.make_model(dy, dz, 0, n, hidden, likelihood="gaussian", lr=1e-3)
+    m2.set_state(m.get_state())
+    s = load_oracle_state(m, np.float64)
+    g = torch.Generator().manual_seed(8)
+    y = torch.randn(T, B, dy, generator=g)
+    eps = torch.randn(T, 2, B, dz, generator=g)
+    monkeypatch.setattr(type(m), "_world", staticmethod(lambda: (1, True)))
+    monkeypatch.setattr(type(m), "_all_reduce_sum", staticmethod(lambda t: None))
+    q = mu = lv = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in range(T):
+            o = orc.filter_step(s, y[t].numpy(), None, mu, lv, eps[t, 0].numpy(), eps[t, 1].numpy())
+            mu, lv = o.mu_t, o.lv_t
+            q, l1, *comp = m.filter(y[t], None, q, verbose=True, eps=(eps[t, 0], eps[t, 1]))
+            close(q.mean, o.mu_t, rtol=5e-5, atol=5e-5)
+            close(q.logvar, o.lv_t, rtol=5e-5, atol=5e-5)
+            close(torch.stack([l1, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
+    state_close(m, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3)
+    assert m.status() == 0
+    monkeypatch.undo()
+    q = None
+    for t in range(T):                                   # the step entry point: same kernels but the state-noise update's
+        q, _ = m2.filter(y[t], None, q, eps=(eps[t, 0], eps[t, 1]))
+    close(m2.transition.logvar, m.transition.logvar, rtol=0, atol=2e-6)
+    close(m2.transition.velocity.w_mean, m.transition.velocity.w_mean, rtol=1e-3, atol=1e-4)     # (B < n: conditioning)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("overlap", [1, 0, 3], ids=["one_launch", "one_stream", "three_streams"])
 def test_results_do_not_depend_on_workspace_contents(vjf, monkeypatch, overlap):
     """The caller's workspace arrives uninitialised (torch.empty).  A workspace of NaNs (every byte 0xFF, also in every counter
