@@ -918,6 +918,18 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     VjfPlan Pk = P;
     void* args[] = {(void*)&Pk, (void*)&A, (void*)&C, (void*)&Q};
     const int grid = m.n_rls + m.n_trial + m.n_gram + m.n_prep + m.n_sgd;
+#ifdef VJF_CHAOS
+    {
+        static bool told = false;
+        const int range[4] = {getenv("VJF_CHAOS_LO") ? atoi(getenv("VJF_CHAOS_LO")) : 0, getenv("VJF_CHAOS_HI") ? atoi(getenv("VJF_CHAOS_HI")) : 1 << 30,
+                              getenv("VJF_CHAOS_SITE") ? atoi(getenv("VJF_CHAOS_SITE")) : -1, getenv("VJF_CHAOS_KIND") ? atoi(getenv("VJF_CHAOS_KIND")) : 0};
+        VJF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vjf_chaos_range), range, sizeof(range)));
+        const unsigned* base = cnt;
+        VJF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vjf_chaos_base), &base, sizeof(base)));
+        if (!told) fprintf(stderr, "vjf chaos build: roles rls %d trial %d gram %d operand %d sgd %d; held: workgroups [%d, %d)\n", m.n_rls, m.n_trial, m.n_gram, m.n_prep, m.n_sgd, range[0], range[1]);
+        told = true;
+    }
+#endif
     static const bool plain = getenv("VJF_DEBUG_PLAIN_LAUNCH") && atoi(getenv("VJF_DEBUG_PLAIN_LAUNCH")) != 0;   // (measurements only)
     if (plain) {
         hipLaunchKernelGGL(vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), kMegaLds, c->stream, Pk, A, C, Q);

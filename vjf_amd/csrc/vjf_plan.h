@@ -176,7 +176,26 @@ struct VjfJob {
 // at agent scope (L2 write-back), drains again, then the relaxed agent-scope count.  Consumer, whole workgroup: one lane
 // polls (relaxed, bounded), acquires at agent scope, its vmcnt drained, the workgroup barrier, and only then the plain loads
 // (MI355X guide, visibility across XCDs, valid forms).
+// -DVJF_CHAOS (diagnostic builds only, tools/chaos_handoffs.sh): one workgroup in eight is held for up to 200 us in front of a wait or
+// a signal, so that an access which is ordered by the usual timing of the roles and not by a hand-off shows as a wrong result.
+#ifdef VJF_CHAOS
+__device__ int vjf_chaos_range[4] = {0, 1 << 30, -1, 0};                    // workgroups [lo, hi) are held (VJF_CHAOS_LO / _HI) at count word [2] (-1: any; VJF_CHAOS_SITE), kind [3] (0 any, 1 waits, 2 signals)
+__device__ const unsigned* vjf_chaos_base = nullptr;
+#endif
+__device__ __forceinline__ void vjf_chaos(int tid, const unsigned* count, int kind) {
+#ifdef VJF_CHAOS
+    if (tid == 0 && (int)blockIdx.x >= vjf_chaos_range[0] && (int)blockIdx.x < vjf_chaos_range[1] &&
+        (vjf_chaos_range[2] < 0 || count - vjf_chaos_base == vjf_chaos_range[2]) && (vjf_chaos_range[3] == 0 || vjf_chaos_range[3] == kind)) {
+        const unsigned long long t0 = wall_clock64();                       // 100 MHz
+        unsigned h = ((unsigned)t0 * 2654435761u) ^ (blockIdx.x * 40503u);
+        h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+        const unsigned d = (h & 7u) == 0u ? (h >> 8) % 20000u : 0u;
+        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+}
 __device__ __forceinline__ void vjf_wg_signal(unsigned* count, int tid) {
+    vjf_chaos(tid, count, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -195,6 +214,7 @@ __device__ __forceinline__ bool vjf_abort_seen(const float* status) {
 // The same for a workgroup whose outputs went out as write-through stores (in memory once vmcnt has drained): no L2 write-back
 // (an agent-scope release by every workgroup of a kernel that runs beside the trial kernel costs that kernel microseconds).
 __device__ __forceinline__ void vjf_wg_signal_wt(unsigned* count, int tid) {
+    vjf_chaos(tid, count, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -206,6 +226,7 @@ __device__ __forceinline__ void vjf_wg_signal_wt(unsigned* count, int tid) {
 #define VJF_FLAG_HANDOFF_ACQUIRE 0x40000000u      /* internal flag bit of the kernels' `flags` words */
 __device__ __forceinline__ bool vjf_wg_wait_sc1(const unsigned* count, unsigned target, int tid, const float* status = nullptr, bool fence = false) {
     bool there = true;
+    vjf_chaos(tid, count, 1);
     if (tid == 0) {
         there = false;
         for (unsigned spins = 0; spins < (1u << 21); ++spins) {
@@ -222,6 +243,7 @@ __device__ __forceinline__ void vjf_store_wt(float* p, float v) { __hip_atomic_s
 // returns false (lane 0 only; the others get true) when the count did not arrive within the bound
 __device__ __forceinline__ bool vjf_wg_wait(const unsigned* count, unsigned target, int tid, const float* status = nullptr) {
     bool there = true;
+    vjf_chaos(tid, count, 1);
     if (tid == 0) {
         there = false;
         for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
