@@ -1,0 +1,22 @@
+"""The hand-offs between roles under perturbed timing (tools/chaos_handoffs.py): sequences on the one-launch route and on the
+three-stream per-step route, run with the diagnostic build of the library in which workgroups are held at random in front of their
+waits and signals, must give what the one-stream per-step kernels give.  Needs a real MI355X:  pytest -m gpu."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_sequences_with_workgroups_held_at_their_handoffs():
+    from vjf_amd import _build
+    _build.build(chaos=True)                                   # (built by __graft_entry__.build(); compiled here if it is missing or stale)
+    env = dict(os.environ, VJF_LIB="chaos")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "chaos_handoffs.py"), "8", "2"], capture_output=True, text=True,
+                       env=env, timeout=900)
+    tail = "\n".join(l for l in (r.stdout + r.stderr).splitlines() if "amdgpu.ids" not in l)[-3000:]
+    assert r.returncode == 0, tail
+    assert "deviating sequences in all: 0" in r.stdout, tail

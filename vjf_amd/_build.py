@@ -12,6 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvjf_hip.so")
+CHAOS_LIB = os.path.join(HERE, "libvjf_hip_chaos.so")
 SOURCES = ["vjf_abi.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -29,26 +30,29 @@ def _inputs():
     return files
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def is_stale(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(f) > t for f in _inputs())
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/*.hip into libvjf_hip.so if missing or older than its sources."""
-    if not force and not is_stale():
-        return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+def build(force=False, verbose=False, chaos=False):
+    """Compile csrc/*.hip into libvjf_hip.so if missing or older than its sources.  chaos=True: the diagnostic build
+    libvjf_hip_chaos.so (-DVJF_CHAOS, see vjf_plan.h) instead."""
+    lib = CHAOS_LIB if chaos else LIB
+    if not force and not is_stale(lib):
+        return lib
+    cmd = [_hipcc()] + FLAGS + (["-DVJF_CHAOS", "-Wno-pass-failed"] if chaos else []) + ["-o", lib + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, chaos="--chaos" in sys.argv))

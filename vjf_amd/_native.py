@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvjf_hip.so")
+# VJF_LIB=chaos loads the diagnostic build of the same sources (-DVJF_CHAOS, vjf_plan.h: workgroups are held at random in front of
+# their hand-offs; tools/chaos_handoffs.py) -- same ABI, same kernels otherwise
+LIB_PATH = os.path.join(HERE, "libvjf_hip_chaos.so" if os.environ.get("VJF_LIB") == "chaos" else "libvjf_hip.so")
 
 ABI_VERSION = 1
 MAX_HIDDEN = 8

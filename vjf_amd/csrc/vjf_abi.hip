@@ -921,12 +921,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
 #ifdef VJF_CHAOS
     {
         static bool told = false;
-        const int range[4] = {getenv("VJF_CHAOS_LO") ? atoi(getenv("VJF_CHAOS_LO")) : 0, getenv("VJF_CHAOS_HI") ? atoi(getenv("VJF_CHAOS_HI")) : 1 << 30,
-                              getenv("VJF_CHAOS_SITE") ? atoi(getenv("VJF_CHAOS_SITE")) : -1, getenv("VJF_CHAOS_KIND") ? atoi(getenv("VJF_CHAOS_KIND")) : 0};
-        VJF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vjf_chaos_range), range, sizeof(range)));
-        const unsigned* base = cnt;
-        VJF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vjf_chaos_base), &base, sizeof(base)));
-        if (!told) fprintf(stderr, "vjf chaos build: roles rls %d trial %d gram %d operand %d sgd %d; held: workgroups [%d, %d)\n", m.n_rls, m.n_trial, m.n_gram, m.n_prep, m.n_sgd, range[0], range[1]);
+        if (!told) fprintf(stderr, "vjf chaos build: roles rls %d trial %d gram %d operand %d sgd %d\n", m.n_rls, m.n_trial, m.n_gram, m.n_prep, m.n_sgd);
         told = true;
     }
 #endif
@@ -1042,10 +1037,25 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
 }
 }  // namespace
 
+#ifdef VJF_CHAOS
+// diagnostic build: which workgroups are held, and where (vjf_plan.h), from the environment at every entry
+static void chaos_refresh(const vjf_ctx* c) {
+    const int range[4] = {getenv("VJF_CHAOS_LO") ? atoi(getenv("VJF_CHAOS_LO")) : 0, getenv("VJF_CHAOS_HI") ? atoi(getenv("VJF_CHAOS_HI")) : 1 << 30,
+                          getenv("VJF_CHAOS_SITE") ? atoi(getenv("VJF_CHAOS_SITE")) : -1, getenv("VJF_CHAOS_KIND") ? atoi(getenv("VJF_CHAOS_KIND")) : 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vjf_chaos_range), range, sizeof(range));
+    const unsigned* base = (const unsigned*)(c->ws + c->cv.mg_cnt);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vjf_chaos_base), &base, sizeof(base));
+}
+#define VJF_CHAOS_REFRESH(c) chaos_refresh(c)
+#else
+#define VJF_CHAOS_REFRESH(c) ((void)0)
+#endif
+
 int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const float* mu_s, const float* lv_s,
                      const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_local: null context");
     DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
+    VJF_CHAOS_REFRESH(c);
     VJF_HIP(hipSetDevice(c->cfg.device));
     return launch_local(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags, false);
 }
@@ -1163,6 +1173,7 @@ int filter_global_impl(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags
 int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_global: null context");
     DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
+    VJF_CHAOS_REFRESH(c);
     if (B_total < 1) return fail(-20, "vjf_filter_global: B_total=%d", B_total);
     return filter_global_impl(c, B_total, loss4, flags, nullptr);   // (the caller's ranks hold shards: no replay, see vjf_hip.h)
 }
@@ -1186,6 +1197,7 @@ int vjf_filter_step(vjf_ctx* c, int32_t B, const float* y, const float* u, const
                     const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, float* loss4, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_step: null context");
     DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
+    VJF_CHAOS_REFRESH(c);
     if (mega_route(c, flags) && eps_s && eps_t && eps_t == eps_s + (size_t)B * c->plan.dz) {        // (the sequence layout of eps: (2, B, dz))
         const int rc = filter_seq_mega(c, 1, B, y, u, eps_s, mu_s, lv_s, mu_t, lv_t, loss4, flags);
         if (rc != kMegaRefused) return rc;
@@ -1219,6 +1231,7 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
                    const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
     if (!c) return fail(-1, "vjf_filter_seq: null context");
     DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
+    VJF_CHAOS_REFRESH(c);
     if (T < 1) return fail(-23, "vjf_filter_seq: T=%d", T);
     if (!y || !eps || !mu || !lv) return fail(-1, "vjf_filter_seq: null tensor");
     const size_t sy = (size_t)B * c->plan.dy, su = (size_t)B * c->plan.du, sz = (size_t)B * c->plan.dz;

@@ -1218,8 +1218,10 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         // loop's operand load, the operand role's P += G / v, the y / W loop's tiles for the state-noise update).  The trial role's
         // forward half of step e - 1, which is all this event waited for, does not wait for that update: without this wait a late
         // RLS role -- the first steps of a process, instruction caches cold -- read sums of the wrong step.  Nothing is read behind it.
+#ifndef VJF_CHAOS_OMIT_GRAM_GUARD        /* (diagnostic builds: without the wait tools/chaos_handoffs.py must report deviations) */
         if (e >= 2 && !vjf_wg_wait_sc1(A.cnt + MG_C_PDONE, (unsigned)(e - 1) * (unsigned)(A.n_rls - 1), tid, SCW + VJF_SC_STATUS))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
+#endif
         if (!vjf_wg_wait_sc1(A.cnt + MG_C_GRAM, (unsigned)(e + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
