@@ -74,6 +74,18 @@ def main():
     y = torch.poisson(torch.exp(0.5 * torch.randn(T, B, 200, generator=g) - 0.5), generator=g).to(dev)
     u, eps = torch.randn(T, B, 2, generator=g).to(dev), torch.randn(T, 2, B, 10, generator=g).to(dev)
     bad += run(poisson, y, u, eps, reps_b, "Poisson d_y=200 n=160 B=1000 (ragged tiles), one launch", 1)
+
+    def two_cols():
+        torch.manual_seed(8)
+        return vjf.VJF.make_model(20, 16, 0, 64, [32, 32], likelihood="gaussian", lr=1e-3)
+    g = torch.Generator().manual_seed(10)
+    T, B = 6, 300
+    y, eps = torch.randn(T, B, 20, generator=g).to(dev), torch.randn(T, 2, B, 16, generator=g).to(dev)
+    bad += run(two_cols, y, None, eps, reps_b, "d_z=16 n=64 two layers B=300, one launch", 1)
+    g = torch.Generator().manual_seed(11)
+    T, B = 5, 12000                                              # (three tiles per trial workgroup)
+    y, eps = torch.randn(T, B, 50, generator=g).to(dev), torch.randn(T, 2, B, 10, generator=g).to(dev)
+    bad += run(config_b, y, None, eps, max(1, reps_b // 2), "configs[1] model, 12000 trials, one launch", 1)
     print("deviating sequences in all:", bad, flush=True)
     sys.exit(1 if bad else 0)
 

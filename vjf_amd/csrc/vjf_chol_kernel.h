@@ -653,6 +653,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // operands in registers: the state's P may now be overwritten
             __syncthreads();
             if (tid == 0) __hip_atomic_store(A.flags_out + VJF_CHOL_MAXBLK + 2, it_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            vjf_chaos(tid, A.wait_count, 1);
             if (A.sig_word && it_wait_target != 0u) {
                 // sigma inside the hand-off word: one poll, no second load; the exit count of the post workgroups is checked by the
                 // wavefront that writes the first column out (below)
@@ -754,6 +755,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
             }
         };
         auto publish = [&](int k0, int k1, unsigned fail) {             // one wavefront: its stores drained, then the flags
+            vjf_chaos(lane, A.flags_out + k0, 2);                       // (diagnostic builds: the wavefront is held)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane >= k0 && lane < k1) __hip_atomic_store(A.flags_out + lane, (it_epoch << 1) | fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };

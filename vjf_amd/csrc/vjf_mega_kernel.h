@@ -506,6 +506,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         bool rls_now = false;
         auto gate = [&]() {
             if (t > 0) {
+                vjf_chaos(tid, cnt + MG_C_SGD, 1);
                 if (tid == 0) {
                     bool there = false;
                     for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {

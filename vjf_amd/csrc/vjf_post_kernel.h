@@ -113,6 +113,7 @@ __device__ __forceinline__ float post_ld(const float* p) { return __hip_atomic_l
 // Wait (one lane polls, relaxed, bounded) until the Cholesky kernel has published flag word `k` for this epoch; the workgroup
 // barrier; then the sc1 loads of the column (see above).  Returns 0 = there, 1 = the factorisation failed, 2 = timed out.
 __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned epoch, int k, int* s_ctl, int tid, const float* status, bool fence = false) {
+    vjf_chaos(tid, flags + k, 1);
     if (tid == 0) {
         int st = 2;
         for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
@@ -137,6 +138,7 @@ __device__ __forceinline__ int post_wait_column(const unsigned* flags, unsigned 
 __device__ __forceinline__ void post_peek_columns(const unsigned* flags, unsigned epoch, int from, int kmax, bool wait_first,
                                                   const unsigned* prep_count, unsigned prep_target, int* s_ctl, int tid, const float* status,
                                                   bool fence = false) {
+    if (wait_first) vjf_chaos(tid, flags + from, 1);
     if (tid == 0) {
         int st = 0, kr = from - 1;
         if (wait_first) {
@@ -181,6 +183,7 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
     int* s_tab = reinterpret_cast<int*>(s_y + 32 * LX);        // [32..64): lower tiles incl. diagonal -> (bi << 8) | bj
     int* s_ctl = s_tab + 64;
     auto leave = [&]() {                                       // every workgroup, on every path, exactly once
+        vjf_chaos(tid, A.done, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (A.stamps && !solve && tid == 0) {                  // diagnostic: when the LAST inverse loop of the step is done
