@@ -1040,8 +1040,10 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
 #ifdef VJF_CHAOS
 // diagnostic build: which workgroups are held, and where (vjf_plan.h), from the environment at every entry
 static void chaos_refresh(const vjf_ctx* c) {
-    const int range[4] = {getenv("VJF_CHAOS_LO") ? atoi(getenv("VJF_CHAOS_LO")) : 0, getenv("VJF_CHAOS_HI") ? atoi(getenv("VJF_CHAOS_HI")) : 1 << 30,
-                          getenv("VJF_CHAOS_SITE") ? atoi(getenv("VJF_CHAOS_SITE")) : -1, getenv("VJF_CHAOS_KIND") ? atoi(getenv("VJF_CHAOS_KIND")) : 0};
+    const int range[6] = {getenv("VJF_CHAOS_LO") ? atoi(getenv("VJF_CHAOS_LO")) : 0, getenv("VJF_CHAOS_HI") ? atoi(getenv("VJF_CHAOS_HI")) : 1 << 30,
+                          getenv("VJF_CHAOS_SITE") ? atoi(getenv("VJF_CHAOS_SITE")) : -1, getenv("VJF_CHAOS_KIND") ? atoi(getenv("VJF_CHAOS_KIND")) : 0,
+                          getenv("VJF_CHAOS_TICKS") && atoi(getenv("VJF_CHAOS_TICKS")) > 0 ? atoi(getenv("VJF_CHAOS_TICKS")) : 20000,
+                          getenv("VJF_CHAOS_MASK") ? atoi(getenv("VJF_CHAOS_MASK")) : 7};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(vjf_chaos_range), range, sizeof(range));
     const unsigned* base = (const unsigned*)(c->ws + c->cv.mg_cnt);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(vjf_chaos_base), &base, sizeof(base));

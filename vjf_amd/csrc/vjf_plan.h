@@ -179,7 +179,8 @@ struct VjfJob {
 // -DVJF_CHAOS (diagnostic builds only, tools/chaos_handoffs.sh): one workgroup in eight is held for up to 200 us in front of a wait or
 // a signal, so that an access which is ordered by the usual timing of the roles and not by a hand-off shows as a wrong result.
 #ifdef VJF_CHAOS
-__device__ int vjf_chaos_range[4] = {0, 1 << 30, -1, 0};                    // workgroups [lo, hi) are held (VJF_CHAOS_LO / _HI) at count word [2] (-1: any; VJF_CHAOS_SITE), kind [3] (0 any, 1 waits, 2 signals)
+__device__ int vjf_chaos_range[6] = {0, 1 << 30, -1, 0, 20000, 7};          // workgroups [lo, hi) are held (VJF_CHAOS_LO / _HI) at count word [2] (-1: any; VJF_CHAOS_SITE), kind [3] (0 any, 1 waits, 2 signals),
+                                                                            // for up to [4] ticks of 10 ns (VJF_CHAOS_TICKS), one time in [5] + 1 (a mask; VJF_CHAOS_MASK)
 __device__ const unsigned* vjf_chaos_base = nullptr;
 #endif
 __device__ __forceinline__ void vjf_chaos(int tid, const unsigned* count, int kind) {
@@ -189,7 +190,7 @@ __device__ __forceinline__ void vjf_chaos(int tid, const unsigned* count, int ki
         const unsigned long long t0 = wall_clock64();                       // 100 MHz
         unsigned h = ((unsigned)t0 * 2654435761u) ^ (blockIdx.x * 40503u);
         h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
-        const unsigned d = (h & 7u) == 0u ? (h >> 8) % 20000u : 0u;
+        const unsigned d = (h & (unsigned)vjf_chaos_range[5]) == 0u ? (h >> 8) % (unsigned)vjf_chaos_range[4] : 0u;
         while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
     }
 #endif
