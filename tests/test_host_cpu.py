@@ -33,6 +33,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/vjf_hip.h but not exported"
     assert declared == set(N.SIGNATURES) | {"vjf_last_error"}, declared ^ (set(N.SIGNATURES) | {"vjf_last_error"})
     assert lib.vjf_abi_version() == N.ABI_VERSION
+    # the diagnostic build of the same sources (hand-offs under perturbed timing, tests/test_gpu_handoffs.py): the same interface
+    from vjf_amd import _build
+    chaos = C.CDLL(_build.build(chaos=True))
+    for name in sorted(declared):
+        assert hasattr(chaos, name), f"{name} missing from the diagnostic build"
+    assert chaos.vjf_abi_version() == N.ABI_VERSION
 
 
 def test_memory_plan_config_b():
