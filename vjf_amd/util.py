@@ -27,6 +27,9 @@ def storage_device() -> torch.device:
 def dev32(a, ndim2: bool = True) -> Tensor:
     """as_tensor -> fp32 -> device -> contiguous (-> at least 2-D), as VJF.filter coerces its inputs
     (vjf/model.py:194-198).  The device path computes in fp32 whatever torch's default dtype is."""
+    if (isinstance(a, Tensor) and a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and (a.ndim >= 2 or not ndim2)
+            and a.device.index == torch.cuda.current_device()):
+        return a                                   # (already what the library takes: the usual case inside a filtering loop)
     t = torch.as_tensor(a)
     t = t.to(device=storage_device(), dtype=torch.float32)
     if ndim2:
