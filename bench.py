@@ -23,6 +23,14 @@ import os
 import sys
 import time
 
+if os.environ.get("VJF_BENCH_MAPS"):      # diagnostic: the process's load map, written by the LAST exit hook of the interpreter
+    import atexit
+
+    def _dump_maps(dst=os.environ["VJF_BENCH_MAPS"]):
+        with open("/proc/self/maps") as f, open(dst, "w") as o:
+            o.write(f.read())
+    atexit.register(_dump_maps)
+
 import numpy as np
 import torch
 
@@ -139,8 +147,8 @@ def cpu_baseline(c, config, s32, q0, y_cpu, eps_cpu, budget_s=12.0):
     finally:
         orc.RBF_GEMM = False
     ref = REFERENCE_CPU.get(config, {})
-    return {"value": val, "unit": "trial-timesteps/s", "cores": int(threads), "kind": "port",
-            "sample": f"(BLAS threads: the fastest of 8/16/32/64/all over 3 steps each) {nstep} steps of the bench workload from the timed run's own state (B={c['B']}, fp32 numpy/BLAS oracle, O(B) variance "
+    return {"value": val, "unit": "trial-timesteps/s", "cores": int(os.cpu_count() or 1), "blas_threads": int(threads), "kind": "port",
+            "sample": f"(host cores: {os.cpu_count()}; BLAS threads: the fastest of 8/16/32/64/all over 3 steps each = {int(threads)}) {nstep} steps of the bench workload from the timed run's own state (B={c['B']}, fp32 numpy/BLAS oracle, O(B) variance "
                       f"form, GEMM distances), {dt:.1f} s; the reference's cost form ((B,B) product for its diagonal): "
                       f"{c['B'] * nf / dtf:.0f} trial-timesteps/s over {nf} steps; the UNMODIFIED reference (torch CPU) on the survey's 8 Xeon "
                       f"cores, BASELINE.md section 2: {json.dumps(ref)}",

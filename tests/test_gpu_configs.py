@@ -135,6 +135,36 @@ def test_config_E_full_width(vjf):
         assert torch.equal(getattr(lr, k2), keep[k2]), k2
 
 
+def test_config_E_at_bench_size(vjf):
+    """configs[4] at the size `bench.py --config E` times: B = 4096 trials, so that the dispatcher (vjf_abi.hip, launch_wide_gemm) takes
+    the 128 x 128-tile kernel `vjf_wide_gemm3_kernel<128, 16, 4, ...>` -- both operand layouts: W^T as torch stores it for the 512-wide
+    layers (`nt`), k-major for Z = Phi w_chol (4096 x 1000 x 1000) -- the kernels that carry the benchmarked step.  One `filter` step
+    and a two-step sequence against the fp64 oracle (posterior, loss terms, state)."""
+    c = dict(CFG_E, B=4096)
+    torch.manual_seed(14)
+    m = _model(vjf, c)
+    s = load_oracle_state(m, np.float64)
+    T = 3
+    y, eps = _data(c, T, 24)
+    yd, ed = y.cuda(), eps.cuda()
+    q, loss, *comp = m.filter(yd[0], None, None, verbose=True, eps=(ed[0, 0], ed[0, 1]))
+    o = orc.filter_step(s, y[0].numpy(), None, None, None, eps[0, 0].numpy(), eps[0, 1].numpy())
+    close(q.mean, o.mu_t, rtol=5e-5, atol=5e-5)
+    close(q.logvar, o.lv_t, rtol=5e-5, atol=5e-5)
+    close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
+    mu, lv, ls = m.filter_sequence(yd[1:], qs=q, eps=ed[1:])
+    om, ol = o.mu_t, o.lv_t
+    for t in range(1, T):
+        o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
+        om, ol = o.mu_t, o.lv_t
+        close(mu[t - 1], o.mu_t, rtol=1e-4, atol=1e-4)
+        close(lv[t - 1], o.lv_t, rtol=1e-4, atol=1e-4)
+        close(ls[t - 1], [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-4, atol=1e-4)
+    close(m.transition.logvar, s.tr_logvar, rtol=0, atol=5e-5)
+    state_close(m, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3, rls_atol=5e-5)
+    assert m.status() == 0 and m.route() == "per-step"
+
+
 def test_config_D_one_gpu_and_shard_sum(vjf):
     """configs[3]: 32768 trials.  (1) all of them on one GPU, two steps against the oracle (single step and sequence entry
     points); (2) the 8-shard protocol of the multi-GPU path on one device: eight `vjf_filter_local` calls of 4096 trials, their
@@ -222,15 +252,18 @@ def test_replay_with_several_tiles_per_workgroup(vjf):
 
 
 @pytest.mark.gpu
-def test_bench_line_contract():
+@pytest.mark.parametrize("config", ["B", "E"])
+def test_bench_line_contract(config):
     """`bench.py` as the round driver runs it (fewer steps): ONE JSON line with the contract's fields, the roofline and cpu_baseline
-    objects, the ELBO of the timed steps checked against the oracle inside the run, status clean."""
+    objects, the ELBO of the timed steps checked against the oracle inside the run, status clean.  `--config E`: the extra line of
+    configs[4] (its ELBO check is the oracle at B = 4096 on the GEMM-per-layer trial path)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "3", "--repeats", "2"],
+    extra = [] if config == "B" else ["--config", "E", "--elbo-steps", "2"]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "3", "--repeats", "2"] + extra,
                          capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
@@ -246,5 +279,5 @@ def test_bench_line_contract():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(d["value"] - 4096 * 12 / (d["ms_per_step"] * 1e-3 * 12)) / d["value"] < 1e-6
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] == os.cpu_count() and 1 <= c["blas_threads"] <= c["cores"] and c["sample"]
     assert d["elbo_check"]["ok"] and d["status_bits"] == 0

@@ -752,7 +752,10 @@ def test_gemm_dispatcher_shapes_against_fp64(vjf):
     from vjf_amd.util import stream_ptr
     g = torch.Generator().manual_seed(123)
     shapes = [(300, 640, 512), (257, 96, 65), (4096, 64, 512), (1000, 1000, 64), (1024, 1000, 1000), (513, 200, 300),
-              (33, 7, 5), (100, 37, 64), (256, 130, 256), (2000, 33, 129), (16, 512, 512), (384, 1000, 40), (4096, 10, 50)]
+              (33, 7, 5), (100, 37, 64), (256, 130, 256), (2000, 33, 129), (16, 512, 512), (384, 1000, 40), (4096, 10, 50),
+              # >= 192 tiles of 128 x 128: vjf_wide_gemm3_kernel<128, 16, 4, false, true> (configs[4]'s layers at B = 4096); rows,
+              # columns and depth off the tile and chunk sizes
+              (4096, 1000, 1000), (4096, 640, 1024), (4096, 512, 1000), (3100, 516, 900)]
     for (B, din, dout) in shapes:
         x = torch.randn(B, din, generator=g)
         W = torch.randn(dout, din, generator=g) / din ** 0.5
@@ -767,6 +770,66 @@ def test_gemm_dispatcher_shapes_against_fp64(vjf):
         out2 = torch.empty(B, dout, device="cuda")                         # no bias
         N.check(N.lib().vjf_linear_forward(N.ptr(xd), N.ptr(Wd), None, N.ptr(out2), B, din, dout, stream_ptr()), "vjf_linear_forward")
         assert ((out2.cpu().double() - (ref - b.double())).abs().max().item()) <= 4e-7 * scale + 1e-6, (B, din, dout)
+
+
+@pytest.mark.gpu
+def test_large_k_major_product_against_fp64(vjf):
+    """The 128 x 128-tile GEMM with a k-major B operand (`vjf_wide_gemm3_kernel<128, 16, 4, false, false>`: Z = Phi w_chol of
+    configs[4] at B = 4096) on its own, through `vjf_blr_sample`: w = w_mean + w_chol @ noise (vjf/module.py:71) is an
+    (n, n) x (n, dout) product with n = 2048 rows and dout = 1536 columns = 192 tiles; the sample Phi w against fp64."""
+    g = torch.Generator().manual_seed(77)
+    n, d, dout, B = 2048, 6, 1536, 40
+    torch.manual_seed(n)
+    blr = vjf.module.LinearRegression(vjf.module.RBF(d, n), dout)
+    blr.w_mean.copy_(torch.randn(n, dout, generator=g) * 0.3)
+    blr.w_chol.copy_(torch.triu(torch.randn(n, n, generator=g)) * 0.05)
+    x = torch.randn(B, d, generator=g)
+    noise = torch.randn(n, dout, generator=g)
+    smp = blr(x, sampling=True, noise=noise)
+    c, lw = blr.feature.centroid.cpu().double(), blr.feature.logwidth.cpu().double()
+    phi = torch.exp(-0.5 * ((x.double()[:, None, :] - c[None]) ** 2).sum(-1) / torch.exp(lw).reshape(1, -1) ** 2)
+    w = blr.w_mean.cpu().double() + blr.w_chol.cpu().double() @ noise.double()
+    ref = phi @ w
+    scale = (phi.abs() @ (blr.w_mean.cpu().double().abs() + blr.w_chol.cpu().double().abs() @ noise.double().abs())).max().item()
+    assert (smp.cpu().double() - ref).abs().max().item() <= 1e-6 * scale + 1e-6
+
+
+@pytest.mark.gpu
+def test_last_step_without_a_gradient_keeps_the_earlier_steps(vjf):
+    """A sequence whose LAST step has no finite loss component (a NaN observation: the reconstruction term, and through the
+    posterior of that trial the dynamics term and the entropy): the reference skips that step's optimizer.step() alone
+    (vjf/model.py:206-214) -- the SGD steps before it stay.  On the one-launch route the SGD role keeps its first round of
+    parameters in registers and writes the state blob at the last step of the launch: also when that step has no gradient.
+    The trained tensors after T steps against the fp32 oracle after the T - 1 steps that had a gradient."""
+    import warnings
+    from tests.helpers import model_arrays
+    B, dz, dy, n, T = 40, 3, 10, 16, 4
+    g = torch.Generator().manual_seed(41)
+    y = torch.randn(T, B, dy, generator=g)
+    eps = torch.randn(T, 2, B, dz, generator=g)
+    y[T - 1, 0, 0] = float("nan")
+    torch.manual_seed(40)
+    m = vjf.VJF.make_model(dy, dz, 0, n, [8], likelihood="gaussian", lr=1e-2)
+    s = load_oracle_state(m, np.float32)
+    w0 = m.recognition.mean.weight.clone()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mu, lv, loss = m.filter_sequence(y, eps=eps)
+        assert m.route() == "one-launch"
+        st = m.status()
+        assert (st & 7) == 7 and not (st & 0x1ff00), hex(st)
+        om = ol = None
+        for t in range(T - 1):
+            o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
+            om, ol = o.mu_t, o.lv_t
+            close(mu[t], o.mu_t, rtol=2e-4, atol=2e-4)
+            close(loss[t], [o.loss, o.recon, o.dyn, o.entropy], rtol=2e-4, atol=2e-4)
+    assert float(loss[T - 1, 0]) == 0.0                               # every component replaced by the constant 0 (model.py:138-145)
+    assert (m.recognition.mean.weight - w0).abs().max() > 1e-4       # the steps before it are in the blob
+    got = model_arrays(m)
+    want = {"mean_W": s.mean_W, "lv_W": s.lv_W, "lv_b": s.lv_b, "dec_W": s.dec_W, "dec_b": s.dec_b, "rec_W0": s.rec_W[0], "rec_b0": s.rec_b[0]}
+    for k, v in want.items():
+        close(got[k], np.asarray(v).reshape(got[k].shape), rtol=2e-3, atol=2e-4)
 
 
 @pytest.mark.gpu

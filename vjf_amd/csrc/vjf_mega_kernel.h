@@ -1533,12 +1533,21 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
                 vv[r] += __shfl_xor(vv[r], 2, 64);
                 vv[r] += __shfl_xor(vv[r], 4, 64);
             }
-            if (!act || part != 0 || !grad_ok || (grp == 1 && freeze)) return;     // (frozen decoder)
+            if (!act || part != 0 || (grp == 1 && freeze)) return;                 // (frozen decoder)
             const int pidx[4] = {pi.x, pi.y, pi.z, pi.w}, cidx[4] = {ci.x, ci.y, ci.z, ci.w};
             float* cdst = tl ? const_cast<float*>(A.img) : A.aux;
             // the state blob itself: nobody reads these parameters from it during the launch when the trial role has the image and
             // this lane group keeps them in registers -- then it is brought up to date at the last step only
             const bool wst = !tl || q0 != q00 || t == A.T - 1;
+            if (!grad_ok) {
+                // no step (model.py:206-214 skips optimizer.step() for this step alone): the steps before it, which this lane group
+                // has kept in registers, still have to reach the blob when this is the last step of the launch
+                if (tl && q0 == q00 && t == A.T - 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (pidx[r] >= 0) mg_st(S + P.train_off + pidx[r], wold[r]);
+                }
+                return;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (pidx[r] < 0) continue;                                     // (padding of the slab's rows)

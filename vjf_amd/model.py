@@ -14,9 +14,11 @@ Drop-in notes:
     in the reference's order (xs then xt), so `torch.manual_seed` reproduces the reference's
     trajectory; `noise="device"` draws on the GPU instead (faster, different stream).
 """
+import atexit
 import os
 import ctypes
 import logging
+import sys
 import weakref
 from itertools import zip_longest
 from typing import Sequence, Tuple, Union
@@ -44,6 +46,24 @@ except Exception:                      # pragma: no cover
             def __iter__(self_): return iter(range(n))
             def set_postfix(self_, *a, **k): pass
         return _R()
+
+
+# Native contexts are destroyed while the HIP runtime is alive: explicitly (`VJF.close()`), when a model is collected in a running
+# interpreter, or -- for whatever is left -- from this hook, which is registered when the module is imported (after torch, so it runs
+# BEFORE torch's and the HIP runtime's own exit handlers).  Nothing calls into the library from `__del__` during interpreter
+# finalisation: by then streams and communicators may be gone.
+_LIVE = weakref.WeakSet()
+
+
+def _close_all():
+    for m in list(_LIVE):
+        try:
+            m.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
 
 
 class LinearDecoder(Module):
@@ -381,6 +401,7 @@ class VJF(Module):
         N.check(L.vjf_ctx_create(ctypes.byref(cfg), N.ptr(self._blob), N.ptr(self._workspace), nbytes.value, stream_ptr(),
                                  ctypes.byref(ctx)), "vjf_ctx_create")
         self._ctx, self._ctx_batch = ctx, B
+        _LIVE.add(self)
         if getattr(self, "_overlap", 1) != 1:
             rc = L.vjf_set_overlap(ctx, int(self._overlap))
             if rc < 0:
@@ -390,10 +411,20 @@ class VJF(Module):
         o = p.value - self._workspace.data_ptr()
         self._reduce = self._workspace[o:o + 4 * n.value].view(torch.float32)
 
+    def close(self):
+        """Destroy the native context (its streams are synchronised first; RCCL communicators and the extra streams of the sharded
+        route are released).  The model stays usable: the next call makes a new context.  Called for every live model at
+        interpreter exit, before the HIP runtime's own exit handlers."""
+        ctx, self._ctx = self._ctx, None
+        self._ctx_batch = 0
+        if ctx is not None and self._lib is not None:
+            self._lib.vjf_ctx_destroy(ctx)
+
     def __del__(self):
+        if sys.is_finalizing():               # (no native call at interpreter shutdown: `_close_all` has run)
+            return
         try:
-            if self._ctx is not None and self._lib is not None:
-                self._lib.vjf_ctx_destroy(self._ctx)
+            self.close()
         except Exception:
             pass
 
