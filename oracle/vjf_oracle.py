@@ -233,6 +233,16 @@ def running_var(acc_var, acc_size, new_var, new_size, size_cap=1000):
     return f1 * acc_var + f2 * new_var, tot
 
 
+def _cholesky(P: np.ndarray) -> np.ndarray:
+    """Lower Cholesky factor IN THE DTYPE OF P (LAPACK spotrf / dpotrf through scipy), as torch.linalg.cholesky computes it for
+    the reference (vjf/module.py:99).  `np.linalg.cholesky` would not do: numpy evaluates every linalg routine in double and rounds
+    the result (numpy/linalg/_linalg.py, `_commonType`: "use higher precision (always double or cdouble)"), so on a float32 matrix
+    it returns the correctly rounded fp64 factor -- for an ill-conditioned precision matrix (few trials against many features)
+    two to three orders of magnitude closer to the exact factor than any fp32 factorisation, the reference's included
+    (tools/rls_accuracy_emu.py)."""
+    return sla.cholesky(P, lower=True, check_finite=False)
+
+
 def rls(s: OracleState, feat: np.ndarray, target: np.ndarray, v, shrink: float = 1.0):
     """Information-form recursive least squares on the RBF weights
     (vjf/module.py:79-112).  Mutates s.w_precision / w_pchol / w_mean / w_chol.
@@ -247,10 +257,10 @@ def rls(s: OracleState, feat: np.ndarray, target: np.ndarray, v, shrink: float =
     P = P * shrink + sf.T @ sf
     status = 0
     try:
-        L = np.linalg.cholesky(P)
+        L = _cholesky(P)
     except np.linalg.LinAlgError:
         lam = np.linalg.eigvalsh(P.astype(np.float64)).min()
-        L = np.linalg.cholesky(P + np.eye(P.shape[0], dtype=dt) * dt.type(abs(lam) * 2))
+        L = _cholesky(P + np.eye(P.shape[0], dtype=dt) * dt.type(abs(lam) * 2))
         status = 1
     s.w_pchol = L.astype(dt)
     s.w_precision = P.astype(dt)
@@ -464,7 +474,7 @@ def kalman_predict(x, L, A, Q, H):
     """vjf/kalman.py:15-50 with cholesky=True."""
     xhat = A @ x
     AL = A @ L
-    Vhat = np.linalg.cholesky(AL @ AL.T + Q)
+    Vhat = _cholesky(AL @ AL.T + Q)
     return H @ xhat, xhat, Vhat
 
 
@@ -474,14 +484,14 @@ def kalman_joseph_update(y, yhat, xhat, Lhat, H, R):
     Vhat = Lhat @ Lhat.T
     HL = H @ Lhat
     S = HL @ HL.T + R
-    L = np.linalg.cholesky(S)
+    L = _cholesky(S)
     G = sla.cho_solve((L, True), H @ Vhat).T
     x = xhat + G @ sla.cho_solve((L, True), e)
     ImKH = np.eye(Vhat.shape[0], dtype=Vhat.dtype) - G @ sla.cho_solve((L, True), H)
     ImKHL = ImKH @ Lhat
     KR = G @ sla.cho_solve((L, True), np.sqrt(R))
     V = ImKHL @ ImKHL.T + KR @ KR.T
-    return x, np.linalg.cholesky(V)
+    return x, _cholesky(V)
 
 
 def blr_kalman(s: OracleState, xu, target, v, diffusion=0.0):
