@@ -127,9 +127,9 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status);
 
 /* Which schedule vjf_filter_seq / vjf_filter_step use on a single rank (results agree to summation order; the one-launch and
  * three-stream routes are bit-identical to each other):
- *   1 (default)  the one-launch route: ONE cooperative launch carries the whole call; the trial, Gram, operand, SGD and RLS
- *                roles are workgroups of one resident grid that hand over through counters in memory (plans it serves: see
- *                vjf_route);
+ *   1 (default)  the one-launch route: ONE launch carries the whole call; the trial, Gram, operand, SGD and RLS roles are
+ *                workgroups of one grid, resident as a whole (checked against the occupancy query before it is launched), that
+ *                hand over through counters in memory (plans it serves: see vjf_route);
  *   3            the per-step route on three internal streams (the route the RCCL path uses), for A/B measurements;
  *   0            the per-step kernels in the one-stream order (also what tools that serialise kernels need).
  * Returns the resulting setting, or a negative error code. */
@@ -182,7 +182,7 @@ int vjf_filter_global(vjf_ctx* ctx, int32_t B_total, float* loss4, uint32_t flag
  * (model.py:252-261).  y (T,B,ydim); u (T,B,udim) or NULL; eps (T,2,B,xdim);
  * mu0/lv0 (B,xdim) or NULL => prior; outputs mu, lv (T,B,xdim), loss (T,4).
  * On a single rank with sgd + update and no warm-up (plans the one-launch route serves: see vjf_route) the whole call -- per
- * chunk of 16384 steps -- is ONE cooperative kernel launch; the call stays asynchronous.  With communicators (vjf_comm_init)
+ * chunk of 16384 steps -- is ONE kernel launch (a grid resident as a whole); the call stays asynchronous.  With communicators (vjf_comm_init)
  * the steps run as per-step kernels on three internal streams with the sums over ranks done by RCCL; otherwise step by step
  * on the caller's stream.  Every in-kernel wait is bounded: one that runs out raises VJF_STATUS_RLS_FAILED plus a
  * VJF_STATUS_WAIT_* detail bit (vjf_get_status), ends the other waits of the call at once, and the outputs of the call are

@@ -31,3 +31,24 @@ def test_random_configurations_of_every_plan_family():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "48", "0"], capture_output=True, text=True, timeout=900)
     tail = "\n".join(l for l in (r.stdout + r.stderr).splitlines() if "amdgpu.ids" not in l and " ok " not in l)[-3000:]
     assert "failures: 0 of 48" in r.stdout, tail
+
+
+def _hard_cases():
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from tools.fuzz_parity import KNOWN_HARD
+    return KNOWN_HARD
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,desc", _hard_cases(), ids=lambda v: (f"case{v}" if isinstance(v, int) else f"B{v['B']}_n{v['n']}_{v['lik']}"))
+def test_few_trials_against_many_features(case, desc):
+    """The seven configurations that failed round 2's random sweeps (seeds 21, 22, 33 and an earlier draw order), pinned by their
+    full description: B = 1 ... 9 trials against 214 ... 1289 features, the precision matrix grows 10^4-fold in two steps
+    (cond 1e5).  Three steps each against the fp64 oracle; where the fixed tolerance is not met the device must be no further
+    from fp64 than three times the oracle run in the reference's OWN arithmetic -- an fp32 LAPACK factorisation, as
+    torch.linalg.cholesky does it (vjf/module.py:99); round 2 measured against numpy's, which works in double."""
+    from tools.fuzz_parity import run_case
+    route, notes = run_case(case, desc)
+    assert route in ("per-step", "one-launch")

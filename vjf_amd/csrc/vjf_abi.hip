@@ -155,7 +155,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 constexpr size_t kMegaLds = kMaxLds - 512;             // dynamic LDS of every workgroup of the launch (one workgroup per CU)
 constexpr int kMegaMaxTrialWg = 256, kMegaMaxGramWg = 64;
 struct MegaShape { int n_rls, n_trial, n_gram, n_prep, n_sgd, ntiles, gram_rows; };
-constexpr int kMegaRefused = 1 << 20;                  // filter_seq_mega: the runtime refused the cooperative launch (not an error code of the ABI)
+constexpr int kMegaRefused = 1 << 20;                  // filter_seq_mega: the grid cannot be resident as a whole (not an error code of the ABI)
 
 bool mega_plan_ok(const VjfPlan& P) {
     const int nbl = (P.n + 31) / 32;
@@ -283,6 +283,7 @@ struct vjf_ctx {
     bool force_streams;    // vjf_set_overlap(ctx, 3): the three-stream per-step route on a single rank too (A/B measurements)
     bool mega_ok;          // the plan fits the one-launch route (vjf_mega_kernel.h)
     int ncu;               // compute units of the device: the one-launch grid has one workgroup per CU
+    int mega_wg_per_cu;    // workgroups of vjf_mega_kernel a compute unit can hold (occupancy query): the residency check of the route
     hipStream_t stream2, stream3;
     hipEvent_t ev_s, ev_c;
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
@@ -375,9 +376,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
         int v = 0;
         VJF_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device));
         c->ncu = v;
-        int coop = 0;
-        VJF_HIP(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, cfg->device));
-        if (!coop) c->mega_ok = false;
+        c->mega_wg_per_cu = 0;
     }
     c->start_count = 0;
     c->stream2 = c->stream3 = nullptr; c->ev_s = c->ev_c = nullptr;
@@ -457,7 +456,13 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     allow_lds(vjf_chol_lds_kernel<32>, c->lds_chol);
     allow_lds(vjf_rls_pair_kernel<4>, c->lds_chol); allow_lds(vjf_rls_pair_kernel<8>, c->lds_chol);
     allow_lds(vjf_rls_pair_kernel<12>, c->lds_chol); allow_lds(vjf_rls_pair_kernel<16>, c->lds_chol);
-    if (c->mega_ok) allow_lds(vjf_mega_kernel, kMegaLds);
+    if (c->mega_ok) {
+        allow_lds(vjf_mega_kernel, kMegaLds);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, vjf_mega_kernel, VJF_MG_THREADS, kMegaLds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        c->mega_wg_per_cu = nb;
+        if (nb < 1) c->mega_ok = false;
+    }
     *out = c;
     return 0;
 }
@@ -777,7 +782,7 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
 // Cholesky workgroup, y / W workgroup, inverse workgroups -- then goes out as ONE launch on `st`, whose workgroups hand the columns
 // of L to each other through flags (all of them belong to one grid; the operand kernel precedes it in `st`, so g is in place).
 int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, bool one_launch, hipEvent_t stop = nullptr,
-               bool no_triclean = false) {
+               bool no_triclean = false, const VjfTrialArgs* ta = nullptr) {
     const VjfPlan& P = c->plan;
     if (!(flags & VJF_FLAG_UPDATE)) return 0;
     VjfCholArgs a{};
@@ -813,6 +818,13 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
         pa.done = colflags + 32; pa.started = colflags + 24; c->post_count += (unsigned)(2 * nbl + 1);
         c->start_count += (unsigned)(2 * nbl + 1);
         pa.red = red; pa.B_total = B_total; pa.fold_sigma = 1; pa.acquire = c->handoff_acquire ? 1 : 0; pa.stamps = a.stamps;
+        // Fewer trials than features on a rank that holds them all (the rows of [Phi | dx] are in the workspace): the new weights
+        // reproduce dx almost exactly, and the quadratic form of the statistics, sum|dx|^2 - 2 tr(W^T Phi^T dx) + tr(W^T G W),
+        // loses the residual under the fp32 rounding of its terms (sigma 1e-5 off where the reference's arithmetic is at 1e-6).
+        // The residual is then formed as the reference forms it, dx - Phi W (vjf/model.py:373-374), behind the update: three
+        // short launches on a route that is launch-bound anyway.
+        const bool direct = ta && !pair && B_total < P.n && ta->B == B_total;
+        if (direct) pa.fold_sigma = 0;
         if (pair) {
             pa.role = 2;
             const dim3 grid(2 + 2 * nbl);
@@ -823,9 +835,21 @@ int launch_rls(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hi
                 default: VJF_LAUNCH(vjf_rls_pair_kernel<16>, grid, dim3(VJF_CHOL_THREADS), c->lds_chol, st, stop, P, a, pa); break;
             }
         } else {
-            VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st, stop, P, pa);
+            VJF_LAUNCH(vjf_rls_post_kernel, dim3(2 * nbl + 1), dim3(VJF_POST_THREADS), c->lds_post, st, direct ? nullptr : stop, P, pa);
         }
         VJF_HIP(hipGetLastError());
+        if (direct) {
+            VjfWideGemm g{};
+            float* R = ta->DEL;                                    // (free: the gradient sums -- and a replay's -- are formed)
+            g.A = ta->E; g.lda = P.ldE; g.Bm = c->state + P.off[VJF_SLOT_W_MEAN]; g.ldb = P.dz; g.C = R; g.ldc = P.dz;
+            g.M = ta->B; g.N = P.dz; g.K = P.n; g.epi = WEPI_NONE;
+            launch_wide_gemm(g, st);
+            VjfResidArgs ra{};
+            ra.state = c->state; ra.red = red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
+            hipLaunchKernelGGL(vjf_resid_direct_kernel, dim3(VJF_RESID_BLOCKS), dim3(256), 0, st, P, ra, (const float*)ta->E, (const float*)R, ta->B);
+            VJF_LAUNCH(vjf_sigma_kernel, dim3(1), dim3(64), 0, st, stop, P, ra, (const int*)nullptr, 1);
+            VJF_HIP(hipGetLastError());
+        }
     } else {
         VjfResidArgs ra{};
         ra.state = c->state; ra.red = red; ra.partial = rpart; ra.B_total = B_total; ra.flags = flags;
@@ -857,7 +881,8 @@ int ensure_stream2(vjf_ctx* c) {
     return 0;
 }
 
-// ---- the one-launch route (single rank; sgd + update, no warm-up): one cooperative launch of vjf_mega_kernel per chunk of steps
+// ---- the one-launch route (single rank; sgd + update, no warm-up): one launch of vjf_mega_kernel -- a grid that is resident as a
+//      whole -- per chunk of steps
 int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
                     const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
     const VjfPlan& P = c->plan;
@@ -916,7 +941,6 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     Q.prep_count = cnt + MG_C_PREP; Q.prep_target = (unsigned)m.n_prep; Q.prep_stride = (unsigned)m.n_prep;
     Q.nsteps = T; Q.step0 = 0; Q.role = 2;
     VjfPlan Pk = P;
-    void* args[] = {(void*)&Pk, (void*)&A, (void*)&C, (void*)&Q};
     const int grid = m.n_rls + m.n_trial + m.n_gram + m.n_prep + m.n_sgd;
 #ifdef VJF_CHAOS
     {
@@ -925,20 +949,23 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
         told = true;
     }
 #endif
-    static const bool plain = getenv("VJF_DEBUG_PLAIN_LAUNCH") && atoi(getenv("VJF_DEBUG_PLAIN_LAUNCH")) != 0;   // (measurements only)
-    if (plain) {
-        hipLaunchKernelGGL(vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), kMegaLds, c->stream, Pk, A, C, Q);
-        VJF_HIP(hipGetLastError());
-        return 0;
-    }
-    // A cooperative launch is refused when the grid cannot be resident as a whole -- compute units masked off or held by another
-    // process: the context then leaves this route for good and the caller's entry point goes on with the per-step kernels
-    // (nothing of the state has been touched yet).
+    // One resident grid: every wait in it is for a workgroup of the SAME launch, so the whole grid must be on the device at once.
+    // The check is the one hipLaunchCooperativeKernel makes -- workgroups per compute unit (occupancy query, made once when the
+    // context is created) x compute units >= grid -- and the launch itself is a plain one: identical residency (MI355X guide,
+    // "Residency and cooperative launch"), and no cooperative queue.  That queue is why the API is avoided: a process that has
+    // made ONE cooperative launch faults in the HIP runtime's exit handler when it runs under rocprofv3 (hsa queue teardown behind
+    // the profiler's finalisation; tools/coop_exit_repro.hip shows it with 20 lines and no other library) -- every profile of
+    // round 2 ended in SIGSEGV for this reason.  When the grid does not fit -- compute units masked off, a smaller part -- the
+    // context leaves this route for good and the caller's entry point goes on with the per-step kernels (nothing of the state
+    // has been touched yet).
     const char* refuse = getenv("VJF_DEBUG_REFUSE_COOP");                  // (test hook)
-    const hipError_t le = (refuse && atoi(refuse)) ? hipErrorCooperativeLaunchTooLarge
-                          : hipLaunchCooperativeKernel((const void*)vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), args, (unsigned)kMegaLds, c->stream);
-    if (le == hipErrorCooperativeLaunchTooLarge || le == hipErrorLaunchOutOfResources) {
-        (void)hipGetLastError();
+    if ((refuse && atoi(refuse)) || c->mega_wg_per_cu < 1 || grid > c->mega_wg_per_cu * c->ncu) {
+        c->mega_ok = false;
+        return kMegaRefused;
+    }
+    hipLaunchKernelGGL(vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), kMegaLds, c->stream, Pk, A, C, Q);
+    const hipError_t le = hipGetLastError();
+    if (le == hipErrorLaunchOutOfResources) {
         c->mega_ok = false;
         return kMegaRefused;
     }
@@ -1151,7 +1178,7 @@ int filter_global_impl(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags
         int rc = launch_prep(c, B_total, loss4, flags, red, 0, c->stream, nullptr, 0, nullptr, 0, replay ? 1 : 0);
         if (rc) return rc;
         if (replay && (rc = launch_replay(c, *ta, B_total, flags, c->stream))) return rc;
-        return launch_rls(c, B_total, flags, red, c->stream, false);
+        return launch_rls(c, B_total, flags, red, c->stream, false, nullptr, false, ta);
     }
     if (c->plan.n > 32 * VJF_CHOL_MAXBLK) {
         // feature counts beyond one CU's LDS: clip + SGD and scalars in the prep kernel, then the RLS update as a sequence of

@@ -1,7 +1,7 @@
-// vjf_mega_kernel.h -- vjf_filter_seq / vjf_filter_step on a single rank as ONE cooperative launch per chunk of steps.
+// vjf_mega_kernel.h -- vjf_filter_seq / vjf_filter_step on a single rank as ONE launch (a grid resident as a whole) per chunk of steps.
 //
 // Every piece of a filtering step (vjf/model.py:179-221) is a ROLE played by workgroups of the same grid, one workgroup per
-// compute unit, all resident for the whole chunk (the launch is cooperative: the runtime refuses a grid that does not fit):
+// compute unit, all resident for the whole chunk (the host launches the grid only if the occupancy query says all of it fits):
 //
 //   RLS roles        workgroup 0: the Cholesky loop (vjf_chol_loop), 1: the y / W loop, 2 .. 1 + 2 nbl: the inverse loops
 //                    (vjf_rls_post_loop) -- module.py:94-102, model.py:373-377, exactly as before
