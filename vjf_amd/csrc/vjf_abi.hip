@@ -1193,6 +1193,7 @@ int filter_global_impl(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags
     VjfSerialArgs s{};
     s.state = c->state; s.red = (const float*)(c->ws + c->cv.red); s.work = (float*)(c->ws + c->cv.work);
     s.loss4 = loss4; s.B_total = B_total; s.flags = flags;
+    s.E = (ta && ta->B == B_total && B_total < c->plan.n) ? ta->E : nullptr;
     hipLaunchKernelGGL(vjf_serial_kernel, dim3(1), dim3(VJF_K2_THREADS), c->lds_k2, c->stream, c->plan, s);
     VJF_HIP(hipGetLastError());
     return 0;

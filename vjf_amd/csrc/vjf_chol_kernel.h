@@ -628,6 +628,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         s_bj[tid] = tid - bi * (bi + 1) / 2;
     }
     if (tid == 0) s_flag[0] = 1;
+    if (tid < 8) s_flag[128 + tid] = 0;                 // the column loop's hand-off words (below)
     __syncthreads();
     if (A.stat_count && (!vjf_wg_wait(A.stat_count, it_stat_target, tid, SC + VJF_SC_STATUS) || (A.inject_epoch && tid == 0 && it_epoch == A.inject_epoch))) {
         vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_STATS);
@@ -759,54 +760,125 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane >= k0 && lane < k1) __hip_atomic_store(A.flags_out + lane, (it_epoch << 1) | fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        int kdone = 0;                                                  // iterations completed = columns published
-        for (int k = 0; k < nbl; ++k) {
-            if (!s_flag[0]) break;
-            {                                                          // panel: L_ik = A_ik L_kk^-T, a plain block product
-                const float* ik = s_aux + (size_t)k * 1024;
-                for (int bi = k + 1 + wave; bi < nbl; bi += VJF_CHOL_THREADS / 64) {
-                    float* pb = s_blk + (size_t)vtri(bi, k) * 1024;
-                    vjf_f32x16 acc;
+        // ---- The column loop without a workgroup barrier in it.  The dependent chain -- Dinv_k from the factor chain of block (k,k),
+        //      the one panel tile L_{k+1,k} = A_{k+1,k} Dinv_k^T, the last update of block (k+1,k+1), the next chain -- runs on
+        //      wavefront 0 alone, back to back (3.4 us a column); it never waits for the bulk of a column's multiply-adds.  Those --
+        //      the other panel tiles and the trailing updates of column k -- belong to six helper wavefronts (1-3, 5-7: the three
+        //      other SIMDs), which work one column behind it in two stages per column (panels | trailing tiles) separated by a
+        //      counter barrier of their own, and which take the two tiles the chain needs next, (k+2,k+1) and (k+2,k+2), first.
+        //      Wavefront 4 (the chain's SIMD: no matrix-core work) writes finished columns out.  All hand-offs are words in LDS:
+        //        c_chain  = columns whose Dinv is in LDS             (wavefront 0)
+        //        c_p1     = columns whose tile L_{k+1,k} is in LDS   (wavefront 0)
+        //        c_a, c_b = columns k whose update of tile (k+2,k+1) / (k+2,k+2) is done (helpers)
+        //        c_hb     = helper arrivals: stage s is complete when c_hb >= 6 (s + 1)
+        //      Every update of a tile is applied in column order by construction (stage barriers), so the bits do not depend on
+        //      timing.  Polls are bounded: a logic error shows as a failed factorisation, not as a hang.
+        volatile int* s_ctl = s_flag + 128;
+        enum { C_CHAIN = 0, C_P1 = 1, C_A = 2, C_B = 3, C_HB = 4 };
+        volatile int* v_ok = s_flag;                                   // [0]: 1 while every pivot was positive (wavefront 0 clears it)
+        auto lds_wait = [&](int w, int target) {                       // one wavefront: all lanes poll the same word
+            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                if (s_ctl[w] >= target || !v_ok[0]) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (s_ctl[w] < target && v_ok[0]) v_ok[0] = 0;             // (cannot happen: ends the step as a failed factorisation)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        auto lds_post = [&](int w, int v) {                            // this wavefront's LDS writes first, then the word
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) s_ctl[w] = v;
+        };
+        auto hb_arrive = [&]() {                                       // a helper's stage is done
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(s_ctl + C_HB), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto panel_tile = [&](int bi, int k) {                         // L_ik = A_ik Dinv_k^T, in place (one wavefront reads all of it first)
+            float* pb = s_blk + (size_t)vtri(bi, k) * 1024;
+            vjf_f32x16 acc;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                    blk_mma<true>(acc, pb, ik, 1.f, lane);
-                    blk_store(acc, pb, lane);                           // same wavefront read all of pb before writing
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            blk_mma<true>(acc, pb, s_aux + (size_t)k * 1024, 1.f, lane);
+            blk_store(acc, pb, lane);
+        };
+        auto trail_tile = [&](int bi, int bj, int k) {                 // A_ij -= L_ik L_jk^T
+            float* cb = s_blk + (size_t)vtri(bi, bj) * 1024;
+            vjf_f32x16 acc;
+            blk_load(acc, cb, lane);
+            blk_mma<true>(acc, s_blk + (size_t)vtri(bi, k) * 1024, s_blk + (size_t)vtri(bj, k) * 1024, -1.f, lane);
+            blk_store(acc, cb, lane);
+        };
+        int kdone = 0;                                                  // wavefront 4: columns written out (their flags stored)
+        if (wave == 0) {
+            for (int k = 0; k < nbl; ++k) {                             // (chain(0) ran before the barrier above)
+                if (!v_ok[0]) break;
+                lds_post(C_CHAIN, k + 1);
+                if (k + 1 < nbl) {
+                    if (k >= 1) lds_wait(C_A, k);                       // tile (k+1,k) carries the updates of columns < k
+                    if (!v_ok[0]) break;
+                    panel_tile(k + 1, k);
+                    lds_post(C_P1, k + 1);
+                    if (k == 0) VJF_STAMP(8);
+                    if (k >= 1) lds_wait(C_B, k);                       // tile (k+1,k+1) carries the updates of columns < k
+                    if (!v_ok[0]) break;
+                    trail_tile(k + 1, k + 1, k);
+                    if (k == 0) VJF_STAMP(4);
+                    diag_chain(k + 1);
+                    if (k == 0) VJF_STAMP(5);
                 }
+                if (k < 7) VJF_STAMP(9 + k);
             }
-            if (k == 0) VJF_STAMP(8);
-            __syncthreads();
-            if (k == 0) VJF_STAMP(3);
-            {
-                const int m = nbl - 1 - k, nt = m * (m + 1) / 2;
-                if (wave == 0) {
-                    if (nt > 0) { trail(k, 0); if (k == 0) VJF_STAMP(4); diag_chain(k + 1); if (k == 0) VJF_STAMP(5); }    // block (k+1,k+1), then the next chain
-                } else if (wave == 4) {
-                    // (wavefront 4 shares wavefront 0's SIMD: it keeps off the matrix core while the chain runs there)
-                    if (A.post) {
-                        // column k of L and Dinv_k are final: out they go beside the next chain.  Their flag follows one phase
-                        // later, when the write-through stores have long drained: this wavefront never holds up the phase barrier
-                        if (k > 0) publish(k - 1, k, 0u);
-                        if (k == 0 && lscr_guard) {                     // (this wavefront alone writes the scratch copies)
-                            bool there = false;
-                            for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
-                                if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - it_wait_target) >= 0) { there = true; break; }
-                                if ((spins & 255u) == 255u && vjf_abort_seen(SC + VJF_SC_STATUS)) break;
-                                __builtin_amdgcn_s_sleep(1);
-                            }
-                            if (!there && lane == 0) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
+        } else if (wave == 4) {
+            if (A.post) {
+                for (int k = 0; k < nbl; ++k) {
+                    // column k of L and Dinv_k out, write-through, as soon as they are final; their flag once the stores have
+                    // drained (nobody waits for this wavefront inside the workgroup)
+                    lds_wait(C_CHAIN, k + 1);
+                    if (k + 1 < nbl) { lds_wait(C_P1, k + 1); lds_wait(C_HB, 6 * (2 * k + 1)); }
+                    if (!v_ok[0]) break;
+                    if (k == 0 && lscr_guard) {                         // (this wavefront alone writes the scratch copies)
+                        bool there = false;
+                        for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
+                            if ((int)(__hip_atomic_load(A.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - it_wait_target) >= 0) { there = true; break; }
+                            if ((spins & 255u) == 255u && vjf_abort_seen(SC + VJF_SC_STATUS)) break;
+                            __builtin_amdgcn_s_sleep(1);
                         }
-                        for (int it = 0; it < nbl - k; ++it) put_block(s_blk + (size_t)vtri(k + it, k) * 1024, A.lscr, n, (k + it) * 32, k * 32, it == 0);
-                        put_block(s_aux + (size_t)k * 1024, A.dinv_out + (size_t)k * 1024, 32, 0, 0, false);
-                        if (k == nbl - 1) publish(k, k + 1, 0u);
+                        if (!there && lane == 0) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
                     }
-                } else {
-                    for (int t = 1 + (wave < 4 ? wave - 1 : wave - 2); t < nt; t += VJF_CHOL_THREADS / 64 - 2) trail(k, t);
+                    for (int it = 0; it < nbl - k; ++it) put_block(s_blk + (size_t)vtri(k + it, k) * 1024, A.lscr, n, (k + it) * 32, k * 32, it == 0);
+                    put_block(s_aux + (size_t)k * 1024, A.dinv_out + (size_t)k * 1024, 32, 0, 0, false);
+                    publish(k, k + 1, 0u);
+                    kdone = k + 1;
                 }
             }
-            __syncthreads();
-            kdone = k + 1;
-            if (k < 7) VJF_STAMP(9 + k);
+        } else {
+            const int hw = wave < 4 ? wave - 1 : wave - 2;              // helper 0 .. 5
+            int stage = 0;
+            for (int k = 0; k + 1 < nbl; ++k) {
+                lds_wait(C_CHAIN, k + 1);
+                if (!v_ok[0]) break;
+                for (int bi = k + 2 + hw; bi < nbl; bi += 6) panel_tile(bi, k);
+                hb_arrive();
+                ++stage;
+                lds_wait(C_HB, 6 * stage);
+                if (!v_ok[0]) break;
+                // trailing tiles of column k: (k+1+r, k+1+c), 0 <= c <= r < m, without (0,0) (the chain's own)
+                const int m = nbl - 1 - k;
+                if (m >= 2) {
+                    if (hw == 0) { lds_wait(C_P1, k + 1); if (v_ok[0]) { trail_tile(k + 2, k + 1, k); lds_post(C_A, k + 1); } }
+                    if (hw == 1) { trail_tile(k + 2, k + 2, k); lds_post(C_B, k + 1); }
+                    for (int r = 2; r < m; ++r)                         // the rest of block column k + 1
+                        if (r % 6 == hw) { lds_wait(C_P1, k + 1); if (v_ok[0]) trail_tile(k + 1 + r, k + 1, k); }
+                    int q = m;
+                    for (int r = 2; r < m; ++r)
+                        for (int c2 = 1; c2 <= r; ++c2, ++q)
+                            if (q % 6 == hw) trail_tile(k + 1 + r, k + 1 + c2, k);
+                }
+                hb_arrive();
+                ++stage;
+                lds_wait(C_HB, 6 * stage);
+            }
         }
+        __syncthreads();
         const bool ok = s_flag[0] != 0;
         VJF_STAMP(2);
         if (!ok) {
@@ -829,10 +901,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                     }
                 }
                 // columns published so far are those of iterations that completed; every other flag says "failed"
-                if (wave == 4) {
-                    if (kdone > 0) publish(kdone - 1, kdone, 0u);      // (stored in the last completed phase, flag still due)
-                    publish(kdone, VJF_CHOL_MAXBLK + 1, 1u);
-                }
+                if (wave == 4) publish(kdone, VJF_CHOL_MAXBLK + 1, 1u);
                 if (tid == 0) { A.ok_out[0] = 0; vjf_status_or(SC + VJF_SC_STATUS, st); }
                 return;
             }

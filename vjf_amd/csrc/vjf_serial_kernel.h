@@ -29,6 +29,8 @@ struct VjfSerialArgs {
     float* loss4;         // device, may be null
     int B_total;
     unsigned flags;
+    const float* E;       // non-null: this rank's rows [Phi | dx | 0] of ALL B_total trials (ldE floats each), and B_total < n -- the
+                          //   state-noise residual is then formed directly, dx - Phi W (model.py:373-374), not from the statistics
 };
 
 static inline size_t vjf_serial_work_floats(const VjfPlan& P) {
@@ -432,6 +434,18 @@ __global__ __launch_bounds__(VJF_K2_THREADS) void vjf_serial_kernel(VjfPlan P, V
             st |= vjf_rls_device(n, dz, expf(-sig), 1.0f, Pm, Wm, Wc, Lm, G, FDX, A.work, lds);
         // residual mean square with the (possibly new) W, fp64 accumulation
         double part = 0.0;
+        if (A.E) {
+            // few trials against many features: the weights reproduce dx almost exactly and the quadratic form below loses the
+            // residual under the rounding of its terms; the difference in fp32 as the reference forms it, the sum in fp64
+            for (int e = tid; e < A.B_total * dz; e += VJF_K2_THREADS) {
+                const int b = e / dz, c = e - b * dz;
+                const float* row = A.E + (size_t)b * P.ldE;
+                float r = 0.f;
+                for (int k = 0; k < n; ++k) r = fmaf(row[k], Wm[(size_t)k * dz + c], r);
+                r = row[n + c] - r;
+                part += (double)r * (double)r;
+            }
+        } else {
         for (int e = tid; e < n * n; e += VJF_K2_THREADS) {
             const int i = e / n, j = e - i * n;
             float d = 0.f;
@@ -439,12 +453,13 @@ __global__ __launch_bounds__(VJF_K2_THREADS) void vjf_serial_kernel(VjfPlan P, V
             part += (double)G[e] * (double)d;
         }
         for (int e = tid; e < n * dz; e += VJF_K2_THREADS) part -= 2.0 * (double)Wm[e] * (double)FDX[e];
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
         if ((tid & 63) == 0) s_dred[tid >> 6] = part;
         __syncthreads();
         if (tid == 0) {
-            double t = (double)sdx2;
+            double t = A.E ? 0.0 : (double)sdx2;
             for (int w = 0; w < VJF_K2_THREADS / 64; ++w) t += s_dred[w];
             if (t < 0.0) t = 0.0;
             const float mse = (float)(t / ((double)Bf * (double)dz));
