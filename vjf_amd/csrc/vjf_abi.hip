@@ -241,7 +241,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
         c.mg_stamps = take((32 * 32 + kMegaMaxTrialWg * 8) * 8);   // ring of role stamps | 8 words per trial workgroup (last step)
         c.mg_pidx = take(slab_len * 4); c.mg_cidx = take(slab_len * 4); c.mg_grp = take(slab_len);
         c.mg_img = take((size_t)vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).th_len * 4 + 64);   // the parameters in the trial role's LDS layout
-        c.mg_pmsave = take((size_t)max_batch * (P.dz + 1) * 4);
+        c.mg_pmsave = take((size_t)2 * max_batch * (P.dz + 1) * 4);
     }
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);

@@ -63,7 +63,7 @@ struct VjfMegaArgs {
     float* mu; float* lv; float* loss;
     float* state; float* aux;
     const float* img;                                 // the optimised parameters as the trial role's LDS holds them (vjf_mega_trial_lds: theta region)
-    float* pmsave;                                    // (B, dz + 1): pt.mean | pt.logvar of every trial at its last step (for a replayed backward pass)
+    float* pmsave;                                    // 2 x (B, dz + 1), by the parity of the step: pt.mean | pt.logvar of every trial (for a replayed backward pass)
     float* slab_early; float* slab_late; float* gslab;
     float* red0; float* red1;                         // reduce buffers of even / odd steps ([G | FDX | sums], as the RLS loops read them)
     float* gbuf;                                      // g (n, dz)
@@ -500,10 +500,8 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         float sig = sig_prev, rho = rho_prev;          // (a replayed pass: the values its step ran with)
         bool tri = false, rls_in = replay;
         // the parameters of step t - 1 (the SGD role's write-through stores) and its verdict on that step's loss
-        // One lane polls the SGD role's count; once it is there it looks -- once -- at the RLS roles' count of the same step, and
-        // at the verdict word.  No acquire: what the trial role takes from other roles (the parameter image, W, w_chol, sigma, rho)
+        // One lane polls the SGD role's count; once it is there it looks -- once -- at the verdict word.  No acquire: what the trial role takes from other roles (the parameter image, W, w_chol, sigma, rho)
         // it reads with sc1 loads behind this poll and the workgroup barrier (MI355X guide, "sc1 loads in place of the acquire").
-        bool rls_now = false;
         auto gate = [&]() {
             if (t > 0) {
                 vjf_chaos(tid, cnt + MG_C_SGD, 1);
@@ -514,18 +512,16 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                         if ((spins & 255u) == 255u && vjf_abort_seen(SCW + VJF_SC_STATUS)) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    const bool rls = !rls_in && (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
                     const unsigned mw = __hip_atomic_load(cnt + MG_C_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!tl || (A.flags & VJF_FLAG_HANDOFF_ACQUIRE)) {         // (parameters read from the state with plain loads; or the conservative hand-off)
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                    s_try[0] = (there ? 1u : 0u) | (rls ? 2u : 0u);
+                    s_try[0] = there ? 1u : 0u;
                     s_try[1] = mw;
                     if (!there) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
                 }
                 __syncthreads(); MG_PHASE();
-                rls_now = (s_try[0] & 2u) != 0u;
                 const unsigned mw = s_try[1];
                 if (!replayed && (mw >> 8) == (unsigned)t) { rbits = mw & 7u; want_replay = true; }
             }
