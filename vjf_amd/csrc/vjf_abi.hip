@@ -160,7 +160,7 @@ constexpr int kMegaRefused = 1 << 20;                  // filter_seq_mega: the g
 bool mega_plan_ok(const VjfPlan& P) {
     const int nbl = (P.n + 31) / 32;
     if (!vjf_chol_lds_ok(P) || P.dz > 16 || nbl > VJF_CHOL_MAXBLK) return false;          // LDS Cholesky loop + y / W and inverse loops
-    if ((size_t)(nbl * (nbl + 1) / 2 + nbl) * 1024 * 4 + (size_t)nbl * 32 * 16 * 4 + 768 > kMegaLds) return false;   // vjf_chol_loop<16>
+    if ((size_t)(nbl * (nbl + 1) / 2 + nbl) * 1024 * 4 + ((size_t)nbl * 32 + 32) * VJF_POST_LDX * 4 + 768 > kMegaLds) return false;   // vjf_chol_loop<16>, solve_here
     if (vjf_post_lds_bytes(P) > kMegaLds) return false;
     if ((size_t)vjf_mega_trial_lds(P).total * 4 > kMegaLds) return false;                 // 32 trials' working set
     if (vjf_mega_gram_lds_floats(P) * 4 > kMegaLds || vjf_mega_prep_lds_floats(P) * 4 > kMegaLds) return false;
@@ -173,7 +173,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
     // one workgroup per compute unit: the RLS loops and the operand role have fixed sizes; the trial role gets 128 / 227 of the
     // rest (one 32-trial tile per workgroup at 256 CUs and 4096 trials), then the SGD role (below), the Gram role whatever remains
     const int nbl = (P.n + 31) / 32;
-    m->n_rls = 2 + 2 * nbl;
+    m->n_rls = 1 + 2 * nbl;                                                          // the Cholesky / solve loop + the inverse loops
     m->n_prep = (P.n + 15) / 16;
     m->ntiles = (B + VJF_MG_TR - 1) / VJF_MG_TR;
     const int rest = ncu - m->n_rls - m->n_prep;
@@ -898,12 +898,12 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     unsigned* cnt = (unsigned*)(c->ws + c->cv.mg_cnt);
     VJF_HIP(hipMemsetAsync(cnt, 0, (size_t)MG_C_WORDS * 4, c->stream));                 // every counter and flag of the launch starts at 0
     const int nbl = (P.n + 31) / 32;
-    const unsigned npost = (unsigned)(2 * nbl + 1);
+    const unsigned npost = (unsigned)(2 * nbl + 1);                                    // the Cholesky / solve loop + 2 nbl inverse loops
     float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};
     float* stw = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     VjfMegaArgs A{};
     A.T = T; A.B = B; A.ntiles = m.ntiles;
-    A.n_rls = m.n_rls; A.n_trial = m.n_trial; A.n_gram = m.n_gram; A.n_prep = m.n_prep; A.n_sgd = m.n_sgd;
+    A.n_rls = m.n_rls; A.n_post = m.n_rls; A.n_trial = m.n_trial; A.n_gram = m.n_gram; A.n_prep = m.n_prep; A.n_sgd = m.n_sgd;
     A.y = y; A.u = u; A.eps = eps; A.mu0 = mu0; A.lv0 = lv0; A.mu = mu; A.lv = lv; A.loss = loss;
     A.state = c->state; A.aux = (float*)(c->ws + c->cv.aux);
     A.img = (const float*)(c->ws + c->cv.mg_img);
@@ -930,16 +930,20 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     C.wait_count = cnt + MG_C_PDONE; C.wait_target = 0; C.wait_stride = npost;
     C.stat_count = cnt + MG_C_STAT; C.stat_target = (unsigned)m.n_gram; C.stat_stride = (unsigned)m.n_gram;
     C.nsteps = T; C.step0 = 0;
-    C.sig_word = (const unsigned long long*)(cnt + MG_C_SIGW);
+    C.sig_word = nullptr;
+    C.solve_here = 1;                                                      // substitutions and state noise in the Cholesky workgroup
+    C.prep_count = cnt + MG_C_PREP; C.prep_target = (unsigned)m.n_prep; C.prep_stride = (unsigned)m.n_prep;
+    C.k1_done = cnt + MG_C_K1; C.k1_target = (unsigned)m.n_trial; C.k1_stride = (unsigned)m.n_trial;
+    C.done = cnt + MG_C_PDONE;
     { const char* ie = getenv("VJF_DEBUG_INJECT"); C.inject_epoch = ie ? (unsigned)atoi(ie) : 0u; }   // (test hook: a hand-off of step k - 1 reports a time-out)
     VjfPostArgs Q{};
     Q.state = c->state; Q.dinv = dinv; Q.gbuf = A.gbuf; Q.lscr = C.lscr; Q.flags = cnt + MG_C_COLFLAGS; Q.epoch = 1; Q.status = stw;
     Q.k1_done = cnt + MG_C_K1; Q.k1_target = (unsigned)m.n_trial; Q.k1_stride = (unsigned)m.n_trial;
     Q.done = cnt + MG_C_PDONE; Q.started = cnt + MG_C_STARTED;
     Q.red = rede[0]; Q.red2 = rede[1]; Q.B_total = B; Q.fold_sigma = 1; Q.stamps = C.stamps; Q.undo_P = 1;
-    Q.sig_word = (unsigned long long*)(cnt + MG_C_SIGW); Q.acquire = acq ? 1 : 0;
+    Q.sig_word = nullptr; Q.acquire = acq ? 1 : 0;
     Q.prep_count = cnt + MG_C_PREP; Q.prep_target = (unsigned)m.n_prep; Q.prep_stride = (unsigned)m.n_prep;
-    Q.nsteps = T; Q.step0 = 0; Q.role = 2;
+    Q.nsteps = T; Q.step0 = 0; Q.role = 1;
     VjfPlan Pk = P;
     const int grid = m.n_rls + m.n_trial + m.n_gram + m.n_prep + m.n_sgd;
 #ifdef VJF_CHAOS
