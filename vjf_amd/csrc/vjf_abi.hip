@@ -160,7 +160,7 @@ constexpr int kMegaRefused = 1 << 20;                  // filter_seq_mega: the g
 bool mega_plan_ok(const VjfPlan& P) {
     const int nbl = (P.n + 31) / 32;
     if (!vjf_chol_lds_ok(P) || P.dz > 16 || nbl > VJF_CHOL_MAXBLK) return false;          // LDS Cholesky loop + y / W and inverse loops
-    if ((size_t)(nbl * (nbl + 1) / 2 + nbl) * 1024 * 4 + ((size_t)nbl * 32 + 32) * VJF_POST_LDX * 4 + 768 > kMegaLds) return false;   // vjf_chol_loop<16>, solve_here
+    if ((size_t)(nbl * (nbl + 1) / 2 + nbl) * 1024 * 4 + (size_t)nbl * 32 * 16 * 4 + 768 > kMegaLds) return false;   // vjf_chol_loop<16>
     if (vjf_post_lds_bytes(P) > kMegaLds) return false;
     if ((size_t)vjf_mega_trial_lds(P).total * 4 > kMegaLds) return false;                 // 32 trials' working set
     if (vjf_mega_gram_lds_floats(P) * 4 > kMegaLds || vjf_mega_prep_lds_floats(P) * 4 > kMegaLds) return false;
@@ -173,7 +173,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
     // one workgroup per compute unit: the RLS loops and the operand role have fixed sizes; the trial role gets 128 / 227 of the
     // rest (one 32-trial tile per workgroup at 256 CUs and 4096 trials), then the SGD role (below), the Gram role whatever remains
     const int nbl = (P.n + 31) / 32;
-    m->n_rls = 1 + 2 * nbl;                                                          // the Cholesky / solve loop + the inverse loops
+    m->n_rls = 2 + 2 * nbl;
     m->n_prep = (P.n + 15) / 16;
     m->ntiles = (B + VJF_MG_TR - 1) / VJF_MG_TR;
     const int rest = ncu - m->n_rls - m->n_prep;
@@ -237,11 +237,11 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
         c.mg_early = take((size_t)2 * kMegaMaxTrialWg * ((size_t)((P.n + 3) & ~3) * 16 + 8) * 4);   // (two sets: even / odd steps)
         c.mg_late = take((size_t)kMegaMaxTrialWg * (slab_len + 8) * 4);
         c.mg_gslab = take((size_t)kMegaMaxGramWg * (nbl * (nbl + 1) / 2) * 1024 * 4);
-        c.mg_cnt = take((size_t)MG_C_WORDS * 4);
+        c.mg_cnt = take((size_t)2 * MG_C_WORDS * 4);           // two counter blocks: a launch runs on one and zeroes the other for the next
         c.mg_stamps = take((32 * 32 + kMegaMaxTrialWg * 8) * 8);   // ring of role stamps | 8 words per trial workgroup (last step)
         c.mg_pidx = take(slab_len * 4); c.mg_cidx = take(slab_len * 4); c.mg_grp = take(slab_len);
         c.mg_img = take((size_t)vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).th_len * 4 + 64);   // the parameters in the trial role's LDS layout
-        c.mg_pmsave = take((size_t)2 * max_batch * (P.dz + 1) * 4);
+        c.mg_pmsave = take((size_t)max_batch * (P.dz + 1) * 4);
     }
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
@@ -284,6 +284,7 @@ struct vjf_ctx {
     bool mega_ok;          // the plan fits the one-launch route (vjf_mega_kernel.h)
     int ncu;               // compute units of the device: the one-launch grid has one workgroup per CU
     int mega_wg_per_cu;    // workgroups of vjf_mega_kernel a compute unit can hold (occupancy query): the residency check of the route
+    unsigned mega_launches; // launches of vjf_mega_kernel so far: launch k counts in counter block k & 1
     hipStream_t stream2, stream3;
     hipEvent_t ev_s, ev_c;
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
@@ -378,7 +379,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
         c->ncu = v;
         c->mega_wg_per_cu = 0;
     }
-    c->start_count = 0;
+    c->start_count = 0; c->mega_launches = 0;
     c->stream2 = c->stream3 = nullptr; c->ev_s = c->ev_c = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1; c->fake_world = 1;
@@ -444,6 +445,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
         if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_cidx, cidx.data(), cidx.size() * 4, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->ws + cv.mg_grp, grpv.data(), grpv.size() * 4, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.mg_img, 0, (size_t)Lo.th_len * 4, c->stream);   // (its padding stays 0)
+        if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.mg_cnt, 0, (size_t)2 * MG_C_WORDS * 4, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `jobs`, `meta` (host) must outlive the copies
     if (e != hipSuccess) { delete c; return fail(-100, "vjf_ctx_create: %s", hipGetErrorString(e)); }
@@ -895,15 +897,17 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     // (parameters that fit the trial role's LDS: it reads the image the SGD role builds at the start of the launch; else the state
     //  and its transposed copies, refreshed here)
     if (!vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).theta) { rc = refresh_aux(c); if (rc) return rc; }
-    unsigned* cnt = (unsigned*)(c->ws + c->cv.mg_cnt);
-    VJF_HIP(hipMemsetAsync(cnt, 0, (size_t)MG_C_WORDS * 4, c->stream));                 // every counter and flag of the launch starts at 0
+    // every counter and flag of the launch starts at 0: the launch before it zeroed this block as its first act (the context's first
+    // launch finds both blocks zeroed by vjf_ctx_create) -- no memset in front of the launch, no dispatch gap behind it
+    unsigned* cnt = (unsigned*)(c->ws + c->cv.mg_cnt) + (size_t)(c->mega_launches & 1u) * MG_C_WORDS;
+    unsigned* cnt_next = (unsigned*)(c->ws + c->cv.mg_cnt) + (size_t)((c->mega_launches + 1u) & 1u) * MG_C_WORDS;
     const int nbl = (P.n + 31) / 32;
-    const unsigned npost = (unsigned)(2 * nbl + 1);                                    // the Cholesky / solve loop + 2 nbl inverse loops
+    const unsigned npost = (unsigned)(2 * nbl + 1);
     float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};
     float* stw = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     VjfMegaArgs A{};
     A.T = T; A.B = B; A.ntiles = m.ntiles;
-    A.n_rls = m.n_rls; A.n_post = m.n_rls; A.n_trial = m.n_trial; A.n_gram = m.n_gram; A.n_prep = m.n_prep; A.n_sgd = m.n_sgd;
+    A.n_rls = m.n_rls; A.n_trial = m.n_trial; A.n_gram = m.n_gram; A.n_prep = m.n_prep; A.n_sgd = m.n_sgd;
     A.y = y; A.u = u; A.eps = eps; A.mu0 = mu0; A.lv0 = lv0; A.mu = mu; A.lv = lv; A.loss = loss;
     A.state = c->state; A.aux = (float*)(c->ws + c->cv.aux);
     A.img = (const float*)(c->ws + c->cv.mg_img);
@@ -911,7 +915,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     A.slab_early = (float*)(c->ws + c->cv.mg_early); A.slab_late = (float*)(c->ws + c->cv.mg_late); A.gslab = (float*)(c->ws + c->cv.mg_gslab);
     A.red0 = rede[0]; A.red1 = rede[1];
     A.gbuf = (float*)(c->ws + c->cv.work);
-    A.cnt = cnt; A.flags = flags;
+    A.cnt = cnt; A.cnt_next = cnt_next; A.flags = flags;
     const bool acq = c->handoff_acquire;                                   // (VJF_HANDOFF_ACQUIRE, read when the context is created)
     if (acq) A.flags |= VJF_FLAG_HANDOFF_ACQUIRE;
     A.slab_len = vjf_mega_slab_layout(P).len;
@@ -930,20 +934,16 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     C.wait_count = cnt + MG_C_PDONE; C.wait_target = 0; C.wait_stride = npost;
     C.stat_count = cnt + MG_C_STAT; C.stat_target = (unsigned)m.n_gram; C.stat_stride = (unsigned)m.n_gram;
     C.nsteps = T; C.step0 = 0;
-    C.sig_word = nullptr;
-    C.solve_here = 1;                                                      // substitutions and state noise in the Cholesky workgroup
-    C.prep_count = cnt + MG_C_PREP; C.prep_target = (unsigned)m.n_prep; C.prep_stride = (unsigned)m.n_prep;
-    C.k1_done = cnt + MG_C_K1; C.k1_target = (unsigned)m.n_trial; C.k1_stride = (unsigned)m.n_trial;
-    C.done = cnt + MG_C_PDONE;
+    C.sig_word = (const unsigned long long*)(cnt + MG_C_SIGW);
     { const char* ie = getenv("VJF_DEBUG_INJECT"); C.inject_epoch = ie ? (unsigned)atoi(ie) : 0u; }   // (test hook: a hand-off of step k - 1 reports a time-out)
     VjfPostArgs Q{};
     Q.state = c->state; Q.dinv = dinv; Q.gbuf = A.gbuf; Q.lscr = C.lscr; Q.flags = cnt + MG_C_COLFLAGS; Q.epoch = 1; Q.status = stw;
     Q.k1_done = cnt + MG_C_K1; Q.k1_target = (unsigned)m.n_trial; Q.k1_stride = (unsigned)m.n_trial;
     Q.done = cnt + MG_C_PDONE; Q.started = cnt + MG_C_STARTED;
     Q.red = rede[0]; Q.red2 = rede[1]; Q.B_total = B; Q.fold_sigma = 1; Q.stamps = C.stamps; Q.undo_P = 1;
-    Q.sig_word = nullptr; Q.acquire = acq ? 1 : 0;
+    Q.sig_word = (unsigned long long*)(cnt + MG_C_SIGW); Q.acquire = acq ? 1 : 0;
     Q.prep_count = cnt + MG_C_PREP; Q.prep_target = (unsigned)m.n_prep; Q.prep_stride = (unsigned)m.n_prep;
-    Q.nsteps = T; Q.step0 = 0; Q.role = 1;
+    Q.nsteps = T; Q.step0 = 0; Q.role = 2;
     VjfPlan Pk = P;
     const int grid = m.n_rls + m.n_trial + m.n_gram + m.n_prep + m.n_sgd;
 #ifdef VJF_CHAOS
@@ -973,6 +973,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
         c->mega_ok = false;
         return kMegaRefused;
     }
+    if (le == hipSuccess) ++c->mega_launches;
     VJF_HIP(le);
     return 0;
 }
@@ -1076,7 +1077,7 @@ static void chaos_refresh(const vjf_ctx* c) {
                           getenv("VJF_CHAOS_TICKS") && atoi(getenv("VJF_CHAOS_TICKS")) > 0 ? atoi(getenv("VJF_CHAOS_TICKS")) : 20000,
                           getenv("VJF_CHAOS_MASK") ? atoi(getenv("VJF_CHAOS_MASK")) : 7};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(vjf_chaos_range), range, sizeof(range));
-    const unsigned* base = (const unsigned*)(c->ws + c->cv.mg_cnt);
+    const unsigned* base = (const unsigned*)(c->ws + c->cv.mg_cnt) + (size_t)(c->mega_launches & 1u) * MG_C_WORDS;   // (the block the next launch counts in)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(vjf_chaos_base), &base, sizeof(base));
 }
 #define VJF_CHAOS_REFRESH(c) chaos_refresh(c)

@@ -512,42 +512,6 @@ __device__ __forceinline__ void trsm_chain(float* pb, const float* Lk, const flo
     }
 }
 
-#define VJF_POST_LDX 17               // right-hand sides of the substitutions: [row][16 columns + 1 pad]
-#define VJF_RESID_BLOCKS 64
-// acc(row = 4*(lane>>4)+r of the 16-row tile, col = lane&15) += sum_m A(tile row, m) * B[m][col], m < 32
-template <class FA>
-__device__ __forceinline__ void post_mma32(vjf_f32x4& acc, const float* Bs, int lane, FA fa) {
-    const int i = lane & 15, kk = lane >> 4;
-    float a[8], b[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) { a[s] = fa(i, 4 * s + kk); b[s] = Bs[(4 * s + kk) * VJF_POST_LDX + i]; }
-    __builtin_amdgcn_sched_barrier(0);
-    vjf_f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};                     // two independent chains: the MFMAs issue back to back
-#pragma unroll
-    for (int s = 0; s < 8; s += 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
-    }
-    acc += acc1;
-}
-
-// What these workgroups take from workgroups that run beside them (columns of L and the inverted diagonal blocks from the
-// Cholesky loop; g, Phi^T dx, the sums from the operand role; Phi^T Phi from the Gram role; sigma and the sample count, their own
-// stores of the step before) was stored write-through and drained before the flag / count that announces it, and is read with
-// sc1 loads -- 16-byte buffer loads or 4-byte agent-scope loads, which bypass this CU's vector L1 -- behind the poll that matched
-// and the workgroup barrier: no agent-scope acquire (an L1 invalidate the whole workgroup would wait ~1.7 us for) per column
-// (MI355X guide, "sc1 loads in place of the acquire").  The rare failure path, which reads more, does acquire.
-typedef unsigned post_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t post_rsrc(const float* base, size_t nfloats) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(nfloats * 4), 0x00020000);
-}
-__device__ __forceinline__ float4 post_ld4(__amdgpu_buffer_rsrc_t r, size_t float_off) {
-    const post_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, 16);      // aux 16 = sc1
-    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-}
-__device__ __forceinline__ float post_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-
 struct VjfCholArgs {
     float* state;
     const float* red;
@@ -581,14 +545,6 @@ struct VjfCholArgs {
                                           //   copies of L and the inverted diagonal blocks must have been read by everybody)
     int no_triclean;       // post mode: the caller clears the zero halves of w_chol / w_pchol itself (vjf_triclean_kernel)
                            //            (vjf_rls_post_kernel copies it to w_pchol once the factor is known to be good)
-    // solve_here (the one-launch route; post, self_prep, looping form): the WHOLE dependent chain of the RLS update stays in this
-    // workgroup -- L y = g rides along with the factorisation (one wavefront, as the columns become final), then L^T W = y, W out,
-    // the state-noise update (model.py:373-377), and sigma is simply there for the next step's P + G / v.  No column of L and no
-    // sigma crosses to another compute unit on that chain (the inverse loops still take the columns from memory: they are off it).
-    int solve_here;
-    const unsigned* prep_count; unsigned prep_target, prep_stride;   // g of the step is in memory (the operand role)
-    const unsigned* k1_done; unsigned k1_target, k1_stride;          // readers of W, w_chol, sigma of the previous step (the trial role)
-    unsigned* done;                                                  // += 1 once W and sigma of the step are in memory
 };
 
 #define VJF_STAMP(i)                                                                        \
@@ -627,8 +583,7 @@ __device__ __forceinline__ void axpy_row(float (&acc)[DZP], float x, const float
 template <int DZP>
 __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArgs& A, float* lds, int* s_dead, const unsigned it_epoch,
                                               const float* it_red, const unsigned it_wait_target, const unsigned it_stat_target,
-                                              const bool it_src_state, const unsigned it_prep_target = 0u, const unsigned it_k1_target = 0u,
-                                              float* sig_carry = nullptr) {
+                                              const bool it_src_state) {
     int tid = threadIdx.x;
     // (the looping form calls this body once per step: without the barrier the compiler hoists every lane-dependent address
     //  of the body out of that loop and spills hundreds of registers)
@@ -650,12 +605,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
     float* s_aux = s_blk + (size_t)ntri * 1024;       // nbl blocks: inverted diagonal blocks of L; later scratch
     float* s_g = s_aux + (size_t)nbl * 1024;          // npad x DZP  g, later W
     // (y = L^-1 g overwrites g in place; for DZP = 32 a second npad x DZP region behind g is reserved)
-    // solve_here: the right-hand sides g -> y -> W as [npad][17] (s_x) and the block just solved [32][17] (s_y) instead
-    const bool sh = A.solve_here != 0;
-    constexpr int LX = VJF_POST_LDX;
-    float* s_x = s_g;
-    float* s_y = s_x + (size_t)npad * LX;
-    int* s_flag = (int*)(s_g + (sh ? (size_t)npad * LX + 32 * LX : (size_t)npad * DZP * (DZP <= 16 ? 1 : 2)));   // [0] ok
+    int* s_flag = (int*)(s_g + (size_t)npad * DZP * (DZP <= 16 ? 1 : 2));   // [0] ok
     double* s_d = (double*)(s_flag + 8);              // 16 doubles for the final reduction
     int* s_bi = s_flag + 64;                          // block-row / block-column of lower block b
     int* s_bj = s_bi + 32;
@@ -705,11 +655,6 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
             __syncthreads();
             if (tid == 0) __hip_atomic_store(A.flags_out + VJF_CHOL_MAXBLK + 2, it_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             vjf_chaos(tid, A.wait_count, 1);
-            if (sh && it_wait_target != 0u) {
-                sig = *sig_carry;                                       // (this workgroup's own state-noise update of the step before)
-                lscr_guard = true;
-                return;
-            }
             if (A.sig_word && it_wait_target != 0u) {
                 // sigma inside the hand-off word: one poll, no second load; the exit count of the post workgroups is checked by the
                 // wavefront that writes the first column out (below)
@@ -862,7 +807,6 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
             blk_mma<true>(acc, s_blk + (size_t)vtri(bi, k) * 1024, s_blk + (size_t)vtri(bj, k) * 1024, -1.f, lane);
             blk_store(acc, cb, lane);
         };
-        const int nh = sh ? 5 : 6;                                      // helper wavefronts (solve_here: wavefront 7 runs the forward substitution)
         int kdone = 0;                                                  // wavefront 4: columns written out (their flags stored)
         if (wave == 0) {
             for (int k = 0; k < nbl; ++k) {                             // (chain(0) ran before the barrier above)
@@ -889,7 +833,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                     // column k of L and Dinv_k out, write-through, as soon as they are final; their flag once the stores have
                     // drained (nobody waits for this wavefront inside the workgroup)
                     lds_wait(C_CHAIN, k + 1);
-                    if (k + 1 < nbl) { lds_wait(C_P1, k + 1); lds_wait(C_HB, nh * (2 * k + 1)); }
+                    if (k + 1 < nbl) { lds_wait(C_P1, k + 1); lds_wait(C_HB, 6 * (2 * k + 1)); }
                     if (!v_ok[0]) break;
                     if (k == 0 && lscr_guard) {                         // (this wavefront alone writes the scratch copies)
                         bool there = false;
@@ -906,64 +850,16 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                     kdone = k + 1;
                 }
             }
-        } else if (sh && wave == 7) {
-            // ---- forward substitution L y = g (module.py:101) riding along with the factorisation: one wavefront, eagerly -- as soon
-            //      as column k of L is final, y_k = Dinv_k r_k and every later block row's r_i -= L_ik y_k.  Behind the last column only
-            //      the last (short) block is left.  g comes from the operand role, usually while the first columns are being factored.
-            const int xr = 4 * (lane >> 4), xc = lane & 15;             // accumulator element (row xr + r, column xc) of a 16-row tile
-            {
-                bool there = A.prep_count == nullptr;
-                vjf_chaos(lane, A.prep_count, 1);
-                for (unsigned spins = 0; !there && spins < VJF_WAIT_SPINS; ++spins) {
-                    if ((int)(__hip_atomic_load(A.prep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - it_prep_target) >= 0) { there = true; break; }
-                    if (!v_ok[0] || ((spins & 255u) == 255u && vjf_abort_seen(SC + VJF_SC_STATUS))) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (!there && v_ok[0] && lane == 0) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_G); *s_dead = 1; v_ok[0] = 0; }
-                if (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                for (int e = lane; e < npad * 16; e += 64) {            // (sc1 loads: the operand role stored g write-through)
-                    const int r = e >> 4, c2 = e & 15;
-                    s_x[r * LX + c2] = (there && r < n && c2 < dz) ? post_ld(A.gbuf + (size_t)r * dz + c2) : 0.f;
-                }
-            }
-            for (int k = 0; k < nbl; ++k) {
-                lds_wait(C_CHAIN, k + 1);
-                if (!v_ok[0]) break;
-                const float* Dk = s_aux + (size_t)k * 1024;
-                vjf_f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
-                post_mma32(y0, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Dk[vsw(i, m)]; });
-                post_mma32(y1, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Dk[vsw(16 + i, m)]; });
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s_y[(xr + r) * LX + xc] = y0[r]; s_y[(16 + xr + r) * LX + xc] = y1[r];
-                    s_x[(k * 32 + xr + r) * LX + xc] = y0[r]; s_x[(k * 32 + 16 + xr + r) * LX + xc] = y1[r];
-                }
-                if (k + 1 < nbl) { lds_wait(C_P1, k + 1); lds_wait(C_HB, nh * (2 * k + 1)); }   // column k of L is final
-                if (!v_ok[0]) break;
-                for (int i = k + 1; i < nbl; ++i) {
-                    const float* Lb = s_blk + (size_t)vtri(i, k) * 1024;
-#pragma unroll
-                    for (int tl = 0; tl < 2; ++tl) {
-                        float* xt = s_x + ((size_t)i * 32 + 16 * tl + xr) * LX + xc;
-                        vjf_f32x4 acc;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[r] = xt[r * LX];
-                        post_mma32(acc, s_y, lane, [&](int ii, int m) { return -Lb[vsw(16 * tl + ii, m)]; });
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) xt[r * LX] = acc[r];
-                    }
-                }
-            }
         } else {
-            const int hw = wave < 4 ? wave - 1 : wave - 2;              // helper 0 .. 5 (solve_here: 0 .. 4)
+            const int hw = wave < 4 ? wave - 1 : wave - 2;              // helper 0 .. 5
             int stage = 0;
             for (int k = 0; k + 1 < nbl; ++k) {
                 lds_wait(C_CHAIN, k + 1);
                 if (!v_ok[0]) break;
-                for (int bi = k + 2 + hw; bi < nbl; bi += nh) panel_tile(bi, k);
+                for (int bi = k + 2 + hw; bi < nbl; bi += 6) panel_tile(bi, k);
                 hb_arrive();
                 ++stage;
-                lds_wait(C_HB, nh * stage);
+                lds_wait(C_HB, 6 * stage);
                 if (!v_ok[0]) break;
                 // trailing tiles of column k: (k+1+r, k+1+c), 0 <= c <= r < m, without (0,0) (the chain's own)
                 const int m = nbl - 1 - k;
@@ -971,198 +867,18 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                     if (hw == 0) { lds_wait(C_P1, k + 1); if (v_ok[0]) { trail_tile(k + 2, k + 1, k); lds_post(C_A, k + 1); } }
                     if (hw == 1) { trail_tile(k + 2, k + 2, k); lds_post(C_B, k + 1); }
                     for (int r = 2; r < m; ++r)                         // the rest of block column k + 1
-                        if (r % nh == hw) { lds_wait(C_P1, k + 1); if (v_ok[0]) trail_tile(k + 1 + r, k + 1, k); }
+                        if (r % 6 == hw) { lds_wait(C_P1, k + 1); if (v_ok[0]) trail_tile(k + 1 + r, k + 1, k); }
                     int q = m;
                     for (int r = 2; r < m; ++r)
                         for (int c2 = 1; c2 <= r; ++c2, ++q)
-                            if (q % nh == hw) trail_tile(k + 1 + r, k + 1 + c2, k);
+                            if (q % 6 == hw) trail_tile(k + 1 + r, k + 1 + c2, k);
                 }
                 hb_arrive();
                 ++stage;
-                lds_wait(C_HB, nh * stage);
+                lds_wait(C_HB, 6 * stage);
             }
         }
         __syncthreads();
-        if (sh) {
-            // ================= solve_here: the rest of the dependent chain, in this workgroup =================
-            const bool failed = s_flag[0] == 0;
-            VJF_STAMP(2);
-            const float inv_v_old = expf(-sig);                         // (the step's P + G / v was formed with this sigma)
-            const float* G = it_red + P.red_G;
-            const int xr = 4 * (lane >> 4), xc = lane & 15;
-            // the tail's operands, requested now so that it does not wait for them: this wavefront's lower 32x32 tiles of G in the
-            // matrix-core accumulator layout (clamped addresses: the tail masks what lies outside the matrix), Phi^T dx, sum |dx|^2
-            float gpre[4][16], fpre[8];
-            unsigned wbits[4];
-            {
-                const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int t = min(wave + 8 * q, ntri - 1), bi = s_bi[t], bj = s_bj[t];
-                    unsigned wq = 0u;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int gi0 = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, gj0 = bj * 32 + c;
-                        gpre[q][r] = post_ld(G + (size_t)min(gi0, n - 1) * n + min(gj0, n - 1));
-                        // weight of the entry in tr(W^T G W) = sum_ij G_ij (W W^T)_ij over the lower triangle: 2 below the diagonal, 1 on it
-                        wq |= ((wave + 8 * q >= ntri || gi0 >= n || gj0 > gi0) ? 0u : (gj0 == gi0 ? 1u : 2u)) << (2 * r);
-                    }
-                    wbits[q] = wq;
-                }
-                const float* FDXp = it_red + P.red_FDX;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {                           // W's [row][16] grid: 224 * 16 <= 8 * 512
-                    const int e = tid + q * VJF_CHOL_THREADS, r = min(e >> 4, n - 1), cc = min(e & 15, dz - 1);
-                    fpre[q] = post_ld(FDXp + r * dz + cc);
-                }
-            }
-            const float pre_sdx2 = post_ld(it_red + P.red_SC + RS_SDX2);
-            const float acc_n = fminf(post_ld(SC + VJF_SC_N_TR), 500.f), pre_tot = acc_n + Bf;   // running_var, size_cap=500 (model.py:375)
-            const float pre_old = (acc_n / pre_tot) * expf(sig);
-            const double pre_scale = 1.0 / ((double)Bf * (double)dz);
-            if (failed) {
-                // Reference: the fallback calls the removed torch.eig and raises (module.py:104-112).  Here the RLS state stays as it
-                // was: the copy of P for the next step and the state's P (which the operand role has updated) are taken back -- exact up
-                // to one rounding --, every column flag not yet stored says "failed", sigma moves on the W that stays.
-                st |= VJF_STATUS_RLS_FAILED;
-                for (int idx = tid; idx < ntri * 256; idx += VJF_CHOL_THREADS) {
-                    const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
-                    const int gi = s_bi[b] * 32 + r, gj = s_bj[b] * 32 + c4;
-                    if (gi < n && gj < n) {
-                        float4 pv = *reinterpret_cast<const float4*>(A.pscr + (size_t)idx * 4);
-                        const float4 gv = *reinterpret_cast<const float4*>(G + (size_t)gi * n + gj);
-                        pv.x = fmaf(-gv.x, inv_v_old, pv.x); pv.y = fmaf(-gv.y, inv_v_old, pv.y); pv.z = fmaf(-gv.z, inv_v_old, pv.z); pv.w = fmaf(-gv.w, inv_v_old, pv.w);
-                        *reinterpret_cast<float4*>(A.pscr + (size_t)idx * 4) = pv;
-                    }
-                }
-                if (wave == 4) publish(kdone, VJF_CHOL_MAXBLK + 1, 1u);
-                if (tid == 0) A.ok_out[0] = 0;
-                // the operand role's P += G / v of this step must be complete before it is taken back
-                if (A.prep_count && !vjf_wg_wait(A.prep_count, it_prep_target, tid, SC + VJF_SC_STATUS)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_G); *s_dead = 1; }
-                for (int e = tid; e < n * n; e += VJF_CHOL_THREADS) vjf_store_wt(Pm + e, fmaf(-G[e], inv_v_old, Pm[e]));
-                for (int e = tid; e < npad * 16; e += VJF_CHOL_THREADS) {
-                    const int r = e >> 4, c2 = e & 15;
-                    s_x[r * LX + c2] = (r < n && c2 < dz) ? post_ld(Wm + (size_t)r * dz + c2) : 0.f;
-                }
-            } else {
-                if (tid == 0) A.ok_out[0] = 1;
-                if (wave == 4) publish(VJF_CHOL_MAXBLK, VJF_CHOL_MAXBLK + 1, 0u);   // the factor as a whole is good
-            }
-            VJF_STAMP(18);
-            // readers of W, w_chol, sigma of the previous step (the trial role): all done?  Nothing of those is written before.
-            if (A.k1_done) {
-                vjf_chaos(tid, A.k1_done, 1);
-                if (tid == 0) {
-                    bool there = false;
-                    for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
-                        if ((int)(__hip_atomic_load(A.k1_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - it_k1_target) >= 0) { there = true; break; }
-                        if ((spins & 255u) == 255u && vjf_abort_seen(SC + VJF_SC_STATUS)) break;
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    if (!there) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1); *s_dead = 1; }
-                }
-            }
-            __syncthreads();
-            if (!failed) {
-                // ---- backward  W_k = Dinv_k^T R_k ;  R_i -= L_ki^T W_k  (i < k),   k = nbl-1 .. 0   (module.py:101): two wavefronts
-                //      form the block, all eight subtract its contribution from the 16-row tiles of the earlier blocks they own
-                const int tile = wave & 1, grp = wave >> 1;
-                for (int k = nbl - 1; k >= 0; --k) {
-                    vjf_f32x4 w = {0.f, 0.f, 0.f, 0.f};
-                    if (wave < 2) {
-                        const float* Dk = s_aux + (size_t)k * 1024;
-                        post_mma32(w, s_x + (size_t)k * 32 * LX, lane, [&](int i, int m) { return Dk[vsw(m, 16 * wave + i)]; });
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s_y[(16 * wave + xr + r) * LX + xc] = w[r];
-                    }
-                    __syncthreads();
-                    if (wave < 2) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s_x[(k * 32 + 16 * wave + xr + r) * LX + xc] = w[r];
-                    }
-                    for (int i = k - 1 - grp; i >= 0; i -= VJF_CHOL_THREADS / 128) {
-                        const float* Lb = s_blk + (size_t)vtri(k, i) * 1024;
-                        float* xt = s_x + ((size_t)i * 32 + 16 * tile + xr) * LX + xc;
-                        vjf_f32x4 acc;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[r] = xt[r * LX];
-                        post_mma32(acc, s_y, lane, [&](int ii, int m) { return -Lb[vsw(m, 16 * tile + ii)]; });
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) xt[r * LX] = acc[r];
-                    }
-                    __syncthreads();
-                }
-                VJF_STAMP(19);
-                for (int e = tid; e < n * 16; e += VJF_CHOL_THREADS) {
-                    const int r = e >> 4, c2 = e & 15;
-                    if (c2 < dz) vjf_store_wt(Wm + r * dz + c2, s_x[r * LX + c2]);   // sc1: the trial and operand roles read it behind the count
-                }
-            }
-            VJF_STAMP(20);
-            // ---- state-noise update on the new W (model.py:373-377):  q = sum|dx|^2 - 2 tr(W^T FDX) + tr(W^T G W)  over the batch.
-            //      tr(W^T G W) = sum_ij G_ij (W W^T)_ij: wavefront w forms the lower 32x32 tiles t = w, w + 8, .. of W W^T on the
-            //      f32 matrix cores and contracts them with its tiles of G (fp64 sums, fixed order).
-            {
-                double part = 0.0;
-                const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int t = wave + 8 * q;
-                    if (t < ntri) {
-                        const int bi = s_bi[t], bj = s_bj[t];
-                        vjf_f32x16 acc;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                        float wa[8], wb[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {                  // columns dz..15 and rows n.. of W are zero
-                            wa[k] = s_x[(bi * 32 + c) * LX + 2 * k + h];
-                            wb[k] = s_x[(bj * 32 + c) * LX + 2 * k + h];
-                        }
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if (2 * k < dz) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[k], wb[k], acc, 0, 0, 0);   // (uniform branch)
-                        double tp = 0.0;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {                 // accumulator: row = (r&3) + 8*(r>>2) + 4*h, column = c
-                            const float wgt = (float)((wbits[q] >> (2 * r)) & 3u);
-                            tp += (double)((wgt * gpre[q][r]) * acc[r]);   // (one fp32 rounding per product; the SUMS are fp64)
-                        }
-                        part += tp;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int e = tid + q * VJF_CHOL_THREADS, r = e >> 4, cc = e & 15;
-                    if (r < n && cc < dz) part -= 2.0 * (double)s_x[r * LX + cc] * (double)fpre[q];
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-                if (lane == 0) s_d[wave] = part;
-                __syncthreads();
-                if (tid == 0) {
-                    double t = 0.0;
-                    for (int w = 0; w < VJF_CHOL_THREADS / 64; ++w) t += s_d[w];
-                    t += (double)pre_sdx2;
-                    if (t < 0.0) t = 0.0;
-                    const float mse = (float)(t * pre_scale);
-                    const float new_sig = logf(pre_old + (Bf / pre_tot) * mse);
-                    vjf_store_wt(S + P.off[VJF_SLOT_TR_LOGVAR], new_sig);
-                    vjf_store_wt(SC + VJF_SC_N_TR, pre_tot);
-                    s_flag[4] = __float_as_int(new_sig);
-                    if (st) vjf_status_or(SC + VJF_SC_STATUS, st);
-                }
-                __syncthreads();
-                *sig_carry = __int_as_float(s_flag[4]);
-            }
-            VJF_STAMP(21);
-            // W and sigma of the step are out: the count the trial role, the operand role and this loop's own scratch guard wait for
-            vjf_chaos(tid, A.done, 2);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0 && A.done) __hip_atomic_fetch_add(A.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
         const bool ok = s_flag[0] != 0;
         VJF_STAMP(2);
         if (!ok) {
@@ -1429,12 +1145,10 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
 template <int DZP>
 __device__ __forceinline__ void vjf_chol_loop(const VjfPlan& P, const VjfCholArgs& A, float* lds, int* s_dead) {
     const int steps = A.nsteps > 0 ? A.nsteps : 1;
-    float sig_carry = 0.f;                             // solve_here: sigma of the step before, from this workgroup's own update
     for (int it = 0; it < steps; ++it) {
         const float* red = ((A.step0 + it) & 1) ? A.red2 : A.red;
         vjf_chol_body<DZP>(P, A, lds, s_dead, A.epoch + (unsigned)it, red, A.wait_target + (unsigned)it * A.wait_stride,
-                           A.stat_target + (unsigned)it * A.stat_stride, it == 0 && A.src_state != 0,
-                           A.prep_target + (unsigned)it * A.prep_stride, A.k1_target + (unsigned)it * A.k1_stride, &sig_carry);
+                           A.stat_target + (unsigned)it * A.stat_stride, it == 0 && A.src_state != 0);
         __syncthreads();
         if (*s_dead) break;
     }

@@ -59,16 +59,16 @@ enum {
 struct VjfMegaArgs {
     int T, B, ntiles;
     int n_rls, n_trial, n_gram, n_prep, n_sgd;        // grid = their sum
-    int n_post;                                       // RLS workgroups that count themselves done with a step (MG_C_PDONE): the Cholesky / solve loop + the inverse loops
     const float* y; const float* u; const float* eps; const float* mu0; const float* lv0;
     float* mu; float* lv; float* loss;
     float* state; float* aux;
     const float* img;                                 // the optimised parameters as the trial role's LDS holds them (vjf_mega_trial_lds: theta region)
-    float* pmsave;                                    // 2 x (B, dz + 1), by the parity of the step: pt.mean | pt.logvar of every trial (for a replayed backward pass)
+    float* pmsave;                                    // (B, dz + 1): pt.mean | pt.logvar of every trial at its last step (for a replayed backward pass)
     float* slab_early; float* slab_late; float* gslab;
     float* red0; float* red1;                         // reduce buffers of even / odd steps ([G | FDX | sums], as the RLS loops read them)
     float* gbuf;                                      // g (n, dz)
     unsigned* cnt;
+    unsigned* cnt_next;                               // the other counter block: zeroed by this launch for the next one
     unsigned flags;
     int early_len, late_len;                          // floats per trial workgroup
     int lds_floats;                                   // dynamic LDS of the launch (floats): decides whether the parameters are staged in it
@@ -444,7 +444,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     int mean_nsl = 1;
     __shared__ unsigned s_try[2];
     unsigned* cnt = A.cnt;
-    const unsigned npost = (unsigned)A.n_post;
+    const unsigned npost = (unsigned)(A.n_rls - 1);
     float* late = A.slab_late + (size_t)wg * A.late_len;
     const int ldn = (n + 3) & ~3;                      // early slab: [16 columns][ldn] Phi^T dx (transposed), then the scalars
     const size_t sy = (size_t)A.B * dy, su = (size_t)A.B * du, sz = (size_t)A.B * dz;
@@ -472,8 +472,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     float sig_prev = 0.f, rho_prev = 0.f;
     unsigned nredo = 0;
     for (int t = 0; t <= A.T; ++t) {
-      bool replay = false, replayed = false, k1_sent = false, m_saved = false;
-      float sig_saved = 0.f;
+      bool replay = false, replayed = false, k1_sent = false;
       unsigned rbits = 0;
       for (;;) {
         const int ts = replay ? t - 1 : t;             // the step whose inputs this pass stages
@@ -502,8 +501,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         float sig = sig_prev, rho = rho_prev;          // (a replayed pass: the values its step ran with)
         bool tri = false, rls_in = replay;
         // the parameters of step t - 1 (the SGD role's write-through stores) and its verdict on that step's loss
-        // One lane polls the SGD role's count; once it is there it looks -- once -- at the verdict word.  No acquire: what the trial role takes from other roles (the parameter image, W, w_chol, sigma, rho)
+        // One lane polls the SGD role's count; once it is there it looks -- once -- at the RLS roles' count of the same step, and
+        // at the verdict word.  No acquire: what the trial role takes from other roles (the parameter image, W, w_chol, sigma, rho)
         // it reads with sc1 loads behind this poll and the workgroup barrier (MI355X guide, "sc1 loads in place of the acquire").
+        bool rls_now = false;
         auto gate = [&]() {
             if (t > 0) {
                 vjf_chaos(tid, cnt + MG_C_SGD, 1);
@@ -514,16 +515,18 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                         if ((spins & 255u) == 255u && vjf_abort_seen(SCW + VJF_SC_STATUS)) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
+                    const bool rls = !rls_in && (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
                     const unsigned mw = __hip_atomic_load(cnt + MG_C_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!tl || (A.flags & VJF_FLAG_HANDOFF_ACQUIRE)) {         // (parameters read from the state with plain loads; or the conservative hand-off)
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                    s_try[0] = there ? 1u : 0u;
+                    s_try[0] = (there ? 1u : 0u) | (rls ? 2u : 0u);
                     s_try[1] = mw;
                     if (!there) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
                 }
                 __syncthreads(); MG_PHASE();
+                rls_now = (s_try[0] & 2u) != 0u;
                 const unsigned mw = s_try[1];
                 if (!replayed && (mw >> 8) == (unsigned)t) { rbits = mw & 7u; want_replay = true; }
             }
@@ -598,305 +601,270 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 __syncthreads(); MG_PHASE();
             }
             if (first) VJF_MG_STAMP(2);
-            // ---- Two hand-offs feed this pass and neither needs the other: the RLS update of the previous step (W, w_chol, sigma) feeds
-            //      the predictive moments (stage 2, the longest phase of the pass: features x w_chol), the parameters of the previous step
-            //      feed the recognition network.  Whichever is in first is used first: with the parameters still on their way -- gradient
-            //      sum, SGD step, image -- the moments are formed in that shadow, and the path parameters -> forward -> losses -> backward
-            //      -> parameters is shorter by that phase; with the parameters there first, the forward pass (and with it the early slab
-            //      the RLS update of THIS step waits for) goes first, as it did before.  Same values either way.
-            // A step that starts over behind the replay of its predecessor takes the moments it saved in its first attempt: the
-            // inverse loops of this step's RLS update -- which need the counted readers of w_chol, not this step's statistics -- may
-            // have rewritten w_chol since.
-            const bool from_save = !replay && replayed && first && m_saved;
-            bool m_first = true;
-            if (first && !replay && !from_save && t > 0) {
-                if (tid == 0) {
-                    unsigned pick = 0u;
-                    for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
-                        const bool th = (int)(__hip_atomic_load(cnt + MG_C_SGD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * (unsigned)A.n_sgd) >= 0;
-                        const bool rl = (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
-                        if (th) break;
-                        if (rl) { pick = 1u; break; }
-                        if ((spins & 255u) == 255u && vjf_abort_seen(SCW + VJF_SC_STATUS)) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    s_try[0] = pick;                                       // (neither within the bound: the gate below reports it)
+            // ---- the RLS update of the previous step (W, w_chol, sigma: write-through stores of the RLS roles) is awaited HERE, in front
+            //      of the parameters: the predictive moments of a step (stage 2, the longest phase of the pass) depend on the features
+            //      and on the RLS state, not on theta -- they are formed while the gradient sum and the SGD step of the previous step are
+            //      still on their way, and the path parameters -> forward -> losses -> backward -> parameters is shorter by that phase.
+            if (first && !replay) {
+                rls_in = true;
+                if (t > 0) {
+                    if (!vjf_wg_wait_sc1(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                        vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
+                    if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+                    mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
                 }
-                __syncthreads(); MG_PHASE();
-                m_first = s_try[0] != 0u;
-                __syncthreads(); MG_PHASE();                               // (s_try is reused by the gate)
+                sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
+                tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;                   // w_chol known upper triangular
             }
-            bool abort_tile = false;
-#pragma nounroll
-            for (int ph = 0; ph < 2; ++ph) {
-            if ((ph == 0) == m_first) {
-                // ---- the RLS update of the previous step (W, w_chol, sigma: write-through stores of the RLS roles)
-                if (first && !replay && !from_save) {
-                    rls_in = true;
-                    if (t > 0) {
-                        if (!vjf_wg_wait_sc1(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
-                            vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
-                        if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
-                        mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
-                    }
-                    sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
-                    tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;                   // w_chol known upper triangular
+            if (first) { VJF_MG_STAMP(5); VJF_MG_STAMPW(2); }
+            // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
+            if (!replay) {
+                const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
+                const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
+                const int ntile = (n + 15) >> 4;
+                float v2a = 0.f, v2b = 0.f;
+                // pt.mean: dz <= 16 rows = one tile, K = n: every wavefront takes a K slice behind its variance tiles; the slice's
+                // operand loads (at most 16 k-steps when n <= 512) go out now, in front of the variance tiles' own
+                const int nsl = min(NW, part_rows / 16);
+                const int msl = nsl - 1 - wave;                                // (the last wavefronts have the lightest variance shares)
+                const int mper = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
+                const int mkb = msl * mper, mke = min(n, (msl + 1) * mper);
+                const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
+                float am[16];
+                if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
+                // tiles in descending cost, dealt to the wavefronts in a snake so that the triangular work balances
+                for (int r = 0;; ++r) {
+                    const int idx = (r & 1) ? r * NW + NW - 1 - wave : r * NW + wave;
+                    if (idx >= ntile) { if (r * NW >= ntile) break; else continue; }
+                    const int tt = ntile - 1 - idx, j0 = tt * 16;
+                    const int K = tri ? min(n, j0 + 16) : n;
+                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    mg_mma2(acc0, acc1, Wc, n, n, j0, s_phi, 0, K, lane);
+                    v2a = fmaf(acc0[0], acc0[0], fmaf(acc0[1], acc0[1], fmaf(acc0[2], acc0[2], fmaf(acc0[3], acc0[3], v2a))));
+                    v2b = fmaf(acc1[0], acc1[0], fmaf(acc1[1], acc1[1], fmaf(acc1[2], acc1[2], fmaf(acc1[3], acc1[3], v2b))));
                 }
-                if (first) { VJF_MG_STAMP(5); VJF_MG_STAMPW(2); }
-                // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
-                if (!replay && !from_save) {
-                    const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
-                    const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
-                    const int ntile = (n + 15) >> 4;
-                    float v2a = 0.f, v2b = 0.f;
-                    // pt.mean: dz <= 16 rows = one tile, K = n: every wavefront takes a K slice behind its variance tiles; the slice's
-                    // operand loads (at most 16 k-steps when n <= 512) go out now, in front of the variance tiles' own
-                    const int nsl = min(NW, part_rows / 16);
-                    const int msl = nsl - 1 - wave;                                // (the last wavefronts have the lightest variance shares)
-                    const int mper = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
-                    const int mkb = msl * mper, mke = min(n, (msl + 1) * mper);
-                    const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
-                    float am[16];
-                    if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
-                    // tiles in descending cost, dealt to the wavefronts in a snake so that the triangular work balances
-                    for (int r = 0;; ++r) {
-                        const int idx = (r & 1) ? r * NW + NW - 1 - wave : r * NW + wave;
-                        if (idx >= ntile) { if (r * NW >= ntile) break; else continue; }
-                        const int tt = ntile - 1 - idx, j0 = tt * 16;
-                        const int K = tri ? min(n, j0 + 16) : n;
-                        vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                        mg_mma2(acc0, acc1, Wc, n, n, j0, s_phi, 0, K, lane);
-                        v2a = fmaf(acc0[0], acc0[0], fmaf(acc0[1], acc0[1], fmaf(acc0[2], acc0[2], fmaf(acc0[3], acc0[3], v2a))));
-                        v2b = fmaf(acc1[0], acc1[0], fmaf(acc1[1], acc1[1], fmaf(acc1[2], acc1[2], fmaf(acc1[3], acc1[3], v2b))));
-                    }
-                    if (first) VJF_MG_STAMP(22);
-                    v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
-                    v2b += __shfl_xor(v2b, 16, 64); v2b += __shfl_xor(v2b, 32, 64);
-                    if (lane < 16) { s_red[wave * TR + lane] = v2a; s_red[wave * TR + 16 + lane] = v2b; }
-                    if (wave < nsl) {
-                        const int sl = msl;
-                        vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                        if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, dz, 0, mkb, mke, 0, lane); }
-                        else mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, mkb, mke, lane);
-                        float* pr = s_part + (size_t)(sl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
-                    }
-                    mean_nsl = nsl;
+                if (first) VJF_MG_STAMP(22);
+                v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
+                v2b += __shfl_xor(v2b, 16, 64); v2b += __shfl_xor(v2b, 32, 64);
+                if (lane < 16) { s_red[wave * TR + lane] = v2a; s_red[wave * TR + 16 + lane] = v2b; }
+                if (wave < nsl) {
+                    const int sl = msl;
+                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, dz, 0, mkb, mke, 0, lane); }
+                    else mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, mkb, mke, lane);
+                    float* pr = s_part + (size_t)(sl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
                 }
-                __syncthreads(); MG_PHASE();
-                // (W, w_chol, sigma read.  Once per step: a step that starts over behind the replay of its predecessor forms the same moments
-                //  again -- the RLS state cannot have moved, its update waits for this step's early slabs -- and has been counted)
-                if (last && tid == 0 && !replay && !from_save && !k1_sent) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (last && !replay && !from_save) k1_sent = true;
-                if (!replay && !from_save) {
-                    if (tid < TR) {
-                        float v = 0.f;
-                        for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
-                        s_plv[tid] = logf(v);
-                    }
-                    for (int e = tid; e < TR * dz; e += NT) {
-                        const int j = e >> 5, b = e & 31;
-                        float v = 0.f;
-                        for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
-                        s_pm[j * LD + b] = s_xu[j * LD + b] + v;
-                    }
+                mean_nsl = nsl;
+            }
+            __syncthreads(); MG_PHASE();
+            // (W, w_chol, sigma read.  Once per step: a step that starts over behind the replay of its predecessor forms the same moments
+            //  again -- the RLS state cannot have moved, its update waits for this step's early slabs -- and has been counted)
+            if (last && tid == 0 && !replay && !k1_sent) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last && !replay) k1_sent = true;
+            if (!replay) {
+                if (tid < TR) {
+                    float v = 0.f;
+                    for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
+                    s_plv[tid] = logf(v);
                 }
-                __syncthreads(); MG_PHASE();
-                // pt.mean | pt.logvar of the tile's trials: kept for a replay of this step (by then W and w_chol have moved on).  Two sets, by the
-                // parity of the step: the moments of step t are formed before the verdict on step t - 1 is known
-                for (int e = tid; e < TR * (dz + 1); e += NT) {
-                    const int j = e >> 5, b = e & 31;
-                    if (b < nb) {
-                        float* sv = A.pmsave + ((size_t)(ts & 1) * A.B + b0 + b) * (dz + 1) + j;
-                        if (!replay && !from_save) *sv = j < dz ? s_pm[j * LD + b] : s_plv[b];
-                        else if (j < dz) s_pm[j * LD + b] = *sv;
-                        else s_plv[b] = *sv;
-                    }
-                }
-                if (replay || from_save) { __syncthreads(); MG_PHASE(); }
-                if (from_save) sig = sig_saved;
-                if (first && !replay && !from_save) { m_saved = true; sig_saved = sig; }
-                if (first) VJF_MG_STAMP(10);
-                if (first) { VJF_MG_STAMP(6); VJF_MG_STAMPW(3); }
-            } else {
-                // ---- theta of the previous step.  Nothing above depends on it: the inputs, the features and the predictive moments of a step
-                //      are ready before the parameters are
-                if (first && !replay) {
-                    gate();
-                    if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
-                    if (want_replay) { abort_tile = true; break; }                 // (uniform: every thread read the same word)
-                    if (t > 0 && !tl) {
-                        mg_warm(A.aux, P.aux_len, wg, tid);                        // (see mg_warm)
-                        mg_warm(S + P.train_off, P.train_len, wg, tid);
-                    }
-                }
-                if (first && !replay) rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);  // (the SGD role's)
-                if (first && tl && !replay && t == 0) {                            // (the image of this launch: the SGD role's first act)
-                    if (!vjf_wg_wait_sc1(cnt + MG_C_IMG, (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
-                        vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
-                    if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
-                }
-                if (first && tl && !replay) {                                      // (a replayed pass: they are in LDS, untouched since its step)
-                    // the parameters of this step into LDS: the image the SGD role keeps has the layout of the region, so this is a flat
-                    // 16-byte copy with all of a thread's loads in flight -- one round trip
-                    const __amdgpu_buffer_rsrc_t r_img = mg_rsrc(A.img);
-                    float4* dst = reinterpret_cast<float4*>(smem + Lo.th0);
-                    const int n4 = Lo.th_len >> 2;
-                    for (int q0 = tid; q0 < n4; q0 += 8 * NT) {
-                        float4 v[8];
-    #pragma unroll
-                        for (int q = 0; q < 8; ++q) if (q0 + q * NT < n4) v[q] = mg_ld4(r_img, (q0 + q * NT) * 4);
-    #pragma unroll
-                        for (int q = 0; q < 8; ++q) if (q0 + q * NT < n4) dst[q0 + q * NT] = v[q];
-                    }
-                    __syncthreads(); MG_PHASE();
-                }
-                if (first) { VJF_MG_STAMP(1); VJF_MG_STAMPX(27, -1); VJF_MG_STAMPW(0); }
-                if (first && A.stamps && tid == 0 && t == A.T - 1 && !replay) {
-                    unsigned xcc;
-                    unsigned hwid;
-                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-                    A.stamps[1024 + (size_t)wg * 8 + 6] = (xcc & 15u) | ((unsigned long long)hwid << 8);
-                    A.stamps[1024 + (size_t)wg * 8 + 7] = rls_in ? 1u : 0u;
-                }
-                // ---- stage 3: recognition forward (recognition.py:31-42)
-                {
-                    const float* xin = s_in;
-                    int kin = din, aoff = 0;
-                    for (int l = 0; l < P.L; ++l) {
-                        const float* WT = A.aux + P.aux_recT[l];                   // (kin, hl)
-                        int th_w = 0, th_ldw = 0, th_b = 0;
-                        if (tl) mg_theta_layer(P, Lo.th0, l, th_w, th_ldw, th_b);
-                        const float* bias = tl ? smem + th_b : S + P.off[VJF_SLOT_REC_B0 + 2 * l];
-                        float* out = s_act + aoff * LD;
-                        const int hl = P.h[l], mt = (hl + 15) >> 4;
-                        for (int tt = wave; tt < mt; tt += NW) {
-                            vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                            if (tl) mg_mma2_lds<false>(acc0, acc1, smem + th_w, th_ldw, hl, tt * 16, xin, 0, kin, lane);
-                            else mg_mma2(acc0, acc1, WT, hl, hl, tt * 16, xin, 0, kin, lane);
-    #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int f = tt * 16 + 4 * (lane >> 4) + r;
-                                if (f < hl) {
-                                    const float bf = bias[f];
-                                    out[f * LD + (lane & 15)] = tanhf(acc0[r] + bf);
-                                    out[f * LD + 16 + (lane & 15)] = tanhf(acc1[r] + bf);
-                                }
-                            }
-                        }
-                        __syncthreads(); MG_PHASE();
-                        xin = out; kin = hl; aoff += hl;
-                    }
-                    if (first) VJF_MG_STAMP(23);
-                    // heads: 2 dz <= 32 rows = at most two 16-row tiles -- the K range is split over the wavefronts, partial tiles meet in
-                    // LDS (s_part: a region that is free until the losses / the backward pass) and are summed in slice order
-                    const float* HT = A.aux + P.aux_headT;                         // (hL, 2dz): mean rows then logvar rows
-                    const int mt = (2 * dz + 15) >> 4;
-                    const int nsl = min(NW / mt, part_rows / (16 * mt));
-                    if (wave < mt * nsl) {
-                        const int tt = wave / nsl, sl = wave - tt * nsl;
-                        const int per = (((kin + 3) >> 2) + nsl - 1) / nsl * 4;
-                        vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                        if (tl) mg_mma2_lds<false>(acc0, acc1, smem + Lo.th_head, Lo.th_ldh, 2 * dz, tt * 16, xin, sl * per, min(kin, (sl + 1) * per), lane);
-                        else mg_mma2(acc0, acc1, HT, 2 * dz, 2 * dz, tt * 16, xin, sl * per, min(kin, (sl + 1) * per), lane);
-                        float* pr = s_part + (size_t)((sl * mt + tt) * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
-                    }
-                    __syncthreads(); MG_PHASE();
-                    if (first) VJF_MG_STAMP(24);
-                    const float* bl = tl ? smem + Lo.th_bl : S + P.off[VJF_SLOT_LV_B];
-                    for (int e = tid; e < TR * 2 * dz; e += NT) {
-                        const int f = e >> 5, b = e & 31;
-                        float v = 0.f;
-                        for (int sl = 0; sl < nsl; ++sl) v += s_part[(size_t)((sl * mt + (f >> 4)) * 16 + (f & 15)) * LD + b];
-                        if (f < dz) s_mu[f * LD + b] = v; else s_lv[(f - dz) * LD + b] = v + bl[f - dz];
-                    }
-                }
-                __syncthreads(); MG_PHASE();
-                if (first) VJF_MG_STAMP(3);
-                // ---- stage 4: xt, dx, posterior out, py = xt C^T + d (model.py:28-30)
                 for (int e = tid; e < TR * dz; e += NT) {
                     const int j = e >> 5, b = e & 31;
-                    const float xt = fmaf(s_e2[j * LD + b], expf(0.5f * s_lv[j * LD + b]), s_mu[j * LD + b]);
-                    s_xt[j * LD + b] = xt;
-                    s_dx[j * LD + b] = b < nb ? xt - s_xu[j * LD + b] : 0.f;
+                    float v = 0.f;
+                    for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
+                    s_pm[j * LD + b] = s_xu[j * LD + b] + v;
                 }
-                if (!replay)
-                for (int e = tid; e < nb * dz; e += NT) {                          // coalesced posterior stores
-                    const int b = mg_div(e, m_dz), j = e - b * dz;
-                    mg_st(mu_t + (size_t)(b0 + b) * dz + j, s_mu[j * LD + b]);         // (write-through: the Gram role forms the next step's
-                    mg_st(lv_t + (size_t)(b0 + b) * dz + j, s_lv[j * LD + b]);         //  features from them)
+            }
+            __syncthreads(); MG_PHASE();
+            // pt.mean | pt.logvar of the tile's trials: kept for a replay of this step (by then W and w_chol have moved on).  Two sets, by the
+            // parity of the step: the moments of step t are formed before the verdict on step t - 1 is known
+            for (int e = tid; e < TR * (dz + 1); e += NT) {
+                const int j = e >> 5, b = e & 31;
+                if (b < nb) {
+                    float* sv = A.pmsave + ((size_t)(ts & 1) * A.B + b0 + b) * (dz + 1) + j;
+                    if (!replay) *sv = j < dz ? s_pm[j * LD + b] : s_plv[b];
+                    else if (j < dz) s_pm[j * LD + b] = *sv;
+                    else s_plv[b] = *sv;
+                }
+            }
+            if (replay) { __syncthreads(); MG_PHASE(); }
+            if (first) VJF_MG_STAMP(10);
+            if (first) { VJF_MG_STAMP(6); VJF_MG_STAMPW(3); }
+            // ---- theta of the previous step.  Nothing above depends on it: the inputs, the features and the predictive moments of a step
+            //      are ready before the parameters are
+            if (first && !replay) {
+                gate();
+                if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+                if (want_replay) break;                                        // (uniform: every thread read the same word)
+                if (t > 0 && !tl) {
+                    mg_warm(A.aux, P.aux_len, wg, tid);                        // (see mg_warm)
+                    mg_warm(S + P.train_off, P.train_len, wg, tid);
+                }
+            }
+            if (first && !replay) rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);  // (the SGD role's)
+            if (first && tl && !replay && t == 0) {                            // (the image of this launch: the SGD role's first act)
+                if (!vjf_wg_wait_sc1(cnt + MG_C_IMG, (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                    vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
+                if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+            }
+            if (first && tl && !replay) {                                      // (a replayed pass: they are in LDS, untouched since its step)
+                // the parameters of this step into LDS: the image the SGD role keeps has the layout of the region, so this is a flat
+                // 16-byte copy with all of a thread's loads in flight -- one round trip
+                const __amdgpu_buffer_rsrc_t r_img = mg_rsrc(A.img);
+                float4* dst = reinterpret_cast<float4*>(smem + Lo.th0);
+                const int n4 = Lo.th_len >> 2;
+                for (int q0 = tid; q0 < n4; q0 += 8 * NT) {
+                    float4 v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (q0 + q * NT < n4) v[q] = mg_ld4(r_img, (q0 + q * NT) * 4);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (q0 + q * NT < n4) dst[q0 + q * NT] = v[q];
                 }
                 __syncthreads(); MG_PHASE();
-                {
-                    // sum |dx|^2 per trial (16 lanes each), then the tile's sum in trial order
-                    constexpr int LPT = NT / TR;
-                    const int b = tid / LPT, sl = tid % LPT;
-                    float sdx2 = 0.f;
-                    for (int j = sl; j < dz; j += LPT) { const float dx = s_dx[j * LD + b]; sdx2 = fmaf(dx, dx, sdx2); }
-                    sdx2 = group_sum<LPT>(sdx2);
-                    if (sl == 0) s_sc[b * RS_N + RS_SDX2] = sdx2;
-                }
-                {
-                    const float* CT = A.aux + P.aux_decT;                          // (dz, dy)
-                    const float* d = tl ? smem + Lo.th_bd : S + P.off[VJF_SLOT_DEC_B];
-                    const int mt = (dy + 15) >> 4;
+            }
+            if (first) { VJF_MG_STAMP(1); VJF_MG_STAMPX(27, -1); VJF_MG_STAMPW(0); }
+            if (first && A.stamps && tid == 0 && t == A.T - 1 && !replay) {
+                unsigned xcc;
+                unsigned hwid;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                A.stamps[1024 + (size_t)wg * 8 + 6] = (xcc & 15u) | ((unsigned long long)hwid << 8);
+                A.stamps[1024 + (size_t)wg * 8 + 7] = rls_in ? 1u : 0u;
+            }
+            // ---- stage 3: recognition forward (recognition.py:31-42)
+            {
+                const float* xin = s_in;
+                int kin = din, aoff = 0;
+                for (int l = 0; l < P.L; ++l) {
+                    const float* WT = A.aux + P.aux_recT[l];                   // (kin, hl)
+                    int th_w = 0, th_ldw = 0, th_b = 0;
+                    if (tl) mg_theta_layer(P, Lo.th0, l, th_w, th_ldw, th_b);
+                    const float* bias = tl ? smem + th_b : S + P.off[VJF_SLOT_REC_B0 + 2 * l];
+                    float* out = s_act + aoff * LD;
+                    const int hl = P.h[l], mt = (hl + 15) >> 4;
                     for (int tt = wave; tt < mt; tt += NW) {
                         vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                        if (tl) mg_mma2_lds<false>(acc0, acc1, smem + Lo.th_dec, Lo.th_ldd, dy, tt * 16, s_xt, 0, dz, lane);
-                        else mg_mma2(acc0, acc1, CT, dy, dy, tt * 16, s_xt, 0, dz, lane);
-    #pragma unroll
+                        if (tl) mg_mma2_lds<false>(acc0, acc1, smem + th_w, th_ldw, hl, tt * 16, xin, 0, kin, lane);
+                        else mg_mma2(acc0, acc1, WT, hl, hl, tt * 16, xin, 0, kin, lane);
+#pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int f = tt * 16 + 4 * (lane >> 4) + r;
-                            if (f < dy) { const float df = d[f]; s_py[f * LD + (lane & 15)] = acc0[r] + df; s_py[f * LD + 16 + (lane & 15)] = acc1[r] + df; }
+                            if (f < hl) {
+                                const float bf = bias[f];
+                                out[f * LD + (lane & 15)] = tanhf(acc0[r] + bf);
+                                out[f * LD + 16 + (lane & 15)] = tanhf(acc1[r] + bf);
+                            }
                         }
                     }
+                    __syncthreads(); MG_PHASE();
+                    xin = out; kin = hl; aoff += hl;
                 }
-                if (first) VJF_MG_STAMP(25);
-                // early slab: Phi^T dx of this tile (module.py:94), 16 features x 16 columns per MFMA tile, K = 32 trials
-                if (!replay) {
-                    const int mt = (n + 15) >> 4;
-                    for (int tt = NW - 1 - wave; tt < mt; tt += NW) {
-                        const int m0 = tt * 16, i = lane & 15, kk = lane >> 4;
-                        const float* arow = ((m0 + i) < n ? s_phi + (size_t)(m0 + i) * LD : s_zero) + kk;
-                        const float* brow = (i < dz ? s_dx + (size_t)i * LD : s_zero) + kk;
-                        float a[8], b[8];
-    #pragma unroll
-                        for (int s = 0; s < 8; ++s) { a[s] = arow[4 * s]; b[s] = brow[4 * s]; }
-                        vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    #pragma unroll
-                        for (int s = 0; s < 8; s += 2) {
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
-                        }
-                        acc += acc1;
-                        // [dz column][feature]: a lane's four registers are four consecutive features of one column (features >= n: the
-                        // zero row of the A operand)
-                        const int fq = m0 + 4 * (lane >> 4), col = lane & 15;
-                        if (col < dz && fq < ldn) {
-                            float* p = early + (size_t)col * ldn + fq;
-                            if (!first) { acc[0] += mg_ld(p); acc[1] += mg_ld(p + 1); acc[2] += mg_ld(p + 2); acc[3] += mg_ld(p + 3); }
-                            mg_st4(p, acc[0], acc[1], acc[2], acc[3]);
-                        }
-                    }
+                if (first) VJF_MG_STAMP(23);
+                // heads: 2 dz <= 32 rows = at most two 16-row tiles -- the K range is split over the wavefronts, partial tiles meet in
+                // LDS (s_part: a region that is free until the losses / the backward pass) and are summed in slice order
+                const float* HT = A.aux + P.aux_headT;                         // (hL, 2dz): mean rows then logvar rows
+                const int mt = (2 * dz + 15) >> 4;
+                const int nsl = min(NW / mt, part_rows / (16 * mt));
+                if (wave < mt * nsl) {
+                    const int tt = wave / nsl, sl = wave - tt * nsl;
+                    const int per = (((kin + 3) >> 2) + nsl - 1) / nsl * 4;
+                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    if (tl) mg_mma2_lds<false>(acc0, acc1, smem + Lo.th_head, Lo.th_ldh, 2 * dz, tt * 16, xin, sl * per, min(kin, (sl + 1) * per), lane);
+                    else mg_mma2(acc0, acc1, HT, 2 * dz, 2 * dz, tt * 16, xin, sl * per, min(kin, (sl + 1) * per), lane);
+                    float* pr = s_part + (size_t)((sl * mt + tt) * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
                 }
                 __syncthreads(); MG_PHASE();
-                if (tid == 0 && !replay) {
+                if (first) VJF_MG_STAMP(24);
+                const float* bl = tl ? smem + Lo.th_bl : S + P.off[VJF_SLOT_LV_B];
+                for (int e = tid; e < TR * 2 * dz; e += NT) {
+                    const int f = e >> 5, b = e & 31;
                     float v = 0.f;
-                    for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + RS_SDX2];
-                    s_wg[RS_SDX2] += v;
-                    if (last) mg_st(early + (size_t)16 * ldn + RS_SDX2, s_wg[RS_SDX2]);
+                    for (int sl = 0; sl < nsl; ++sl) v += s_part[(size_t)((sl * mt + (f >> 4)) * 16 + (f & 15)) * LD + b];
+                    if (f < dz) s_mu[f * LD + b] = v; else s_lv[(f - dz) * LD + b] = v + bl[f - dz];
                 }
-                if (first) VJF_MG_STAMP(26);
-                if (last && !replay) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
-                if (first) VJF_MG_STAMP(4);
-                if (last) { VJF_MG_STAMPX(28, -1); VJF_MG_STAMPW(1); }
             }
+            __syncthreads(); MG_PHASE();
+            if (first) VJF_MG_STAMP(3);
+            // ---- stage 4: xt, dx, posterior out, py = xt C^T + d (model.py:28-30)
+            for (int e = tid; e < TR * dz; e += NT) {
+                const int j = e >> 5, b = e & 31;
+                const float xt = fmaf(s_e2[j * LD + b], expf(0.5f * s_lv[j * LD + b]), s_mu[j * LD + b]);
+                s_xt[j * LD + b] = xt;
+                s_dx[j * LD + b] = b < nb ? xt - s_xu[j * LD + b] : 0.f;
             }
-            if (abort_tile) break;
+            if (!replay)
+            for (int e = tid; e < nb * dz; e += NT) {                          // coalesced posterior stores
+                const int b = mg_div(e, m_dz), j = e - b * dz;
+                mg_st(mu_t + (size_t)(b0 + b) * dz + j, s_mu[j * LD + b]);         // (write-through: the Gram role forms the next step's
+                mg_st(lv_t + (size_t)(b0 + b) * dz + j, s_lv[j * LD + b]);         //  features from them)
+            }
+            __syncthreads(); MG_PHASE();
+            {
+                // sum |dx|^2 per trial (16 lanes each), then the tile's sum in trial order
+                constexpr int LPT = NT / TR;
+                const int b = tid / LPT, sl = tid % LPT;
+                float sdx2 = 0.f;
+                for (int j = sl; j < dz; j += LPT) { const float dx = s_dx[j * LD + b]; sdx2 = fmaf(dx, dx, sdx2); }
+                sdx2 = group_sum<LPT>(sdx2);
+                if (sl == 0) s_sc[b * RS_N + RS_SDX2] = sdx2;
+            }
+            {
+                const float* CT = A.aux + P.aux_decT;                          // (dz, dy)
+                const float* d = tl ? smem + Lo.th_bd : S + P.off[VJF_SLOT_DEC_B];
+                const int mt = (dy + 15) >> 4;
+                for (int tt = wave; tt < mt; tt += NW) {
+                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    if (tl) mg_mma2_lds<false>(acc0, acc1, smem + Lo.th_dec, Lo.th_ldd, dy, tt * 16, s_xt, 0, dz, lane);
+                    else mg_mma2(acc0, acc1, CT, dy, dy, tt * 16, s_xt, 0, dz, lane);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = tt * 16 + 4 * (lane >> 4) + r;
+                        if (f < dy) { const float df = d[f]; s_py[f * LD + (lane & 15)] = acc0[r] + df; s_py[f * LD + 16 + (lane & 15)] = acc1[r] + df; }
+                    }
+                }
+            }
+            if (first) VJF_MG_STAMP(25);
+            // early slab: Phi^T dx of this tile (module.py:94), 16 features x 16 columns per MFMA tile, K = 32 trials
+            if (!replay) {
+                const int mt = (n + 15) >> 4;
+                for (int tt = NW - 1 - wave; tt < mt; tt += NW) {
+                    const int m0 = tt * 16, i = lane & 15, kk = lane >> 4;
+                    const float* arow = ((m0 + i) < n ? s_phi + (size_t)(m0 + i) * LD : s_zero) + kk;
+                    const float* brow = (i < dz ? s_dx + (size_t)i * LD : s_zero) + kk;
+                    float a[8], b[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) { a[s] = arow[4 * s]; b[s] = brow[4 * s]; }
+                    vjf_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 8; s += 2) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
+                    }
+                    acc += acc1;
+                    // [dz column][feature]: a lane's four registers are four consecutive features of one column (features >= n: the
+                    // zero row of the A operand)
+                    const int fq = m0 + 4 * (lane >> 4), col = lane & 15;
+                    if (col < dz && fq < ldn) {
+                        float* p = early + (size_t)col * ldn + fq;
+                        if (!first) { acc[0] += mg_ld(p); acc[1] += mg_ld(p + 1); acc[2] += mg_ld(p + 2); acc[3] += mg_ld(p + 3); }
+                        mg_st4(p, acc[0], acc[1], acc[2], acc[3]);
+                    }
+                }
+            }
+            __syncthreads(); MG_PHASE();
+            if (tid == 0 && !replay) {
+                float v = 0.f;
+                for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + RS_SDX2];
+                s_wg[RS_SDX2] += v;
+                if (last) mg_st(early + (size_t)16 * ldn + RS_SDX2, s_wg[RS_SDX2]);
+            }
+            if (first) VJF_MG_STAMP(26);
+            if (last && !replay) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
+            if (first) VJF_MG_STAMP(4);
+            if (last) { VJF_MG_STAMPX(28, -1); VJF_MG_STAMPW(1); }
             // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
             {
                 constexpr int LPT = NT / TR;
@@ -1234,7 +1202,7 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
         // forward half of step e - 1, which is all this event waited for, does not wait for that update: without this wait a late
         // RLS role -- the first steps of a process, instruction caches cold -- read sums of the wrong step.  Nothing is read behind it.
 #ifndef VJF_CHAOS_OMIT_GRAM_GUARD        /* (diagnostic builds: without the wait tools/chaos_handoffs.py must report deviations) */
-        if (e >= 2 && !vjf_wg_wait_sc1(A.cnt + MG_C_PDONE, (unsigned)(e - 1) * (unsigned)A.n_post, tid, SCW + VJF_SC_STATUS))
+        if (e >= 2 && !vjf_wg_wait_sc1(A.cnt + MG_C_PDONE, (unsigned)(e - 1) * (unsigned)(A.n_rls - 1), tid, SCW + VJF_SC_STATUS))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
 #endif
         if (!vjf_wg_wait_sc1(A.cnt + MG_C_GRAM, (unsigned)(e + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
@@ -1312,7 +1280,7 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
     float* s_f = s_r + NW * 16 * 17;                   // [16][17]     Phi^T dx rows
     float* S = A.state;
     float* SCW = S + P.off[VJF_SLOT_SCALARS];
-    const unsigned npost = (unsigned)A.n_post;
+    const unsigned npost = (unsigned)(A.n_rls - 1);
     const unsigned* runw = A.cnt + MG_C_COLFLAGS + VJF_CHOL_MAXBLK + 2;
     // (every byte taken from other roles is read with sc1 loads behind the counts' polls and the workgroup barrier: no acquires)
     const __amdgpu_buffer_rsrc_t r_early = mg_rsrc(A.slab_early);
@@ -1450,6 +1418,10 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     const __amdgpu_buffer_rsrc_t r_late = mg_rsrc(A.slab_late);
     // A lane group serves the same quads in every step: the table entries and the parameters of its first round stay in
     // registers for the whole launch (a longer parameter vector reads the later rounds' from memory each step)
+    // the next launch's counters: zeroed here, by the last workgroup of the grid, before anything else (that block belongs to the
+    // launch before this one, which is complete; the kernel boundary makes the zeros visible to the next launch)
+    if (sw == A.n_sgd - 1)
+        for (int i = tid; i < MG_C_WORDS; i += NT) A.cnt_next[i] = 0u;
     const int q00 = (sw * NT) >> 3;
     int4 k_pi, k_ci;
     int k_grp;
@@ -1645,8 +1617,9 @@ __global__ __launch_bounds__(VJF_MG_THREADS) void vjf_mega_kernel(VjfPlan P, Vjf
     if (threadIdx.x == 0) s_dead = 0;
     __syncthreads();
     int b = (int)blockIdx.x;
-    if (b == 0) { vjf_chol_loop<16>(P, C, lds, &s_dead); return; }          // Cholesky + both substitutions + state noise (solve_here)
-    if (b < A.n_rls) { vjf_rls_post_loop(P, Q, lds, &s_dead, 1, b - 1); return; }   // the inverse loops
+    if (b == 0) { vjf_chol_loop<16>(P, C, lds, &s_dead); return; }
+    if (b == 1) { vjf_rls_post_loop(P, Q, lds, &s_dead, 2, 0); return; }
+    if (b < A.n_rls) { vjf_rls_post_loop(P, Q, lds, &s_dead, 1, b - 2); return; }
     b -= A.n_rls;
     if (b < A.n_trial) { vjf_mega_trial(P, A, lds, b); return; }
     b -= A.n_trial;

@@ -21,6 +21,8 @@
 #define VJF_POST_THREADS 512
 #define VJF_POST_KPAR 4                // wavefronts = 2 row tiles x 4 interleaved block sums
 #define VJF_POST_LDB 33               // padded leading dimension of a 32x32 block in LDS
+#define VJF_POST_LDX 17               // right-hand sides: [row][16 columns + 1 pad]
+#define VJF_RESID_BLOCKS 64
 
 struct VjfPostArgs {
     float* state;
@@ -74,6 +76,39 @@ static inline size_t vjf_post_lds_bytes(const VjfPlan& P) {
     // L blocks + Dinv blocks | solution | block just solved | block table
     return ((size_t)(nbl * (nbl - 1) / 2 + nbl) * 32 * VJF_POST_LDB + (size_t)nbl * 32 * VJF_POST_LDX + 32 * VJF_POST_LDX + 64 + 16 + 16) * 4;
 }
+
+// acc(row = 4*(lane>>4)+r of the 16-row tile, col = lane&15) += sum_m A(tile row, m) * B[m][col], m < 32
+template <class FA>
+__device__ __forceinline__ void post_mma32(vjf_f32x4& acc, const float* Bs, int lane, FA fa) {
+    const int i = lane & 15, kk = lane >> 4;
+    float a[8], b[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { a[s] = fa(i, 4 * s + kk); b[s] = Bs[(4 * s + kk) * VJF_POST_LDX + i]; }
+    __builtin_amdgcn_sched_barrier(0);
+    vjf_f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};                     // two independent chains: the MFMAs issue back to back
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
+    }
+    acc += acc1;
+}
+
+// What these workgroups take from workgroups that run beside them (columns of L and the inverted diagonal blocks from the
+// Cholesky loop; g, Phi^T dx, the sums from the operand role; Phi^T Phi from the Gram role; sigma and the sample count, their own
+// stores of the step before) was stored write-through and drained before the flag / count that announces it, and is read with
+// sc1 loads -- 16-byte buffer loads or 4-byte agent-scope loads, which bypass this CU's vector L1 -- behind the poll that matched
+// and the workgroup barrier: no agent-scope acquire (an L1 invalidate the whole workgroup would wait ~1.7 us for) per column
+// (MI355X guide, "sc1 loads in place of the acquire").  The rare failure path, which reads more, does acquire.
+typedef unsigned post_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t post_rsrc(const float* base, size_t nfloats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(nfloats * 4), 0x00020000);
+}
+__device__ __forceinline__ float4 post_ld4(__amdgpu_buffer_rsrc_t r, size_t float_off) {
+    const post_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, 16);      // aux 16 = sc1
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+__device__ __forceinline__ float post_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Wait (one lane polls, relaxed, bounded) until the Cholesky kernel has published flag word `k` for this epoch; the workgroup
 // barrier; then the sc1 loads of the column (see above).  Returns 0 = there, 1 = the factorisation failed, 2 = timed out.
@@ -390,7 +425,7 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
                 const int gc = j0 * 32 + c0 + c;
                 if (gc >= n) continue;
                 // (16-byte write-through stores: n % 4 == 0 on this path and `first` is a multiple of 32 -- a quarter of the fabric
-                //  writes of the scalar form, beside the trial role's gradient slabs, which leave at the same time)
+                //  writes of the scalar form, beside the trial role's gradient slabs, which can leave at the same time)
                 for (int i = first + 4 * lane; i < n; i += 256) {
                     vjf_f32x4 o = {s_x[i * LX + c], s_x[(i + 1) * LX + c], s_x[(i + 2) * LX + c], s_x[(i + 3) * LX + c]};
                     float* dstp = Wc + (size_t)gc * n + i;

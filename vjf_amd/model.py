@@ -635,9 +635,10 @@ class VJF(Module):
         self._push_lr()
         L = self._backend()
         dev = self._blob.device
-        mu = torch.empty(T, B, self.xdim, device=dev, dtype=torch.float32)
-        lv = torch.empty(T, B, self.xdim, device=dev, dtype=torch.float32)
-        loss = torch.empty(T, 4, device=dev, dtype=torch.float32)
+        # (one allocation for the three outputs: the call's host time is what a short sequence pays per step)
+        nz = T * B * self.xdim
+        out = torch.empty(2 * nz + 4 * T, device=dev, dtype=torch.float32)
+        mu, lv, loss = out[:nz].view(T, B, self.xdim), out[nz:2 * nz].view(T, B, self.xdim), out[2 * nz:].view(T, 4)
         flags = self._flags(sgd, update, warm_up)
         L.vjf_set_stream(self._ctx, stream_ptr())
         world, sharded = self._world()

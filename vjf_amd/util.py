@@ -37,10 +37,16 @@ def dev32(a, ndim2: bool = True) -> Tensor:
     return t.contiguous()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """The HIP stream torch is on (the library launches on the caller's stream): the raw handle, without a Stream object."""
     import ctypes
     if not torch.cuda.is_available():
         return ctypes.c_void_p(0)
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
