@@ -472,7 +472,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     float sig_prev = 0.f, rho_prev = 0.f;
     unsigned nredo = 0;
     for (int t = 0; t <= A.T; ++t) {
-      bool replay = false, replayed = false, k1_sent = false;
+      bool replay = false, replayed = false;
       unsigned rbits = 0;
       for (;;) {
         const int ts = replay ? t - 1 : t;             // the step whose inputs this pass stages
@@ -601,98 +601,28 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 __syncthreads(); MG_PHASE();
             }
             if (first) VJF_MG_STAMP(2);
-            // ---- the RLS update of the previous step (W, w_chol, sigma: write-through stores of the RLS roles) is awaited HERE, in front
-            //      of the parameters: the predictive moments of a step (stage 2, the longest phase of the pass) depend on the features
-            //      and on the RLS state, not on theta -- they are formed while the gradient sum and the SGD step of the previous step are
-            //      still on their way, and the path parameters -> forward -> losses -> backward -> parameters is shorter by that phase.
+            // ---- the RLS update of the previous step (W, w_chol, sigma: write-through stores of the RLS roles), if it is complete
+            //      already: its acquire and the L2 warm-up then cost nothing on the path parameters -> forward -> backward.  If not,
+            //      the same happens behind the forward pass (below): the values read are the same either way.
             if (first && !replay) {
-                rls_in = true;
+                rls_in = t == 0;
                 if (t > 0) {
-                    if (!vjf_wg_wait_sc1(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
-                        vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
-                    if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
-                    mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
+                    if (tid == 0) {
+                        const bool there = (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
+                        if (there && (A.flags & VJF_FLAG_HANDOFF_ACQUIRE)) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                        s_try[0] = there ? 1u : 0u;
+                    }
+                    __syncthreads(); MG_PHASE();
+                    rls_in = s_try[0] != 0u;
+                    if (rls_in) mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
                 }
-                sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
-                tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;                   // w_chol known upper triangular
-            }
-            if (first) { VJF_MG_STAMP(5); VJF_MG_STAMPW(2); }
-            // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
-            if (!replay) {
-                const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
-                const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
-                const int ntile = (n + 15) >> 4;
-                float v2a = 0.f, v2b = 0.f;
-                // pt.mean: dz <= 16 rows = one tile, K = n: every wavefront takes a K slice behind its variance tiles; the slice's
-                // operand loads (at most 16 k-steps when n <= 512) go out now, in front of the variance tiles' own
-                const int nsl = min(NW, part_rows / 16);
-                const int msl = nsl - 1 - wave;                                // (the last wavefronts have the lightest variance shares)
-                const int mper = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
-                const int mkb = msl * mper, mke = min(n, (msl + 1) * mper);
-                const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
-                float am[16];
-                if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
-                // tiles in descending cost, dealt to the wavefronts in a snake so that the triangular work balances
-                for (int r = 0;; ++r) {
-                    const int idx = (r & 1) ? r * NW + NW - 1 - wave : r * NW + wave;
-                    if (idx >= ntile) { if (r * NW >= ntile) break; else continue; }
-                    const int tt = ntile - 1 - idx, j0 = tt * 16;
-                    const int K = tri ? min(n, j0 + 16) : n;
-                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2(acc0, acc1, Wc, n, n, j0, s_phi, 0, K, lane);
-                    v2a = fmaf(acc0[0], acc0[0], fmaf(acc0[1], acc0[1], fmaf(acc0[2], acc0[2], fmaf(acc0[3], acc0[3], v2a))));
-                    v2b = fmaf(acc1[0], acc1[0], fmaf(acc1[1], acc1[1], fmaf(acc1[2], acc1[2], fmaf(acc1[3], acc1[3], v2b))));
-                }
-                if (first) VJF_MG_STAMP(22);
-                v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
-                v2b += __shfl_xor(v2b, 16, 64); v2b += __shfl_xor(v2b, 32, 64);
-                if (lane < 16) { s_red[wave * TR + lane] = v2a; s_red[wave * TR + 16 + lane] = v2b; }
-                if (wave < nsl) {
-                    const int sl = msl;
-                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, dz, 0, mkb, mke, 0, lane); }
-                    else mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, mkb, mke, lane);
-                    float* pr = s_part + (size_t)(sl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
-                }
-                mean_nsl = nsl;
-            }
-            __syncthreads(); MG_PHASE();
-            // (W, w_chol, sigma read.  Once per step: a step that starts over behind the replay of its predecessor forms the same moments
-            //  again -- the RLS state cannot have moved, its update waits for this step's early slabs -- and has been counted)
-            if (last && tid == 0 && !replay && !k1_sent) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (last && !replay) k1_sent = true;
-            if (!replay) {
-                if (tid < TR) {
-                    float v = 0.f;
-                    for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
-                    s_plv[tid] = logf(v);
-                }
-                for (int e = tid; e < TR * dz; e += NT) {
-                    const int j = e >> 5, b = e & 31;
-                    float v = 0.f;
-                    for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
-                    s_pm[j * LD + b] = s_xu[j * LD + b] + v;
+                if (rls_in) {
+                    sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
+                    tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;               // w_chol known upper triangular
                 }
             }
-            __syncthreads(); MG_PHASE();
-            // pt.mean | pt.logvar of the tile's trials: kept for a replay of this step (by then W and w_chol have moved on).  Two sets, by the
-            // parity of the step: the moments of step t are formed before the verdict on step t - 1 is known
-            for (int e = tid; e < TR * (dz + 1); e += NT) {
-                const int j = e >> 5, b = e & 31;
-                if (b < nb) {
-                    float* sv = A.pmsave + ((size_t)(ts & 1) * A.B + b0 + b) * (dz + 1) + j;
-                    if (!replay) *sv = j < dz ? s_pm[j * LD + b] : s_plv[b];
-                    else if (j < dz) s_pm[j * LD + b] = *sv;
-                    else s_plv[b] = *sv;
-                }
-            }
-            if (replay) { __syncthreads(); MG_PHASE(); }
-            if (first) VJF_MG_STAMP(10);
-            if (first) { VJF_MG_STAMP(6); VJF_MG_STAMPW(3); }
-            // ---- theta of the previous step.  Nothing above depends on it: the inputs, the features and the predictive moments of a step
-            //      are ready before the parameters are
+            // ---- theta of the previous step.  Nothing above depends on it: the inputs and the features of a step are ready before the
+            //      parameters are
             if (first && !replay) {
                 gate();
                 if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
@@ -702,7 +632,15 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     mg_warm(S + P.train_off, P.train_len, wg, tid);
                 }
             }
+            float4 wv[2];
+            const bool warm_now = first && !replay && rls_now && !rls_in;      // the RLS update landed while this workgroup waited for the parameters
             if (first && !replay) rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);  // (the SGD role's)
+            if (warm_now) {
+                mg_warm_issue(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid, wv);
+                sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
+                tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
+                rls_in = true;
+            }
             if (first && tl && !replay && t == 0) {                            // (the image of this launch: the SGD role's first act)
                 if (!vjf_wg_wait_sc1(cnt + MG_C_IMG, (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
@@ -723,6 +661,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
                 __syncthreads(); MG_PHASE();
             }
+            if (warm_now) mg_warm_retire(wv);
             if (first) { VJF_MG_STAMP(1); VJF_MG_STAMPX(27, -1); VJF_MG_STAMPW(0); }
             if (first && A.stamps && tid == 0 && t == A.T - 1 && !replay) {
                 unsigned xcc;
@@ -865,6 +804,86 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (last && !replay) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
             if (first) VJF_MG_STAMP(4);
             if (last) { VJF_MG_STAMPX(28, -1); VJF_MG_STAMPW(1); }
+            // ---- the RLS update of the previous step, if it had not landed before the forward pass
+            if (first && !rls_in) {
+                if (!vjf_wg_wait_sc1(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                    vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
+                if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+                mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
+                sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
+                tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
+            }
+            if (first) { VJF_MG_STAMP(5); VJF_MG_STAMPW(2); }
+            // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
+            if (!replay) {
+                const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
+                const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
+                const int ntile = (n + 15) >> 4;
+                float v2a = 0.f, v2b = 0.f;
+                // pt.mean: dz <= 16 rows = one tile, K = n: every wavefront takes a K slice behind its variance tiles; the slice's
+                // operand loads (at most 16 k-steps when n <= 512) go out now, in front of the variance tiles' own
+                const int nsl = min(NW, part_rows / 16);
+                const int msl = nsl - 1 - wave;                                // (the last wavefronts have the lightest variance shares)
+                const int mper = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
+                const int mkb = msl * mper, mke = min(n, (msl + 1) * mper);
+                const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
+                float am[16];
+                if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
+                // tiles in descending cost, dealt to the wavefronts in a snake so that the triangular work balances
+                for (int r = 0;; ++r) {
+                    const int idx = (r & 1) ? r * NW + NW - 1 - wave : r * NW + wave;
+                    if (idx >= ntile) { if (r * NW >= ntile) break; else continue; }
+                    const int tt = ntile - 1 - idx, j0 = tt * 16;
+                    const int K = tri ? min(n, j0 + 16) : n;
+                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    mg_mma2(acc0, acc1, Wc, n, n, j0, s_phi, 0, K, lane);
+                    v2a = fmaf(acc0[0], acc0[0], fmaf(acc0[1], acc0[1], fmaf(acc0[2], acc0[2], fmaf(acc0[3], acc0[3], v2a))));
+                    v2b = fmaf(acc1[0], acc1[0], fmaf(acc1[1], acc1[1], fmaf(acc1[2], acc1[2], fmaf(acc1[3], acc1[3], v2b))));
+                }
+                if (first) VJF_MG_STAMP(22);
+                v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
+                v2b += __shfl_xor(v2b, 16, 64); v2b += __shfl_xor(v2b, 32, 64);
+                if (lane < 16) { s_red[wave * TR + lane] = v2a; s_red[wave * TR + 16 + lane] = v2b; }
+                if (wave < nsl) {
+                    const int sl = msl;
+                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, dz, 0, mkb, mke, 0, lane); }
+                    else mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, mkb, mke, lane);
+                    float* pr = s_part + (size_t)(sl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
+                }
+                mean_nsl = nsl;
+            }
+            __syncthreads(); MG_PHASE();
+            if (last && tid == 0 && !replay) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
+            if (!replay) {
+                if (tid < TR) {
+                    float v = 0.f;
+                    for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
+                    s_plv[tid] = logf(v);
+                }
+                for (int e = tid; e < TR * dz; e += NT) {
+                    const int j = e >> 5, b = e & 31;
+                    float v = 0.f;
+                    for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
+                    s_pm[j * LD + b] = s_xu[j * LD + b] + v;
+                }
+            }
+            __syncthreads(); MG_PHASE();
+            // pt.mean | pt.logvar of the tile's trials: kept for a replay of this step (by then W and w_chol have moved on)
+            for (int e = tid; e < TR * (dz + 1); e += NT) {
+                const int j = e >> 5, b = e & 31;
+                if (b < nb) {
+                    float* sv = A.pmsave + (size_t)(b0 + b) * (dz + 1) + j;
+                    if (!replay) *sv = j < dz ? s_pm[j * LD + b] : s_plv[b];
+                    else if (j < dz) s_pm[j * LD + b] = *sv;
+                    else s_plv[b] = *sv;
+                }
+            }
+            if (replay) { __syncthreads(); MG_PHASE(); }
+            if (first) VJF_MG_STAMP(10);
+            if (first) { VJF_MG_STAMP(6); VJF_MG_STAMPW(3); }
             // ---- stage 5: per-trial loss terms and backward seeds (no 1/B); 16 lanes per trial
             {
                 constexpr int LPT = NT / TR;
