@@ -628,7 +628,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         s_bj[tid] = tid - bi * (bi + 1) / 2;
     }
     if (tid == 0) s_flag[0] = 1;
-    if (tid < 8) s_flag[128 + tid] = 0;                 // the column loop's hand-off words (below)
+    if (tid < 16) s_flag[128 + tid] = 0;                // the column loop's hand-off words (below)
     __syncthreads();
     if (A.stat_count && (!vjf_wg_wait(A.stat_count, it_stat_target, tid, SC + VJF_SC_STATUS) || (A.inject_epoch && tid == 0 && it_epoch == A.inject_epoch))) {
         vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_STATS);
@@ -770,7 +770,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         //        c_chain  = columns whose Dinv is in LDS             (wavefront 0)
         //        c_p1     = columns whose tile L_{k+1,k} is in LDS   (wavefront 0)
         //        c_a, c_b = columns k whose update of tile (k+2,k+1) / (k+2,k+2) is done (helpers)
-        //        c_hb     = helper arrivals: stage s is complete when c_hb >= 6 (s + 1)
+        //        c_hb[h]  = stages helper h has completed: stage s is complete when every c_hb[h] > s
         //      Every update of a tile is applied in column order by construction (stage barriers), so the bits do not depend on
         //      timing.  Polls are bounded: a logic error shows as a failed factorisation, not as a hang.
         volatile int* s_ctl = s_flag + 128;
@@ -788,9 +788,19 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) s_ctl[w] = v;
         };
-        auto hb_arrive = [&]() {                                       // a helper's stage is done
+        auto hb_arrive = [&](int hw, int stages_done) {                // a helper's stage is done: its own word (no atomic: one writer)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(s_ctl + C_HB), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) s_ctl[C_HB + hw] = stages_done;
+        };
+        auto hb_wait = [&](int stages_done) {                          // every helper has that many stages behind it
+            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                int lo = s_ctl[C_HB];
+#pragma unroll
+                for (int h2 = 1; h2 < 6; ++h2) lo = min(lo, (int)s_ctl[C_HB + h2]);
+                if (lo >= stages_done || !v_ok[0]) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
         auto panel_tile = [&](int bi, int k) {                         // L_ik = A_ik Dinv_k^T, in place (one wavefront reads all of it first)
             float* pb = s_blk + (size_t)vtri(bi, k) * 1024;
@@ -833,7 +843,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                     // column k of L and Dinv_k out, write-through, as soon as they are final; their flag once the stores have
                     // drained (nobody waits for this wavefront inside the workgroup)
                     lds_wait(C_CHAIN, k + 1);
-                    if (k + 1 < nbl) { lds_wait(C_P1, k + 1); lds_wait(C_HB, 6 * (2 * k + 1)); }
+                    if (k + 1 < nbl) { lds_wait(C_P1, k + 1); hb_wait(2 * k + 1); }
                     if (!v_ok[0]) break;
                     if (k == 0 && lscr_guard) {                         // (this wavefront alone writes the scratch copies)
                         bool there = false;
@@ -857,9 +867,8 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                 lds_wait(C_CHAIN, k + 1);
                 if (!v_ok[0]) break;
                 for (int bi = k + 2 + hw; bi < nbl; bi += 6) panel_tile(bi, k);
-                hb_arrive();
-                ++stage;
-                lds_wait(C_HB, 6 * stage);
+                hb_arrive(hw, ++stage);
+                hb_wait(stage);
                 if (!v_ok[0]) break;
                 // trailing tiles of column k: (k+1+r, k+1+c), 0 <= c <= r < m, without (0,0) (the chain's own)
                 const int m = nbl - 1 - k;
@@ -873,9 +882,8 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                         for (int c2 = 1; c2 <= r; ++c2, ++q)
                             if (q % 6 == hw) trail_tile(k + 1 + r, k + 1 + c2, k);
                 }
-                hb_arrive();
-                ++stage;
-                lds_wait(C_HB, 6 * stage);
+                hb_arrive(hw, ++stage);
+                hb_wait(stage);
             }
         }
         __syncthreads();

@@ -1437,10 +1437,6 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     const __amdgpu_buffer_rsrc_t r_late = mg_rsrc(A.slab_late);
     // A lane group serves the same quads in every step: the table entries and the parameters of its first round stay in
     // registers for the whole launch (a longer parameter vector reads the later rounds' from memory each step)
-    // the next launch's counters: zeroed here, by the last workgroup of the grid, before anything else (that block belongs to the
-    // launch before this one, which is complete; the kernel boundary makes the zeros visible to the next launch)
-    if (sw == A.n_sgd - 1)
-        for (int i = tid; i < MG_C_WORDS; i += NT) A.cnt_next[i] = 0u;
     const int q00 = (sw * NT) >> 3;
     int4 k_pi, k_ci;
     int k_grp;
@@ -1636,6 +1632,11 @@ __global__ __launch_bounds__(VJF_MG_THREADS) void vjf_mega_kernel(VjfPlan P, Vjf
     if (threadIdx.x == 0) s_dead = 0;
     __syncthreads();
     int b = (int)blockIdx.x;
+    // the NEXT launch's counters are zeroed here, by one workgroup of the operand role, before anything else (that block belongs to the
+    // launch before this one, which is complete; the kernel boundary makes the zeros visible to the next launch): no memset in
+    // front of a launch
+    if (b == A.n_rls + A.n_trial + A.n_gram)
+        for (int i = threadIdx.x; i < MG_C_WORDS; i += VJF_MG_THREADS) A.cnt_next[i] = 0u;
     if (b == 0) { vjf_chol_loop<16>(P, C, lds, &s_dead); return; }
     if (b == 1) { vjf_rls_post_loop(P, Q, lds, &s_dead, 2, 0); return; }
     if (b < A.n_rls) { vjf_rls_post_loop(P, Q, lds, &s_dead, 1, b - 2); return; }
