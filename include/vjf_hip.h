@@ -35,6 +35,12 @@ extern "C" {
 #define VJF_FLAG_SGD 1u      /* sgd=True    : backward, clip to +-1, SGD step (model.py:206-214) */
 #define VJF_FLAG_UPDATE 2u   /* update=True : closed-form updates (model.py:215-216, 156-177)   */
 #define VJF_FLAG_WARM_UP 4u  /* warm_up=True: no dynamics term / no RLS (model.py:148, 370)     */
+#define VJF_FLAG_EXACT_NONFINITE 8u   /* trials sharded over ranks (communicators in the context): a step whose loss has a non-finite
+                                       * component is REPLAYED as on one rank (model.py:138-149: the component becomes the constant 0,
+                                       * the gradient is that of the others) -- at the price of a second sum over ranks in EVERY step
+                                       * (its launches return at once on ordinary steps, the collective itself cannot be skipped:
+                                       * every rank must enter it).  Without the flag such a step's SGD update is skipped and
+                                       * VJF_STATUS_NONFINITE_* raised.  No effect on one rank (always replayed there). */
 
 /* sticky status bits, read with vjf_get_status */
 #define VJF_STATUS_NONFINITE_RECON 1u   /* l_recon non-finite -> replaced by 0 (model.py:138-139) */

@@ -525,6 +525,59 @@ def test_sharded_route_fake_world_of_two(vjf, monkeypatch):
     assert m1.status() == 0 and m2.status() == 0
 
 
+def test_nonfinite_component_on_the_sharded_route(vjf, monkeypatch):
+    """vjf/model.py:138-149 where trials are sharded over ranks (the in-library RCCL route, VJF_DEBUG_FAKE_WORLD=2: two ranks holding
+    the same trials): with `exact_nonfinite` the step whose dynamics term overflows is replayed -- the verdict is taken on the summed
+    loss terms, the backward half runs again without that component's seeds, its gradient goes through a second sum over ranks --
+    and posterior, loss terms and state follow the fp32 oracle on the batch written twice.  Without the flag the step's SGD update
+    is skipped (the documented deviation), which the oracle comparison would not survive."""
+    import os
+    import warnings
+    import torch.distributed as dist
+    B, dz, dy, n, T = 48, 3, 10, 16, 4
+    g = torch.Generator().manual_seed(51)
+    y = torch.randn(T, B, dy, generator=g)
+    eps = torch.randn(T, 2, B, dz, generator=g)
+    torch.manual_seed(50)
+    m = vjf.VJF.make_model(dy, dz, 0, n, [8], likelihood="gaussian", lr=1e-2)
+    m.exact_nonfinite = True
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29539")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.setenv("VJF_DEBUG_FAKE_WORLD", "2")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    os.environ["VJF_FORCE_DIST"] = "1"
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mu0, lv0, _ = m.filter_sequence(y[:2], eps=eps[:2])
+            assert m.route() == "streams"
+            with torch.no_grad():
+                m.transition.velocity.w_chol.mul_(1e25)           # the predictive variance, and with it the dynamics term, overflows
+            s = load_oracle_state(m, np.float32)
+            w_before = m.recognition.mean.weight.clone()
+            mu, lv, loss = m.filter_sequence(y[2:], qs=vjf.Gaussian(mu0[-1], lv0[-1]), eps=eps[2:])
+            torch.cuda.synchronize()
+            st = m.status()
+    finally:
+        os.environ.pop("VJF_FORCE_DIST", None)
+        dist.destroy_process_group()
+    assert st & 2 and not (st & 0x1ff00), hex(st)                  # VJF_STATUS_NONFINITE_DYN, no time-out
+    y2, e2 = torch.cat([y, y], 1), torch.cat([eps, eps], 2)       # the two "ranks" hold the same trials
+    om, ol = torch.cat([mu0[-1], mu0[-1]]).cpu().numpy(), torch.cat([lv0[-1], lv0[-1]]).cpu().numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in range(2, T):
+            o = orc.filter_step(s, y2[t].numpy(), None, om, ol, e2[t, 0].numpy(), e2[t, 1].numpy())
+            om, ol = o.mu_t, o.lv_t
+            close(mu[t - 2], o.mu_t[:B], rtol=2e-4, atol=2e-4)
+            close(loss[t - 2], [o.loss, o.recon, o.dyn, o.entropy], rtol=2e-4, atol=2e-4)
+            if t == 2:
+                assert o.dyn == 0.0
+    state_close(m, s, rtol=2e-3, atol=2e-4, rls_rtol=2e-2, rls_atol=2e-3)
+    assert (m.recognition.mean.weight - w_before).abs().max() > 1e-4   # the other components' gradient was applied
+
+
 def test_state_io_resume_is_bit_exact(vjf, tmp_path):
     """save_state after some steps, load into a fresh model, continue: identical to the uninterrupted run."""
     z, info, _ = gio.traj_case("g5_medium_gaussian_f32")

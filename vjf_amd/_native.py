@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libvjf_hip_chaos.so" if os.environ.get("VJF_LIB")
 ABI_VERSION = 1
 MAX_HIDDEN = 8
 LIK_GAUSSIAN, LIK_POISSON = 0, 1
-FLAG_SGD, FLAG_UPDATE, FLAG_WARM_UP = 1, 2, 4
+FLAG_SGD, FLAG_UPDATE, FLAG_WARM_UP, FLAG_EXACT_NONFINITE = 1, 2, 4, 8
 STATUS_NONFINITE_RECON, STATUS_NONFINITE_DYN, STATUS_NONFINITE_ENT, STATUS_RLS_FAILED = 1, 2, 4, 8
 
 # enum vjf_slot

@@ -648,8 +648,9 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
         VjfTrialMfmaArgs m{};
         m.t = a; m.aux = (const float*)(c->ws + c->cv.aux); m.part = part;
         m.rls_done = rls_done; m.rls_target = rls_target;
-        if (a.replay) {                                            // the backward half again, nothing counted
-            m.part = 2;
+        if (a.replay) {                                            // the backward half again; counted only where an RLS update on another
+            m.part = 2;                                            // stream must not overwrite W, w_chol, sigma under it (count_fwd)
+            if (count_fwd) m.done = (unsigned*)(c->ws + c->cv.flags) + 16;
             hipLaunchKernelGGL(vjf_trial_mfma_kernel, dim3(nblk), dim3(VJF_K1M_THREADS), c->lds_k1m, st, P, m);
             VJF_HIP(hipGetLastError());
             return 0;
@@ -998,6 +999,7 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};   // RLS statistics of even / odd steps (chain B)
     const int fw = c->fake_world;
     const int Bt = B * c->world * fw;                                      // trials of all ranks
+    const bool exact = (flags & VJF_FLAG_EXACT_NONFINITE) && (flags & VJF_FLAG_SGD) && c->comm_a != nullptr;
     auto args = [&](int t) {
         return trial_args(c, B, y + t * sy, u ? u + t * su : nullptr, t ? mu + (t - 1) * sz : mu0, t ? lv + (t - 1) * sz : lv0,
                           eps + (size_t)t * 2 * sz, eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags, t & 1);
@@ -1051,16 +1053,30 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         }
         if (t > 0) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, pdone, post_before, stw);
         if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb))) return rc;
+        if (exact) c->k1_count += (unsigned)trial_blocks(c, B);           // (the replayed backward half of this step reads W, w_chol, sigma too)
         if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, true, nullptr, true))) return rc;
         if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, t & 1))) return rc;
         if (c->comm_a) {                                                   // sum the gradients and the loss sums over ranks
-            if ((rc = all_reduce(redg, (size_t)P.train_len, c->comm_a, sa))) return rc;
-            if ((rc = all_reduce(redg + P.red_SC, (size_t)RS_N, c->comm_a, sa))) return rc;
+            if ((rc = all_reduce(redg, (size_t)P.red_SCA + 4, c->comm_a, sa))) return rc;   // [grad | loss sums]: ONE collective
         }
         // (the scalar workgroup ends once the RLS workgroups of step t are resident: the next backward half spins on their results
         //  and must not take the CUs they need before they are placed)
-        rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, fl + VJF_CHOL_MAXBLK + 2, c->epoch, fl + 24, c->start_count);
+        rc = launch_prep(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, fl + VJF_CHOL_MAXBLK + 2, c->epoch, fl + 24, c->start_count,
+                         exact ? 1 : 0);
         if (rc) return rc;
+        if (exact) {
+            // VJF_FLAG_EXACT_NONFINITE: the verdict on the step's loss (the same on every rank: it is taken on the summed loss terms) is
+            // in the flag block now.  The backward half again with the dropped components' seeds at zero, its gradient sums, their sum
+            // over ranks, the SGD pass from them -- every launch returns at once on an ordinary step; the collective runs regardless.
+            VjfTrialArgs ar = args(t);
+            ar.replay = 1;
+            ar.replay_mask = (const unsigned*)(c->ws + c->cv.flags) + kReplayMaskWord;
+            ar.replay_rho = (const float*)(c->ws + c->cv.flags) + kReplayRhoWord;
+            if ((rc = launch_trial(c, ar, 2, sa, true))) return rc;
+            if ((rc = launch_gram(c, B, ne, ng, 0u, redg, sa, t & 1, ar.replay_mask))) return rc;
+            if ((rc = all_reduce(redg, (size_t)P.red_SCA, c->comm_a, sa))) return rc;
+            if ((rc = launch_prep(c, Bt, nullptr, flags, redg, 2, sa, nullptr, 0, nullptr, 0, 2))) return rc;
+        }
         if (t + 1 < T && (rc = launch_trial(c, args(t + 1), 1, sa, true))) return rc;
     }
     VJF_HIP(hipEventRecord(c->ev_c, sb));
@@ -1468,7 +1484,7 @@ void rls_plan(int n, int dout, VjfPlan* P) {
     memset(P, 0, sizeof *P);
     P->n = n; P->dz = dout;
     P->ldE = (int)vjf_align(n + dout, VJF_TILE);
-    P->red_G = 0; P->red_FDX = n * n; P->red_SC = (int)vjf_align((int64_t)n * n + (int64_t)n * dout, 4);
+    P->red_SCA = 0; P->red_G = 0; P->red_FDX = n * n; P->red_SC = (int)vjf_align((int64_t)n * n + (int64_t)n * dout, 4);
     P->red_len = P->red_SC + RS_N;
 }
 struct RlsCarve { size_t E, slabs, red, work, jobs, partial, total; int njobs, nsplit; };

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void vjf_prep_kernel(VjfPlan P, VjfPrepArgs A)
     const int tid = threadIdx.x, bid = blockIdx.x + A.bid0;
     float* S = A.state;
     float* SC = S + P.off[VJF_SLOT_SCALARS];
-    const float* RSC = A.red + P.red_SC;
+    const float* RSC = A.red + P.red_SCA;                      // the loss sums (RS_LRECON .. RS_SSEY)
     const bool do_sgd = A.flags & VJF_FLAG_SGD, do_upd = A.flags & VJF_FLAG_UPDATE, warm = A.flags & VJF_FLAG_WARM_UP;
     const float Bf = (float)A.B_total, invB = 1.0f / Bf;
     float l_recon = RSC[RS_LRECON] * invB, l_dyn = RSC[RS_LDYN] * invB, ent = RSC[RS_ENT] * invB;

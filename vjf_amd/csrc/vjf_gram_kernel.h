@@ -120,7 +120,7 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
             }
             for (; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
             v = vjf_sum32(v);
-            if (l == 0 && ((A.sc_mask >> sc) & 1u)) A.red[P.red_SC + sc] = (float)v;
+            if (l == 0 && ((A.sc_mask >> sc) & 1u)) A.red[(sc < RS_SDX2 ? P.red_SCA : P.red_SC) + sc] = (float)v;   // (loss sums behind the gradients)
         }
         return;
     }

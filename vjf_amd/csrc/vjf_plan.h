@@ -29,8 +29,10 @@ struct VjfPlan {
     int colA_xt;
     int colD_da[VJF_MAX_HIDDEN];
     int colD_dmu, colD_dlv, colD_dpy;
-    // reduce buffer (fp32 elements): [ grad (train_len) | G (n*n) | FDX (n*dz) | scalars (8) ]
-    int red_G, red_FDX, red_SC, red_len;
+    // reduce buffer (fp32 elements): [ grad (train_len) | loss sums (4: RS_LRECON .. RS_SSEY) | G (n*n) | FDX (n*dz) | scalars (8) ]
+    // -- what the gradient chain sums over ranks ([grad | loss sums]) and what the RLS chain sums ([G | FDX | sum |dx|^2]) are each ONE
+    // contiguous range: one all-reduce per chain and step.  The loss sums live at red_SCA + RS_x, sum |dx|^2 at red_SC + RS_SDX2.
+    int red_SCA, red_G, red_FDX, red_SC, red_len;
     // "aux": k-major (transposed) copies of the weights whose torch layout is output-major, so that the
     // MFMA A-operand of the forward products is read in 64-byte row segments.  Workspace, fp32 elements.
     //   aux_recT[l] : (h_{l-1}, h_l)      = rec_W[l]^T
@@ -121,6 +123,7 @@ static inline int vjf_make_plan(const vjf_config* c, VjfPlan* p) {
     p->colD_dpy = col; col += p->dy;
     p->ldD = (int)vjf_align(col, 4);
     int64_t r = vjf_align(p->train_len, 4);            // (G is read as float4)
+    p->red_SCA = (int)r; r += 4;                      // RS_LRECON, RS_LDYN, RS_ENT, RS_SSEY right behind the gradients
     p->red_G = (int)r; r += (int64_t)p->n * p->n;
     p->red_FDX = (int)r; r = vjf_align(r + (int64_t)p->n * p->dz, 4);
     p->red_SC = (int)r; r += RS_N;

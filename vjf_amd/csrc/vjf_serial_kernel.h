@@ -371,14 +371,14 @@ __global__ __launch_bounds__(VJF_K2_THREADS) void vjf_serial_kernel(VjfPlan P, V
     const int tid = threadIdx.x;
     float* S = A.state;
     float* SC = S + P.off[VJF_SLOT_SCALARS];
-    const float* RSC = A.red + P.red_SC;
+    const float* RSC = A.red + P.red_SCA;                      // the loss sums; sum |dx|^2 sits with the RLS statistics
     const int n = P.n, dz = P.dz;
     const bool do_sgd = A.flags & VJF_FLAG_SGD, do_upd = A.flags & VJF_FLAG_UPDATE, warm = A.flags & VJF_FLAG_WARM_UP;
     const float Bf = (float)A.B_total, invB = 1.0f / Bf;
 
     // ---- losses with the finite guards (model.py:138-149); every thread evaluates the same scalars
     float l_recon = RSC[RS_LRECON] * invB, l_dyn = RSC[RS_LDYN] * invB, ent = RSC[RS_ENT] * invB;
-    const float sse_y = RSC[RS_SSEY], sdx2 = RSC[RS_SDX2];
+    const float sse_y = RSC[RS_SSEY], sdx2 = A.red[P.red_SC + RS_SDX2];
     const bool ok_r = isfinite(l_recon), ok_d = isfinite(l_dyn), ok_h = isfinite(ent);
     if (!ok_r) l_recon = 0.f;
     if (!ok_d) l_dyn = 0.f;

@@ -125,7 +125,10 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
     const bool tri = S[P.off[VJF_SLOT_SCALARS] + VJF_SC_TRI_CLEAN] != 0.f;   // w_chol known upper triangular
     const bool fwd = AA.part != 2, bwd = AA.part != 1;
     const unsigned rbits = A.replay ? __hip_atomic_load(A.replay_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    if (A.replay && rbits == 0u) return;                        // (uniform: the usual step)
+    if (A.replay && rbits == 0u) {                              // (uniform: the usual step)
+        if (AA.done && tid == 0) __hip_atomic_fetch_add(AA.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a counted replay: the RLS update waits for it)
+        return;
+    }
     const bool m_r = !(rbits & 1u), m_d = !(rbits & 2u), m_h = !(rbits & 4u);   // loss components kept
     const bool handoff = AA.fwd_done != nullptr && !bwd;        // part 1 inside vjf_filter_seq
     constexpr int LD = VJF_LDT;

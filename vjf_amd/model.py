@@ -488,9 +488,14 @@ class VJF(Module):
     def _overlap_flag(self) -> bool:
         return bool(getattr(self, "_overlap", 1))
 
-    @staticmethod
-    def _flags(sgd, update, warm_up):
-        return (N.FLAG_SGD if sgd else 0) | (N.FLAG_UPDATE if update else 0) | (N.FLAG_WARM_UP if warm_up else 0)
+    # Trials sharded over ranks: True replays a step whose loss has a non-finite component exactly as the reference defines it
+    # (vjf/model.py:138-149) at the price of a second sum over ranks in every step; False (default) skips such a step's SGD update
+    # and raises the status bit.  One rank always replays (include/vjf_hip.h, VJF_FLAG_EXACT_NONFINITE).
+    exact_nonfinite = False
+
+    def _flags(self, sgd, update, warm_up):
+        return ((N.FLAG_SGD if sgd else 0) | (N.FLAG_UPDATE if update else 0) | (N.FLAG_WARM_UP if warm_up else 0)
+                | (N.FLAG_EXACT_NONFINITE if self.exact_nonfinite else 0))
 
     # ------------------------------------------------------------------ operator-level API (reference structure)
     def prior(self, y: Tensor) -> Gaussian:
