@@ -173,6 +173,11 @@ def main():
                     help="N = 1 only: run the sharded route (RCCL communicators inside the context) with a one-rank group")
     a = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: libraries that write to file descriptor 1 (RCCL prints a version banner
+    # there when a communicator is made) go to stderr for the length of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -360,12 +365,15 @@ def main():
         }
         if not a.no_cpu_baseline and s32 is not None:
             out["cpu_baseline"] = cpu_baseline(c, a.config, s32, q0, y[W:].cpu().numpy(), eps[W:].cpu().numpy())
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
         if elbo_check is not None and not elbo_check["ok"]:
             print(f"bench.py: the ELBO of the timed steps differs from the oracle: {elbo_check}", file=sys.stderr)
             sys.exit(3)
     if world > 1:
         dist.barrier()
+    if world > 1 or a.force_dist:
+        model.close()                                           # (RCCL communicators of the context, before the process group goes)
         dist.destroy_process_group()
 
 

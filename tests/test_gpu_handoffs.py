@@ -11,10 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_sequences_with_workgroups_held_at_their_handoffs():
+@pytest.mark.parametrize("acquire", ["0", "1"], ids=["sc1_loads_alone", "with_acquires"])
+def test_sequences_with_workgroups_held_at_their_handoffs(acquire):
+    """Both forms of the hand-offs: the default (sc1 loads of every handed-off byte behind the poll and the barrier) and
+    VJF_HANDOFF_ACQUIRE=1 (an agent-scope acquire behind every wait as well)."""
     from vjf_amd import _build
     _build.build(chaos=True)                                   # (built by __graft_entry__.build(); compiled here if it is missing or stale)
-    env = dict(os.environ, VJF_LIB="chaos")
+    env = dict(os.environ, VJF_LIB="chaos", VJF_HANDOFF_ACQUIRE=acquire)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "chaos_handoffs.py"), "8", "2"], capture_output=True, text=True,
                        env=env, timeout=900)
     tail = "\n".join(l for l in (r.stdout + r.stderr).splitlines() if "amdgpu.ids" not in l)[-3000:]

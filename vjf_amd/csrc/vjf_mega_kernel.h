@@ -805,13 +805,18 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (first) VJF_MG_STAMP(4);
             if (last) { VJF_MG_STAMPX(28, -1); VJF_MG_STAMPW(1); }
             // ---- the RLS update of the previous step, if it had not landed before the forward pass
+            float4 wv_late[2];
+            bool warm_late = false;
             if (first && !rls_in) {
                 if (!vjf_wg_wait_sc1(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
                 if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
-                mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
+                // (sigma and the triangle flag first, then this workgroup's share of the L2 warm-up with its loads left in flight: the
+                //  variance tiles' own operand loads go out behind them instead of waiting a round trip for them)
                 sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
                 tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
+                mg_warm_issue(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid, wv_late);
+                warm_late = true;
             }
             if (first) { VJF_MG_STAMP(5); VJF_MG_STAMPW(2); }
             // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
@@ -856,6 +861,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 mean_nsl = nsl;
             }
             __syncthreads(); MG_PHASE();
+            if (warm_late) mg_warm_retire(wv_late);
             if (last && tid == 0 && !replay) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
             if (!replay) {
                 if (tid < TR) {
