@@ -628,20 +628,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         s_bj[tid] = tid - bi * (bi + 1) / 2;
     }
     if (tid == 0) s_flag[0] = 1;
-    if (tid < 28 || (tid >= 56 && tid < 64)) s_flag[128 + tid] = 0;   // the column loop's tile state words and chain count (below)
-    if (tid == 64) {
-        // owner of every tile among the six helper wavefronts: greedy over the tiles in the order (l, i), each to the helper with the
-        // least work so far -- work = the updates the owner applies (+ the panel for i >= l + 2)
-        int load[6] = {0, 0, 0, 0, 0, 0};
-        for (int l = 0; l < nbl; ++l)
-            for (int i = l; i < nbl; ++i) {
-                const int w = i == l ? (l >= 2 ? l - 1 : 0) : (i == l + 1 ? l : l + 1);
-                int best = 0;
-                for (int h2 = 1; h2 < 6; ++h2) if (load[h2] < load[best]) best = h2;
-                s_flag[128 + 28 + vtri(i, l)] = w > 0 ? best : 7;       // (7: nobody -- (0,0), (1,0), (1,1))
-                if (w > 0) load[best] += w;
-            }
-    }
+    if (tid < 16) s_flag[128 + tid] = 0;                // the column loop's hand-off words (below)
     __syncthreads();
     if (A.stat_count && (!vjf_wg_wait(A.stat_count, it_stat_target, tid, SC + VJF_SC_STATUS) || (A.inject_epoch && tid == 0 && it_epoch == A.inject_epoch))) {
         vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_STATS);
@@ -775,34 +762,46 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         };
         // ---- The column loop without a workgroup barrier in it.  The dependent chain -- Dinv_k from the factor chain of block (k,k),
         //      the one panel tile L_{k+1,k} = A_{k+1,k} Dinv_k^T, the last update of block (k+1,k+1), the next chain -- runs on
-        //      wavefront 0 alone, back to back; it never waits for the bulk of a column's multiply-adds.  Those belong to six helper
-        //      wavefronts (1-3, 5-7: the three other SIMDs).  Every tile (i, l) below the first column has ONE owner among them for the
-        //      whole factorisation, which applies the updates of columns k = 0, 1, .. to it in that order (so the bits do not depend
-        //      on timing) and, for i >= l + 2, turns it into L_il once Dinv_l exists.  The last update of a diagonal tile and the
-        //      panel of the tile below it are the chain wavefront's.  No stage barrier: a tile carries a state word in LDS,
-        //        st[t] = updates applied | final << 8,
-        //      an update of (i, l) by column k waits for L_ik and L_lk to be final, and a helper that has its updates of column l
-        //      behind it turns to the panels of that column the moment the chain has produced Dinv_l -- what the chain needs next
-        //      (tiles (l+1, l) and (l+1, l+1) with all earlier updates) is first in every owner's order.  Wavefront 4 (the chain's SIMD:
-        //      no matrix-core work) writes finished columns out.  Polls are bounded: a logic error shows as a failed factorisation,
-        //      not as a hang.
-        volatile int* s_ctl = s_flag + 128;                            // [0 .. 27] st[t]; [28 .. 55] owner of tile t; [56] columns whose Dinv is in LDS
-        enum { C_ST = 0, C_OWN = 28, C_CHAIN = 56 };
+        //      wavefront 0 alone, back to back (3.4 us a column); it never waits for the bulk of a column's multiply-adds.  Those --
+        //      the other panel tiles and the trailing updates of column k -- belong to six helper wavefronts (1-3, 5-7: the three
+        //      other SIMDs), which work one column behind it in two stages per column (panels | trailing tiles) separated by a
+        //      counter barrier of their own, and which take the two tiles the chain needs next, (k+2,k+1) and (k+2,k+2), first.
+        //      Wavefront 4 (the chain's SIMD: no matrix-core work) writes finished columns out.  All hand-offs are words in LDS:
+        //        c_chain  = columns whose Dinv is in LDS             (wavefront 0)
+        //        c_p1     = columns whose tile L_{k+1,k} is in LDS   (wavefront 0)
+        //        c_a, c_b = columns k whose update of tile (k+2,k+1) / (k+2,k+2) is done (helpers)
+        //        c_hb[h]  = stages helper h has completed: stage s is complete when every c_hb[h] > s
+        //      Every update of a tile is applied in column order by construction (stage barriers), so the bits do not depend on
+        //      timing.  Polls are bounded: a logic error shows as a failed factorisation, not as a hang.
+        volatile int* s_ctl = s_flag + 128;
+        enum { C_CHAIN = 0, C_P1 = 1, C_A = 2, C_B = 3, C_HB = 4 };
         volatile int* v_ok = s_flag;                                   // [0]: 1 while every pivot was positive (wavefront 0 clears it)
-        auto word_wait = [&](int w, int mask, int target) {            // one wavefront: (word & mask) >= target
+        auto lds_wait = [&](int w, int target) {                       // one wavefront: all lanes poll the same word
             for (unsigned spins = 0; spins < (1u << 22); ++spins) {
-                if ((s_ctl[w] & mask) >= target || !v_ok[0]) break;
+                if (s_ctl[w] >= target || !v_ok[0]) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            if ((s_ctl[w] & mask) < target && v_ok[0]) v_ok[0] = 0;    // (cannot happen: ends the step as a failed factorisation)
+            if (s_ctl[w] < target && v_ok[0]) v_ok[0] = 0;             // (cannot happen: ends the step as a failed factorisation)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
-        auto word_post = [&](int w, int v) {                           // this wavefront's LDS writes first, then the word
+        auto lds_post = [&](int w, int v) {                            // this wavefront's LDS writes first, then the word
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) s_ctl[w] = v;
         };
-        auto wait_final = [&](int bi, int bj) { word_wait(C_ST + vtri(bi, bj), 0x100, 0x100); };
-        auto wait_updates = [&](int bi, int bj, int nupd) { word_wait(C_ST + vtri(bi, bj), 0xff, nupd); };
+        auto hb_arrive = [&](int hw, int stages_done) {                // a helper's stage is done: its own word (no atomic: one writer)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) s_ctl[C_HB + hw] = stages_done;
+        };
+        auto hb_wait = [&](int stages_done) {                          // every helper has that many stages behind it
+            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                int lo = s_ctl[C_HB];
+#pragma unroll
+                for (int h2 = 1; h2 < 6; ++h2) lo = min(lo, (int)s_ctl[C_HB + h2]);
+                if (lo >= stages_done || !v_ok[0]) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
         auto panel_tile = [&](int bi, int k) {                         // L_ik = A_ik Dinv_k^T, in place (one wavefront reads all of it first)
             float* pb = s_blk + (size_t)vtri(bi, k) * 1024;
             vjf_f32x16 acc;
@@ -822,15 +821,14 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         if (wave == 0) {
             for (int k = 0; k < nbl; ++k) {                             // (chain(0) ran before the barrier above)
                 if (!v_ok[0]) break;
-                word_post(C_ST + vtri(k, k), 0x100 | k);                // L_kk and Dinv_k are in LDS
-                word_post(C_CHAIN, k + 1);
+                lds_post(C_CHAIN, k + 1);
                 if (k + 1 < nbl) {
-                    wait_updates(k + 1, k, k);                          // tile (k+1,k) carries the updates of columns < k (its owner's)
+                    if (k >= 1) lds_wait(C_A, k);                       // tile (k+1,k) carries the updates of columns < k
                     if (!v_ok[0]) break;
                     panel_tile(k + 1, k);
-                    word_post(C_ST + vtri(k + 1, k), 0x100 | k);
+                    lds_post(C_P1, k + 1);
                     if (k == 0) VJF_STAMP(8);
-                    wait_updates(k + 1, k + 1, k);                      // tile (k+1,k+1) carries the updates of columns < k
+                    if (k >= 1) lds_wait(C_B, k);                       // tile (k+1,k+1) carries the updates of columns < k
                     if (!v_ok[0]) break;
                     trail_tile(k + 1, k + 1, k);
                     if (k == 0) VJF_STAMP(4);
@@ -842,9 +840,10 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         } else if (wave == 4) {
             if (A.post) {
                 for (int k = 0; k < nbl; ++k) {
-                    // column k of L and Dinv_k out, write-through, as soon as every tile of it is final; their flag once the stores
-                    // have drained (nobody waits for this wavefront inside the workgroup)
-                    for (int i = k; i < nbl; ++i) wait_final(i, k);
+                    // column k of L and Dinv_k out, write-through, as soon as they are final; their flag once the stores have
+                    // drained (nobody waits for this wavefront inside the workgroup)
+                    lds_wait(C_CHAIN, k + 1);
+                    if (k + 1 < nbl) { lds_wait(C_P1, k + 1); hb_wait(2 * k + 1); }
                     if (!v_ok[0]) break;
                     if (k == 0 && lscr_guard) {                         // (this wavefront alone writes the scratch copies)
                         bool there = false;
@@ -863,43 +862,29 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
             }
         } else {
             const int hw = wave < 4 ? wave - 1 : wave - 2;              // helper 0 .. 5
-            int pc = 0;                                                 // panels of columns < pc are done (this helper's share)
-            int ready_col = 0;                                          // this helper's tiles of columns <= ready_col carry all their updates
-            auto panels = [&](bool block) {                             // turn to the panels of every column the chain has finished
-                while (pc < nbl - 1 && pc <= ready_col && v_ok[0]) {
-                    if (block) word_wait(C_CHAIN, 0xffff, pc + 1);
-                    else if (s_ctl[C_CHAIN] < pc + 1) break;
-                    if (!v_ok[0]) break;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    for (int i = pc + 2; i < nbl; ++i)
-                        if (s_ctl[C_OWN + vtri(i, pc)] == hw) { panel_tile(i, pc); word_post(C_ST + vtri(i, pc), 0x100 | pc); }
-                    ++pc;
+            int stage = 0;
+            for (int k = 0; k + 1 < nbl; ++k) {
+                lds_wait(C_CHAIN, k + 1);
+                if (!v_ok[0]) break;
+                for (int bi = k + 2 + hw; bi < nbl; bi += 6) panel_tile(bi, k);
+                hb_arrive(hw, ++stage);
+                hb_wait(stage);
+                if (!v_ok[0]) break;
+                // trailing tiles of column k: (k+1+r, k+1+c), 0 <= c <= r < m, without (0,0) (the chain's own)
+                const int m = nbl - 1 - k;
+                if (m >= 2) {
+                    if (hw == 0) { lds_wait(C_P1, k + 1); if (v_ok[0]) { trail_tile(k + 2, k + 1, k); lds_post(C_A, k + 1); } }
+                    if (hw == 1) { trail_tile(k + 2, k + 2, k); lds_post(C_B, k + 1); }
+                    for (int r = 2; r < m; ++r)                         // the rest of block column k + 1
+                        if (r % 6 == hw) { lds_wait(C_P1, k + 1); if (v_ok[0]) trail_tile(k + 1 + r, k + 1, k); }
+                    int q = m;
+                    for (int r = 2; r < m; ++r)
+                        for (int c2 = 1; c2 <= r; ++c2, ++q)
+                            if (q % 6 == hw) trail_tile(k + 1 + r, k + 1 + c2, k);
                 }
-            };
-            for (int k = 0; k + 1 < nbl && v_ok[0]; ++k) {              // the updates that column k of L gives, tiles in the order (l, i)
-                // (this helper's own panels of column k first -- the updates below wait for column k to be final, its tiles included)
-                while (pc <= k && pc < nbl - 1 && v_ok[0]) {
-                    word_wait(C_CHAIN, 0xffff, pc + 1);
-                    if (!v_ok[0]) break;
-                    for (int i = pc + 2; i < nbl; ++i)
-                        if (s_ctl[C_OWN + vtri(i, pc)] == hw) { panel_tile(i, pc); word_post(C_ST + vtri(i, pc), 0x100 | pc); }
-                    ++pc;
-                }
-                for (int l = k + 1; l < nbl && v_ok[0]; ++l) {
-                    for (int i = l; i < nbl; ++i) {
-                        if (s_ctl[C_OWN + vtri(i, l)] != hw) continue;
-                        if (i == l && k == l - 1) continue;             // (the last update of a diagonal tile is the chain's)
-                        panels(false);
-                        wait_final(i, k);
-                        wait_final(l, k);
-                        if (!v_ok[0]) break;
-                        trail_tile(i, l, k);
-                        word_post(C_ST + vtri(i, l), k + 1);
-                    }
-                    if (l == k + 1) ready_col = k + 1;                  // (column k + 1 of this helper's tiles: complete)
-                }
+                hb_arrive(hw, ++stage);
+                hb_wait(stage);
             }
-            panels(true);
         }
         __syncthreads();
         const bool ok = s_flag[0] != 0;
