@@ -103,11 +103,6 @@ int split_for(int B) {
     return s;
 }
 
-// Feature counts from 512 up (configs[4]: 1000): the RLS statistics E^T E are ONE split-K GEMM on 128 x 128 tiles (vjf_trial_wide.h)
-// instead of 32 x 32 tiles from scalar loads
-bool gram_gemm_plan(const VjfPlan& P) { return P.n >= 512; }
-int gram_gemm_splits(int B) { return B >= 2048 ? 8 : B >= 512 ? 4 : 1; }
-
 void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
     jobs.clear();
     // kind 0: lower tiles of E^T E that touch Phi columns
@@ -211,7 +206,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
 }
 
 struct Carve {
-    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, gslabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -225,7 +220,6 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     c.partial = take(((size_t)max_batch / 4 + 2) * RS_N * 4);
     c.partial2 = take(((size_t)max_batch / 4 + 2) * RS_N * 4);
     c.slabs = take((size_t)njobs * split_for(max_batch) * 1024 * 4);
-    c.gslabs = take(gram_gemm_plan(P) ? (size_t)gram_gemm_splits(max_batch) * P.ldE * vjf_align(P.n, 4) * 4 : 16);   // K slabs of the statistics GEMM
     c.red = take((size_t)P.red_len * 4);
     c.red2 = take((size_t)P.red_len * 4);                  // RLS statistics of even / odd steps in the multi-stream sequence
     c.red3 = take((size_t)P.red_len * 4);
@@ -738,28 +732,6 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
 // Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
 int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, int gen = 0, const unsigned* run_if = nullptr) {
     const VjfPlan& P = c->plan;
-    if (gram_gemm_plan(P) && job0 == 0 && njobs >= c->n_ejobs && c->n_ejobs > 0) {
-        // the statistics as one GEMM over the trials: C = E^T E, rows = all ldE columns of E (the padding columns are zero), columns
-        // = the features (rounded up to 4: 16-byte operand loads), K split over blockIdx.z into slabs, lower tiles only
-        const int M = P.ldE, N = (int)vjf_align(P.n, 4), ns = gram_gemm_splits(B);
-        VjfWideGemm g{};
-        const float* E = (const float*)(c->ws + (gen ? c->cv.E2 : c->cv.E));
-        g.A = E; g.lda = P.ldE; g.ta = 1; g.Bm = E; g.ldb = P.ldE; g.nt = 0; g.C = (float*)(c->ws + c->cv.gslabs); g.ldc = N;
-        g.M = M; g.N = N; g.K = B; g.epi = WEPI_NONE; g.va = g.vb = 1; g.lower = 1;
-        g.kslice = (int)vjf_align((B + ns - 1) / ns, 32);
-        g.ok = (const int*)run_if;
-        hipLaunchKernelGGL((vjf_wide_gemm3_kernel<128, 16, 4, true, false, true>), dim3((N + 127) / 128, (M + 127) / 128, ns), dim3(512), 0, st, g);
-        VJF_HIP(hipGetLastError());
-        VjfGramgReduceArgs r{};
-        r.slabs = g.C; r.red = red; r.nsplit = ns; r.M = M; r.N = N; r.run_if = run_if;
-        const int ntc = (P.n + 31) / 32, ntr = (P.n + P.dz + 31) / 32;
-        int tiles = 0;
-        for (int ti = 0; ti < ntr; ++ti) tiles += ti + 1 < ntc ? ti + 1 : ntc;
-        hipLaunchKernelGGL(vjf_gramg_reduce_kernel, dim3(tiles), dim3(256), 0, st, P, r);
-        VJF_HIP(hipGetLastError());
-        if (njobs > c->n_ejobs || sc_mask) return launch_gram(c, B, c->n_ejobs, njobs - c->n_ejobs, sc_mask, red, st, gen, run_if);
-        return 0;
-    }
     const int nsplit = split_for(B);
     VjfGramArgs g{};
     g.jobs = (const VjfJob*)(c->ws + c->cv.jobs);
@@ -768,7 +740,7 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     g.B = B; g.nsplit = nsplit; g.job0 = job0;
     g.rows_per_split = ((B + nsplit - 1) / nsplit + 7) / 8 * 8;
     g.run_if = run_if;
-    if (njobs > 0) hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(VJF_GRAM_THREADS), 0, st, P, g);
+    hipLaunchKernelGGL(vjf_gram_kernel, dim3(njobs * nsplit), dim3(VJF_GRAM_THREADS), 0, st, P, g);
     VJF_HIP(hipGetLastError());
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial)); r.red = red;

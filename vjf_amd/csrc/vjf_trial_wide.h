@@ -29,7 +29,6 @@ struct VjfWideGemm {
                                    // others + bias[n - dz] -> C2 (log-variance); both (M, dz) with ldc
     const int* ok;                 // non-null: nothing is done when ok[0] == 0 (the RLS path after a failed factorisation)
     int va, vb;                    // vjf_wide_gemm2_kernel: A / B can be read 16 bytes at a time (set by the launcher)
-    int kslice, lower;             // vjf_wide_gemm3_kernel<.., SPLIT = true>: K range per blockIdx.z (a multiple of 2 KC); lower-triangle tiles only
 };
 
 // the fused epilogues of the wide GEMM kernels: C[m][n] <- f(v)
@@ -124,10 +123,7 @@ __global__ __launch_bounds__(256) void vjf_wide_gemm_kernel(VjfWideGemm g) {
 // multiple of 4: g.va and g.vb).
 // (TA / BT: the layouts g.ta / g.nt as template parameters -- with run-time branches inside the loop the compiler can no longer
 //  count which loads a store has to wait for, and waits for all of them.)
-// SPLIT: blockIdx.z takes the K range [z kslice, (z + 1) kslice) and writes its partial product to slab z (g.C + z M ldc: the sum
-// over the slabs, in slab order, is taken by the caller's reduce kernel); with g.lower the tiles that lie entirely above the diagonal are
-// skipped (a symmetric product: the statistics Phi^T Phi).
-template <int TN, int KC, int NWR, bool TA, bool BT, bool SPLIT = false>
+template <int TN, int KC, int NWR, bool TA, bool BT>
 __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(4))) void vjf_wide_gemm3_kernel(VjfWideGemm g) {
     constexpr int TM = 128, NB = TN / 64;                                   // NB: 32-column blocks per wavefront
     constexpr int NT = NWR * 128, RB = TM / NWR / 32;                       // NWR x 2 wavefronts of (RB x 32) x TN/2 each
@@ -148,8 +144,6 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(4))) 
         }
     }
     const int m0 = bm * TM, n0 = bn * TN;
-    if (SPLIT && g.lower && n0 > m0 + TM - 1) return;                      // (a tile above the diagonal)
-    const int kbeg = SPLIT ? (int)blockIdx.z * g.kslice : 0, kend = SPLIT ? min(g.K, kbeg + g.kslice) : g.K;
     const int wr = wave >> 1, wc = wave & 1;
     constexpr int sa = TM + 4, sb = TN + 4;                                 // LDS row strides
     vjf_f32x16 acc[RB][NB];
@@ -170,12 +164,12 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(4))) 
 #pragma unroll
         for (int q = 0; q < F; ++q) {
             const int gr = min(r0 + q * RP + kc_row, rows - 1);
-            rv[q] = *reinterpret_cast<const float4*>(base + (size_t)gr * ld + (k < kend ? k : kbeg));
+            rv[q] = *reinterpret_cast<const float4*>(base + (size_t)gr * ld + (k < g.K ? k : 0));
         }
     };
     auto store_kc = [&](float* sx, int S, const float4* rv, int F, int k0) {
         constexpr int RP = NT / L;
-        const bool in = k0 + 4 * kc_kq < kend;
+        const bool in = k0 + 4 * kc_kq < g.K;
 #pragma unroll
         for (int q = 0; q < F; ++q) {
             float* d = sx + (size_t)(4 * kc_kq) * S + q * RP + kc_row;
@@ -187,7 +181,7 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(4))) 
 #pragma unroll
         for (int q = 0; q < F; ++q) {
             const int f = tid + NT * q, k = k0 + f / (R / 4), c = c0 + (f % (R / 4)) * 4;
-            const bool in = k < kend && c < cols;
+            const bool in = k < g.K && c < cols;
             rv[q] = *reinterpret_cast<const float4*>(base + (in ? (size_t)k * ld + c : 0));
         }
     };
@@ -195,7 +189,7 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(4))) 
 #pragma unroll
         for (int q = 0; q < F; ++q) {
             const int f = tid + NT * q, kk = f / (R / 4), c = (f % (R / 4)) * 4;
-            const bool in = k0 + kk < kend && c0 + c < cols;
+            const bool in = k0 + kk < g.K && c0 + c < cols;
             float4 v = rv[q];
             if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(sx + (size_t)kk * S + c) = v;
@@ -217,8 +211,8 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(4))) 
     // chunks ahead of their LDS store.
     auto chunk = [&](int cur, int k0) {
         const int nxt = cur ^ 1;
-        if (k0 + KC < kend) store(nxt, k0 + KC);
-        if (k0 + 3 * KC < kend) load(nxt, k0 + 3 * KC);
+        if (k0 + KC < g.K) store(nxt, k0 + KC);
+        if (k0 + 3 * KC < g.K) load(nxt, k0 + 3 * KC);
         const float* pa = s_a[cur] + oa;
         const float* pb = s_b[cur] + ob;
 #pragma unroll
@@ -244,17 +238,15 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(4))) 
         }
         __syncthreads();
     };
-    load(0, kbeg);
-    store(0, kbeg);
-    if (kbeg + KC < kend) load(1, kbeg + KC);
-    if (kbeg + 2 * KC < kend) load(0, kbeg + 2 * KC);
+    load(0, 0);
+    store(0, 0);
+    if (KC < g.K) load(1, KC);
+    if (2 * KC < g.K) load(0, 2 * KC);
     __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += 2 * KC) {
+    for (int k0 = 0; k0 < g.K; k0 += 2 * KC) {
         chunk(0, k0);
-        if (k0 + KC < kend) chunk(1, k0 + KC);
+        if (k0 + KC < g.K) chunk(1, k0 + KC);
     }
-    VjfWideGemm gz = g;
-    if (SPLIT) gz.C = g.C + (size_t)blockIdx.z * g.M * g.ldc;
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -265,7 +257,7 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(4))) 
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wr * RB + i) * 32 + vrow(r, h);
                 if (m >= g.M) continue;
-                vjf_wide_epilogue(gz, m, n, acc[i][j][r]);
+                vjf_wide_epilogue(g, m, n, acc[i][j][r]);
             }
         }
 }
@@ -548,41 +540,5 @@ __global__ __launch_bounds__(256) void vjf_wide_loss_kernel(VjfPlan P, VjfWideAr
         float v = 0.f;
         if (threadIdx.x <= RS_SDX2) v = ((s_sc[0][threadIdx.x] + s_sc[1][threadIdx.x]) + s_sc[2][threadIdx.x]) + s_sc[3][threadIdx.x];
         A.partial[(size_t)blockIdx.x * RS_N + threadIdx.x] = v;
-    }
-}
-
-
-// The statistics Gram of the wide route as ONE split-K GEMM (vjf_wide_gemm3_kernel<128, 16, 4, true, false, true>: E^T E over the
-// trials, lower tiles only) instead of 32 x 32 tiles from scalar loads: this kernel sums the K slabs in slab order (deterministic) and
-// scatters -- G = Phi^T Phi (module.py:96) into both triangles, transposed through LDS so that both stores are row-contiguous, and
-// the rows n .. n + dz of E^T E as Phi^T dx (module.py:94).  grid = lower 32 x 32 tiles of the (ldE x n) product, 256 threads.
-struct VjfGramgReduceArgs { const float* slabs; float* red; int nsplit, M, N; const unsigned* run_if; };
-__global__ __launch_bounds__(256) void vjf_gramg_reduce_kernel(VjfPlan P, VjfGramgReduceArgs A) {
-    __shared__ float s_t[32][33];
-    if (A.run_if && __hip_atomic_load(A.run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-    const int ntc = (P.n + 31) / 32;                                      // column tiles
-    int ti = 0, rem = blockIdx.x;                                         // tile (ti, tj), tj <= min(ti, ntc - 1), rows in order
-    for (;; ++ti) { const int w = min(ti + 1, ntc); if (rem < w) break; rem -= w; }
-    const int tj = rem;
-    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;                // 8 rows per pass
-    const size_t plane = (size_t)A.M * A.N;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = r0 + 8 * q, gm = ti * 32 + r, gn = tj * 32 + c;
-        float v = 0.f;
-        if (gm < P.n + P.dz && gn < P.n)
-            for (int z = 0; z < A.nsplit; ++z) v += A.slabs[(size_t)z * plane + (size_t)gm * A.N + gn];
-        s_t[r][c] = v;
-        if (gm < P.n) { if (gn < P.n && gn <= gm) A.red[P.red_G + (size_t)gm * P.n + gn] = v; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = r0 + 8 * q;                                         // transposed element: row tj * 32 + r, column ti * 32 + c
-        const int gn = tj * 32 + r, gm = ti * 32 + c;
-        const float v = s_t[c][r];
-        if (gn >= P.n) continue;
-        if (gm < P.n) { if (gn < gm) A.red[P.red_G + (size_t)gn * P.n + gm] = v; }
-        else if (gm < P.n + P.dz) A.red[P.red_FDX + (size_t)gn * P.dz + (gm - P.n)] = v;
     }
 }
