@@ -801,7 +801,11 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 if (last) mg_st(early + (size_t)16 * ldn + RS_SDX2, s_wg[RS_SDX2]);
             }
             if (first) VJF_MG_STAMP(26);
-            if (last && !replay) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
+            // (one tile per workgroup and the RLS update of the previous step still to be taken in: the early slab's write-through
+            //  stores are not drained here -- their acknowledgements travel beside the round trips of that hand-off, below, and the
+            //  count follows there)
+            const bool fuse_fwd = first && last && !replay && !rls_in;
+            if (last && !replay && !fuse_fwd) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
             if (first) VJF_MG_STAMP(4);
             if (last) { VJF_MG_STAMPX(28, -1); VJF_MG_STAMPW(1); }
             // ---- the RLS update of the previous step, if it had not landed before the forward pass
@@ -815,6 +819,14 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 //  variance tiles' own operand loads go out behind them instead of waiting a round trip for them)
                 sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
                 tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
+                if (fuse_fwd) {
+                    // every wavefront's stores of the forward pass (posterior, early slab) and these two loads are behind it: the count
+                    // the operand and Gram roles wait for
+                    vjf_chaos(tid, cnt + MG_C_FWD, 2);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_fetch_add(cnt + MG_C_FWD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 mg_warm_issue(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid, wv_late);
                 warm_late = true;
             }
