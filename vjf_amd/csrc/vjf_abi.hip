@@ -206,7 +206,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
 }
 
 struct Carve {
-    size_t pscr; size_t mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t pscr; size_t mg_xt, mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -242,6 +242,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
         c.mg_pidx = take(slab_len * 4); c.mg_cidx = take(slab_len * 4); c.mg_grp = take(slab_len);
         c.mg_img = take((size_t)vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).th_len * 4 + 64);   // the parameters in the trial role's LDS layout
         c.mg_pmsave = take((size_t)max_batch * (P.dz + 1) * 4);
+        c.mg_xt = take((size_t)P.n * P.n * 4);               // row-major L^-1 (= w_chol^T) for the trial role's 16-byte operand loads
     }
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
@@ -920,6 +921,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     A.slab_early = (float*)(c->ws + c->cv.mg_early); A.slab_late = (float*)(c->ws + c->cv.mg_late); A.gslab = (float*)(c->ws + c->cv.mg_gslab);
     A.red0 = rede[0]; A.red1 = rede[1];
     A.gbuf = (float*)(c->ws + c->cv.work);
+    A.xt = (const float*)(c->ws + c->cv.mg_xt);
     A.cnt = cnt; A.cnt_next = cnt_next; A.flags = flags;
     const bool acq = c->handoff_acquire;                                   // (VJF_HANDOFF_ACQUIRE, read when the context is created)
     if (acq) A.flags |= VJF_FLAG_HANDOFF_ACQUIRE;
@@ -949,6 +951,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     Q.sig_word = (unsigned long long*)(cnt + MG_C_SIGW); Q.acquire = acq ? 1 : 0;
     Q.prep_count = cnt + MG_C_PREP; Q.prep_target = (unsigned)m.n_prep; Q.prep_stride = (unsigned)m.n_prep;
     Q.nsteps = T; Q.step0 = 0; Q.role = 2;
+    Q.xt = (float*)(c->ws + c->cv.mg_xt); Q.xt_count = cnt + MG_C_XT;
     VjfPlan Pk = P;
     const int grid = m.n_rls + m.n_trial + m.n_gram + m.n_prep + m.n_sgd;
 #ifdef VJF_CHAOS

@@ -51,6 +51,7 @@ enum {
     MG_C_REDO_S = 176,   // SGD workgroups done with a replayed step                         target (replays so far) n_sgd
     MG_C_IMG = 208,      // SGD workgroups whose share of the parameter image is in memory (start of the launch)  target n_sgd
     MG_C_SIGW = 224,     // 8 bytes: {epoch, sigma} from the y / W loop to the Cholesky loop of the next step
+    MG_C_XT = 240,       // inverse workgroups whose share of xt = w_chol^T is in memory (start of the launch)              target 2 nbl
     MG_C_MASK = 192,     // (step + 1) << 8 | non-finite loss components (1 recon, 2 dynamics, 4 entropy) of the last step that had one
     MG_C_COLFLAGS = 160, // [0 .. VJF_CHOL_MAXBLK]: column flags of the Cholesky loop; [VJF_CHOL_MAXBLK + 2]: its "operands loaded" word
     MG_C_WORDS = 256
@@ -67,6 +68,7 @@ struct VjfMegaArgs {
     float* slab_early; float* slab_late; float* gslab;
     float* red0; float* red1;                         // reduce buffers of even / odd steps ([G | FDX | sums], as the RLS loops read them)
     float* gbuf;                                      // g (n, dz)
+    const float* xt;                                  // (n, n) row-major L^-1 = w_chol^T: the inverse loops keep it beside w_chol (vjf_post_kernel.h)
     unsigned* cnt;
     unsigned* cnt_next;                               // the other counter block: zeroed by this launch for the next one
     unsigned flags;
@@ -285,6 +287,52 @@ __device__ __forceinline__ void mg_mma2(vjf_f32x4& acc0, vjf_f32x4& acc1, const 
         if (s0 + 16 < nst) {
             mm16(a1, s0 + 16);
             if (s0 + 48 < nst) ld16(a1, s0 + 48);
+        }
+    }
+}
+
+// The predictive-variance product from the ROW-major inverse factor:  acc_g(row, col) += sum_{k < ke} Xt[(m0 + row) * n + k] * Xs[k * LD + 16 g + col].
+// A lane takes 16 bytes along k: lane (i, kk) loads Xt[m0 + i][16 t + 4 kk .. + 3] and feeds component c to the MFMA of step
+// (t, c), whose k index is 16 t + 4 kk + c -- any order of the k indices is a valid product as long as both operands use it (the B
+// operand reads that row of Xs).  One 16-byte sc1 load per lane and 16 k instead of four 4-byte ones; batches of four loads (64 k),
+// two batches in flight.
+__device__ __forceinline__ void mg_mma2x(vjf_f32x4& acc0, vjf_f32x4& acc1, __amdgpu_buffer_rsrc_t rx, int n, int M, int m0, const float* Xs, int ke, int lane) {
+    constexpr int LD = VJF_MG_LD;
+    const int i = lane & 15, kk = lane >> 4;
+    const bool rv = (m0 + i) < M;
+    const int rowoff = (rv ? m0 + i : 0) * n + 4 * kk;
+    const float* xp = Xs + i;
+    const int nt = (ke + 15) >> 4;                    // blocks of 16 k
+    auto ld4 = [&](float4 (&a)[4], int t0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int kq = 16 * (t0 + q) + 4 * kk; a[q] = mg_ld4(rx, rowoff + (kq + 3 < n ? 16 * (t0 + q) : 0)); }
+    };
+    auto mm4 = [&](const float4 (&a)[4], int t0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (t0 + q < nt) {                         // (uniform)
+                const int k0 = 16 * (t0 + q) + 4 * kk;
+                const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = k0 + c, kc = min(k, ke - 1);
+                    const float v = (rv && k < ke) ? av[c] : 0.f;      // (masked at use: see mg_mma2)
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v, xp[kc * LD], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v, xp[kc * LD + 16], acc1, 0, 0, 0);
+                }
+            }
+        }
+    };
+    if (nt <= 0) return;
+    float4 a0[4], a1[4];
+    ld4(a0, 0);
+    if (nt > 4) ld4(a1, 4);
+    for (int t0 = 0; t0 < nt; t0 += 8) {
+        mm4(a0, t0);
+        if (t0 + 8 < nt) ld4(a0, t0 + 8);
+        if (t0 + 4 < nt) {
+            mm4(a1, t0 + 4);
+            if (t0 + 12 < nt) ld4(a1, t0 + 12);
         }
     }
 }
@@ -614,11 +662,16 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     }
                     __syncthreads(); MG_PHASE();
                     rls_in = s_try[0] != 0u;
-                    if (rls_in) mg_warm(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid);
+                    if (rls_in) mg_warm(A.xt, P.n * P.n, wg, tid);
                 }
                 if (rls_in) {
                     sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
                     tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;               // w_chol known upper triangular
+                }
+                if (t == 0) {                                                 // (the row-major copy of L^-1 of this launch: the inverse loops' first act)
+                    if (!vjf_wg_wait_sc1(cnt + MG_C_XT, (unsigned)(A.n_rls - 2), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                        vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
+                    if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
                 }
             }
             // ---- theta of the previous step.  Nothing above depends on it: the inputs and the features of a step are ready before the
@@ -636,7 +689,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             const bool warm_now = first && !replay && rls_now && !rls_in;      // the RLS update landed while this workgroup waited for the parameters
             if (first && !replay) rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);  // (the SGD role's)
             if (warm_now) {
-                mg_warm_issue(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid, wv);
+                mg_warm_issue(A.xt, P.n * P.n, wg, tid, wv);
                 sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
                 tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
                 rls_in = true;
@@ -827,13 +880,13 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     __syncthreads();
                     if (tid == 0) __hip_atomic_fetch_add(cnt + MG_C_FWD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                mg_warm_issue(S + P.off[VJF_SLOT_W_MEAN], P.n * P.dz + P.n * P.n, wg, tid, wv_late);
+                mg_warm_issue(A.xt, P.n * P.n, wg, tid, wv_late);
                 warm_late = true;
             }
             if (first) { VJF_MG_STAMP(5); VJF_MG_STAMPW(2); }
             // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
             if (!replay) {
-                const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
+                const __amdgpu_buffer_rsrc_t r_xt = mg_rsrc(A.xt);
                 const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
                 const int ntile = (n + 15) >> 4;
                 float v2a = 0.f, v2b = 0.f;
@@ -853,7 +906,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     const int tt = ntile - 1 - idx, j0 = tt * 16;
                     const int K = tri ? min(n, j0 + 16) : n;
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2(acc0, acc1, Wc, n, n, j0, s_phi, 0, K, lane);
+                    mg_mma2x(acc0, acc1, r_xt, n, n, j0, s_phi, K, lane);       // rows j0 .. j0 + 15 of L^-1 = columns of w_chol
                     v2a = fmaf(acc0[0], acc0[0], fmaf(acc0[1], acc0[1], fmaf(acc0[2], acc0[2], fmaf(acc0[3], acc0[3], v2a))));
                     v2b = fmaf(acc1[0], acc1[0], fmaf(acc1[1], acc1[1], fmaf(acc1[2], acc1[2], fmaf(acc1[3], acc1[3], v2b))));
                 }
@@ -1594,7 +1647,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
             for (int e = sw * NT + tid; e < n * n; e += A.n_sgd * NT) {
                 const int i = e / n, j = e - i * n;
                 if ((i >> 5) < (j >> 5)) mg_st(Lm + e, 0.f);
-                if ((i >> 5) > (j >> 5)) mg_st(Wc + e, 0.f);
+                if ((i >> 5) > (j >> 5)) { mg_st(Wc + e, 0.f); mg_st(const_cast<float*>(A.xt) + (size_t)j * n + i, 0.f); }   // (and its row-major transpose)
             }
         }
         const unsigned bad = (ok_r ? 0u : 1u) | (ok_d ? 0u : 2u) | (ok_h ? 0u : 4u);

@@ -56,6 +56,9 @@ struct VjfPostArgs {
     int acquire;                  // 1: every wait acquires at agent scope as well (the one-launch route's default)
     unsigned long long* sig_word; // non-null: the new sigma also goes out as ONE 8-byte word {epoch, bits of sigma} for the Cholesky loop
                                   //   of the next step (it then needs neither this workgroup's exit count nor a second load)
+    float* xt;                    // non-null (the one-launch route): (n, n) row-major L^-1 = w_chol^T, kept beside w_chol for the trial role,
+                                  //   whose predictive-variance products read it 16 bytes at a time along k (vjf_mega_kernel.h)
+    unsigned* xt_count;           //   += 1 per inverse workgroup once, at the start of a launch, its share of xt = w_chol^T (from the state) is in memory
 };
 
 #define VJF_POST_STAMP(i)                                                                   \
@@ -432,6 +435,19 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
                     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dstp), "v"(o) : "memory");
                 }
             }
+            if (A.xt) {
+                // the same 16 columns of X = L^-1 row by row: xt[i][j0 * 32 + c0 .. + 16) (rows above the block: zeros the trial role
+                // never reads; rows inside it above the diagonal: the zeros of the substitution)
+                const int gc0 = j0 * 32 + c0;
+                for (int e = tid; e < (n - first) * 4; e += VJF_POST_THREADS) {
+                    const int i = first + (e >> 2), q = (e & 3) * 4;
+                    if (gc0 + q < n) {                                  // (n % 4 == 0)
+                        vjf_f32x4 o = {s_x[i * LX + q], s_x[i * LX + q + 1], s_x[i * LX + q + 2], s_x[i * LX + q + 3]};
+                        float* dstp = A.xt + (size_t)i * n + gc0 + q;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dstp), "v"(o) : "memory");
+                    }
+                }
+            }
             leave();
             return;
         }
@@ -557,6 +573,17 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
 // One pass (nsteps <= 0) or the looping form: nsteps steps, one after the other (see VjfPostArgs::nsteps)
 __device__ __forceinline__ void vjf_rls_post_loop(const VjfPlan& P, const VjfPostArgs& A, float* lds, int* s_dead, const int role, const int bix) {
     const int steps = A.nsteps > 0 ? A.nsteps : 1;
+    if (A.xt && role == 1) {
+        // start of a launch: xt = w_chol^T from the state (the caller may have rewritten the blob since the last launch), a share per
+        // inverse workgroup; the trial role waits for all of them before its first predictive variance
+        const int n = P.n, nwg = 2 * ((n + 31) / 32);
+        const float* Wc = A.state + P.off[VJF_SLOT_W_CHOL];
+        for (int e = bix * VJF_POST_THREADS + (int)threadIdx.x; e < n * n; e += nwg * VJF_POST_THREADS) {
+            const int k = e / n, j = e - k * n;
+            vjf_store_wt(A.xt + (size_t)j * n + k, Wc[e]);
+        }
+        vjf_wg_signal_wt(A.xt_count, (int)threadIdx.x);
+    }
     for (int it = 0; it < steps; ++it) {
         const float* red = ((A.step0 + it) & 1) ? A.red2 : A.red;
         vjf_rls_post_body(P, A, lds, s_dead, A.epoch + (unsigned)it, red, A.k1_target + (unsigned)it * A.k1_stride,
