@@ -389,7 +389,11 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
     }
     // (every column up to the last one reported good pivots: the factor as a whole is good -- its own flag, which the Cholesky
     //  loop raises right behind the last column's, need not be waited for)
-    if (A.k1_done) {                                           // readers of W, w_chol, sigma on another stream: all done?
+    // readers of W, w_chol, sigma on another stream: all done?  The y / W loop of the one-launch route asks only when it is about to
+    // STORE W and sigma (below): the substitutions, the state-noise update and the sigma word for the next factorisation do not
+    // touch what those readers read, and the poll's round trip is off the path sigma -> Cholesky -> W -> sigma.
+    const bool k1_late = solve && A.fold_sigma && A.sig_word != nullptr;
+    if (A.k1_done && !k1_late) {
         if (tid == 0) {
             int st = 2;
             for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
@@ -478,12 +482,15 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
             __syncthreads();
         }
         VJF_POST_STAMP(19);
+    }   // !failed
+    auto store_W = [&]() {
         float* Wm = A.state + P.off[VJF_SLOT_W_MEAN];
         for (int e = tid; e < n * 16; e += VJF_POST_THREADS) {
             const int r = e >> 4, c = e & 15;
             if (c < dz) __hip_atomic_store(Wm + r * dz + c, s_x[r * LX + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1
         }
-    }   // !failed
+    };
+    if (!failed && !k1_late) store_W();
     if (!A.fold_sigma) { leave(); return; }
     // ---- state-noise update on the new W (model.py:373-377):  q = sum|dx|^2 - 2 tr(W^T FDX) + tr(W^T G W)  over the batch.
     //      tr(W^T G W) = sum_ij G_ij (W W^T)_ij: wavefront w forms the lower 32x32 tiles t = w, w + 8, .. of W W^T on the
@@ -558,14 +565,32 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
             float* SC = St + P.off[VJF_SLOT_SCALARS];
             const float mse = (float)(t * pre_scale);
             const float new_sig = logf(pre_old + ((float)A.B_total / pre_tot) * mse);
-            __hip_atomic_store(St + P.off[VJF_SLOT_TR_LOGVAR], new_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(SC + VJF_SC_N_TR, pre_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (A.sig_word)
+            if (A.sig_word)                                    // (first: the next step's factorisation waits for this word alone)
                 __hip_atomic_store(A.sig_word, ((unsigned long long)it_epoch << 32) | (unsigned long long)__float_as_uint(new_sig), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+            bool ok1 = true;
+            if (k1_late && A.k1_done) {                        // sigma, the sample count and W of the state: behind their last readers
+                ok1 = false;
+                for (unsigned spins = 0; spins < VJF_SPIN_LIMIT; ++spins) {
+                    const unsigned v = __hip_atomic_load(A.k1_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(v - it_k1_target) >= 0) { ok1 = true; break; }
+                    if ((spins & 255u) == 255u && vjf_abort_seen(A.status)) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                if (!ok1) { vjf_status_or(A.status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_COLUMN); *s_dead = 1; }
+            }
+            s_ctl[0] = ok1 ? 1 : 0;
+            if (ok1) {
+                __hip_atomic_store(St + P.off[VJF_SLOT_TR_LOGVAR], new_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(SC + VJF_SC_N_TR, pre_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (failed) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED);
         }
         VJF_POST_STAMP(21);
+        if (k1_late) {
+            __syncthreads();
+            if (s_ctl[0] && !failed) store_W();
+        }
     }
     leave();
 }
