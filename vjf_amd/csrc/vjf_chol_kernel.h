@@ -630,7 +630,9 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
     if (tid == 0) s_flag[0] = 1;
     if (tid < 16) s_flag[128 + tid] = 0;                // the column loop's hand-off words (below)
     __syncthreads();
-    if (A.stat_count && (!vjf_wg_wait(A.stat_count, it_stat_target, tid, SC + VJF_SC_STATUS) || (A.inject_epoch && tid == 0 && it_epoch == A.inject_epoch))) {
+    // (the statistics of the step: the Gram role's write-through stores, read below with sc1 loads behind this count -- an acquire
+    //  as well only in the VJF_HANDOFF_ACQUIRE=1 form)
+    if (A.stat_count && (!vjf_wg_wait_sc1(A.stat_count, it_stat_target, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) || (A.inject_epoch && tid == 0 && it_epoch == A.inject_epoch))) {
         vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_STATS);
         *s_dead = 1;
     }
@@ -679,8 +681,15 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
             if (!vjf_wg_wait_sc1(A.wait_count, it_wait_target, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u)) { vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_SIGMA); *s_dead = 1; }
             sig = __hip_atomic_load(S + P.off[VJF_SLOT_TR_LOGVAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
+        typedef unsigned chol_u4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t r_G = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, 0x7fffffff, 0x00020000);
         auto g4 = [&](int gi, int gj) {                                 // 4 entries of G, zero outside the matrix
-            return (gi < n && gj < n) ? *reinterpret_cast<const float4*>(G + (size_t)gi * n + gj) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(gi < n && gj < n)) return make_float4(0.f, 0.f, 0.f, 0.f);
+            if (A.stat_count) {                                         // (another role's stores of this launch: sc1, past this CU's L1)
+                const chol_u4 v4 = __builtin_amdgcn_raw_buffer_load_b128(r_G, (gi * n + gj) * 4, 0, 16);
+                return make_float4(__uint_as_float(v4[0]), __uint_as_float(v4[1]), __uint_as_float(v4[2]), __uint_as_float(v4[3]));
+            }
+            return *reinterpret_cast<const float4*>(G + (size_t)gi * n + gj);
         };
         constexpr int NT = VJF_CHOL_THREADS - 64, NQ = ((VJF_CHOL_MAXBLK * (VJF_CHOL_MAXBLK + 1) / 2 - 1) * 256 + NT - 1) / NT;
         const int t2 = tid - 64;

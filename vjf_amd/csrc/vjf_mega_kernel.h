@@ -1322,21 +1322,31 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
                     vv[r] += __shfl_xor(vv[r], 1, 64);
                     vv[r] += __shfl_xor(vv[r], 2, 64);
                 }
+                // Four consecutive quads (16 lanes) hold rows gr0 .. gr0 + 3 of four consecutive columns: a 4 x 4 transpose through
+                // shuffles gives every one of them a ROW segment too, so that both triangles leave as 16-byte write-through stores
+                // (the scalar form was 4 fabric writes per quad: 29 k per step, and the Cholesky loop waits for this sum).  A
+                // diagonal block is written in full from both sides: its (i, j) and (j, i) sums are the same bits.
+                const int a4 = (lane >> 2) & 3, lb = lane & ~15;
+                float o[4];
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2) {
+                    const float t0 = __shfl(vv[0], lb + 4 * b2, 64), t1 = __shfl(vv[1], lb + 4 * b2, 64);
+                    const float t2 = __shfl(vv[2], lb + 4 * b2, 64), t3 = __shfl(vv[3], lb + 4 * b2, 64);
+                    o[b2] = a4 == 0 ? t0 : a4 == 1 ? t1 : a4 == 2 ? t2 : t3;
+                }
                 if (part == 0 && quad < nq) {
                     const int idx = quad * 4, tt = idx >> 10, el = idx & 1023, code = s_tab[tt];
                     const int j = el >> 8, ln = (el >> 2) & 63;
                     const int gc = (code & 255) * 32 + (ln & 31);
                     const int gr0 = (code >> 8) * 32 + 8 * j + 4 * (ln >> 5);            // the quad: rows gr0 .. gr0 + 3 of column gc
-                    if ((code >> 8) != (code & 255) && gr0 + 3 < n && gc < n) {
-                        // off the diagonal blocks: the transposed entries are four consecutive floats of row gc
-                        mg_st4(red + P.red_G + (size_t)gc * n + gr0, vv[0], vv[1], vv[2], vv[3]);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) mg_st(red + P.red_G + (size_t)(gr0 + r) * n + gc, vv[r]);
+                    if (gr0 + 3 < n && gc < n) {
+                        mg_st4(red + P.red_G + (size_t)gc * n + gr0, vv[0], vv[1], vv[2], vv[3]);                // row gc, columns gr0 .. gr0 + 3
+                        mg_st4(red + P.red_G + (size_t)(gr0 + a4) * n + (gc - a4), o[0], o[1], o[2], o[3]);        // row gr0 + a4, columns gc - a4 .. + 3
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int gr = gr0 + r;
-                            if (gr < n && gc <= gr) {
+                            if (gr < n && gc < n && ((code >> 8) != (code & 255) || gc <= gr)) {
                                 mg_st(red + P.red_G + (size_t)gr * n + gc, vv[r]);
                                 mg_st(red + P.red_G + (size_t)gc * n + gr, vv[r]);
                             }
