@@ -136,13 +136,16 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status);
  *   1 (default)  the one-launch route: ONE launch carries the whole call; the trial, Gram, operand, SGD and RLS roles are
  *                workgroups of one grid, resident as a whole (checked against the occupancy query before it is launched), that
  *                hand over through counters in memory (plans it serves: see vjf_route);
+ *                plans whose RLS update is a sequence of launches (n_rbf > 224) run that update on a second internal stream,
+ *                beside the backward half of its step and the forward half of the next (bit-identical to the one-stream order);
  *   3            the per-step route on three internal streams (the route the RCCL path uses), for A/B measurements;
  *   0            the per-step kernels in the one-stream order (also what tools that serialise kernels need).
  * Returns the resulting setting, or a negative error code. */
 int vjf_set_overlap(vjf_ctx* ctx, int enable);
 
 /* The route a vjf_filter_seq call with these flags would take now: 1 one-launch, 3 three-stream per-step (with communicators:
- * the RCCL route), 0 one-stream per-step.  Negative on error. */
+ * the RCCL route), 2 per-step with the multi-launch RLS update on a second stream (T > 1), 0 one-stream per-step.
+ * Negative on error. */
 int vjf_route(vjf_ctx* ctx, uint32_t flags);
 
 /* Trials sharded over ranks, one process per GPU: with communicators attached, vjf_filter_seq sums the RLS statistics and

@@ -162,7 +162,7 @@ def test_config_E_at_bench_size(vjf):
         close(ls[t - 1], [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-4, atol=1e-4)
     close(m.transition.logvar, s.tr_logvar, rtol=0, atol=5e-5)
     state_close(m, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3, rls_atol=5e-5)
-    assert m.status() == 0 and m.route() == "per-step"
+    assert m.status() == 0 and m.route() == "two-stream"
 
 
 def test_config_D_one_gpu_and_shard_sum(vjf):

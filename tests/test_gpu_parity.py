@@ -313,7 +313,7 @@ def test_nonfinite_loss_is_flagged(vjf):
     assert float(recon) == 0.0             # replaced by the constant 0 (model.py:138-139)
 
 
-@pytest.mark.parametrize("route", ["one_launch", "one_stream", "rls_launches", "wide"])
+@pytest.mark.parametrize("route", ["one_launch", "one_stream", "rls_launches", "wide", "rls_launches_two_streams", "wide_two_streams"])
 @pytest.mark.parametrize("which", ["recon", "dynamics"])
 def test_nonfinite_component_is_dropped_like_the_reference(vjf, which, route):
     """vjf/model.py:138-149: a loss component whose batch mean is not finite becomes the constant 0 -- the step's gradient is that
@@ -323,8 +323,11 @@ def test_nonfinite_component_is_dropped_like_the_reference(vjf, which, route):
     The flagged step is replayed inside the launch (the middle of a sequence) and behind the last step of a call (filter()).
     Routes: the one-launch route; the per-step kernels on one stream (the backward half, the gradient sums and the SGD pass are
     launched again behind the first SGD pass and return at once on ordinary steps); the same with the multi-launch RLS (RBF(260)) and on
-    the GEMM-per-layer trial path (d_y = 300, RBF(1200), hidden [400])."""
+    the GEMM-per-layer trial path (d_y = 300, RBF(1200), hidden [400]); the last two again with the RLS update on a stream of its own
+    (the default for those plans: it must not overwrite W, w_chol, sigma under the replayed backward half)."""
     import warnings
+    two = route.endswith("_two_streams")
+    route = route.replace("_two_streams", "")
     lik = "poisson" if which == "recon" else "gaussian"
     B, dz, dy, n, T = {"wide": (20, 6, 300, 1200, 3), "rls_launches": (40, 3, 10, 260, 4)}.get(route, (40, 3, 10, 16, 4))
     hidden = [400] if route == "wide" else [8]
@@ -335,7 +338,7 @@ def test_nonfinite_component_is_dropped_like_the_reference(vjf, which, route):
     def fresh():
         torch.manual_seed(30)
         m = vjf.VJF.make_model(dy, dz, 0, n, hidden, likelihood=lik, lr=1e-2)
-        if route != "one_launch":
+        if route != "one_launch" and not two:
             m.set_overlap(False)
         return m
 
@@ -356,7 +359,7 @@ def test_nonfinite_component_is_dropped_like_the_reference(vjf, which, route):
         poison(m)
         s = load_oracle_state(m, np.float32)
         mu, lv, loss = m.filter_sequence(y[1:], qs=vjf.Gaussian(mu0[-1], lv0[-1]), eps=eps[1:])
-        assert m.route() == ("one-launch" if route == "one_launch" else "per-step")
+        assert m.route() == ("one-launch" if route == "one_launch" else "two-stream" if two else "per-step")
         st = m.status()
         assert st & bit and not (st & ~0x7 & ~8), hex(st)
         om, ol = mu0[-1].cpu().numpy(), lv0[-1].cpu().numpy()
@@ -772,6 +775,43 @@ def test_split_entry_points_on_the_multi_launch_rls_routes(vjf, monkeypatch, n, 
         q, _ = m2.filter(y[t], None, q, eps=(eps[t, 0], eps[t, 1]))
     close(m2.transition.logvar, m.transition.logvar, rtol=0, atol=2e-6)
     close(m2.transition.velocity.w_mean, m.transition.velocity.w_mean, rtol=1e-3, atol=1e-4)     # (B < n: conditioning)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,hidden,dy,B", [(300, [40], 20, 48), (1150, [400], 300, 48), (260, [8], 10, 700)], ids=["rls_launches", "wide", "rls_launches_B700"])
+def test_rls_update_on_its_own_stream_gives_the_one_stream_bits(vjf, monkeypatch, n, hidden, dy, B):
+    """Plans whose RLS update is a sequence of launches (n_rbf > 224): `filter_sequence` runs that update on a second stream beside
+    the backward half of its step and the forward half of the next (route 'two-stream'); `set_overlap(False)` keeps the one-stream
+    order.  Same kernels, same operands: every output and the whole state blob must agree bit for bit -- also from a workspace of
+    NaNs, also across two calls (the second starts from the first one's state), also with an RLS failure in the middle (a
+    precision matrix made indefinite between the calls: the update is dropped, the status bit raised, the sequence goes on)."""
+    g = torch.Generator().manual_seed(91)
+    T, dz = 5, 4
+    y, eps = torch.randn(2 * T, B, dy, generator=g), torch.randn(2 * T, 2, B, dz, generator=g)
+    outs = []
+    for overlap, pattern in ((1, "0xFF"), (0, "0x00")):
+        monkeypatch.setenv("VJF_DEBUG_POISON_WS", pattern)
+        torch.manual_seed(9)
+        m = vjf.VJF.make_model(dy, dz, 0, n, hidden, likelihood="gaussian", lr=1e-2)
+        m.set_overlap(overlap)
+        mu, lv, ls = m.filter_sequence(y[:T].cuda(), None, None, eps=eps[:T].cuda())
+        assert m.route() == ("two-stream" if overlap else "per-step")
+        assert m.check_status() == 0
+        blob1 = m._blob.cpu().numpy().copy()
+        lr = m.transition.velocity
+        with torch.no_grad():
+            P = lr.w_precision.clone()
+            P[n - 40:, n - 40:] -= 1e7 * torch.eye(40, device=P.device)
+            lr.w_precision.copy_(P)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mu2, lv2, ls2 = m.filter_sequence(y[T:].cuda(), None, vjf.Gaussian(mu[-1], lv[-1]), eps=eps[T:].cuda())
+        assert m.status() & 8
+        outs.append((mu.cpu().numpy(), lv.cpu().numpy(), ls.cpu().numpy(), blob1, mu2.cpu().numpy(), ls2.cpu().numpy(), m._blob.cpu().numpy().copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)
 
 
 @pytest.mark.gpu

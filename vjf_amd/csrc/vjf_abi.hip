@@ -206,7 +206,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
 }
 
 struct Carve {
-    size_t pscr; size_t mg_xt, mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, total;
+    size_t pscr; size_t mg_xt, mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, resid, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -246,6 +246,8 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
     }
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
+    // multi-launch RLS on a stream of its own (filter_seq_two): Phi W of the state-noise update, beside the trial chain's DEL rows
+    c.resid = take(P.n > 32 * VJF_CHOL_MAXBLK ? (size_t)max_batch * P.dz * 4 : 16);
     c.total = o;
     return c;
 }
@@ -288,6 +290,7 @@ struct vjf_ctx {
     unsigned mega_launches; // launches of vjf_mega_kernel so far: launch k counts in counter block k & 1
     hipStream_t stream2, stream3;
     hipEvent_t ev_s, ev_c;
+    hipEvent_t ev_f[2], ev_r[2], ev_b[2];   // two-stream route of the multi-launch RLS plans: forward half / RLS update / backward half of even, odd steps
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
     unsigned k1_count;     // workgroups of the matrix-core trial kernel (whole step or backward half) launched so far
     unsigned post_count;   // workgroups of the post kernel launched so far
@@ -386,6 +389,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     }
     c->start_count = 0; c->mega_launches = 0;
     c->stream2 = c->stream3 = nullptr; c->ev_s = c->ev_c = nullptr;
+    for (int i = 0; i < 2; ++i) c->ev_f[i] = c->ev_r[i] = c->ev_b[i] = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1; c->fake_world = 1;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
@@ -484,6 +488,7 @@ int vjf_ctx_destroy(vjf_ctx* ctx) {
     if (ctx && ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3);
         (void)hipEventDestroy(ctx->ev_s); (void)hipEventDestroy(ctx->ev_c);
+        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(ctx->ev_f[i]); (void)hipEventDestroy(ctx->ev_r[i]); (void)hipEventDestroy(ctx->ev_b[i]); }
         (void)hipStreamDestroy(ctx->stream2); (void)hipStreamDestroy(ctx->stream3);
     }
     delete ctx;
@@ -886,6 +891,11 @@ int ensure_stream2(vjf_ctx* c) {
     VJF_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     VJF_HIP(hipEventCreate(&c->ev_c));
     VJF_HIP(hipEventCreate(&c->ev_s));          // (default flags: the events are attached to kernel launches)
+    for (int i = 0; i < 2; ++i) {
+        VJF_HIP(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming));
+        VJF_HIP(hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming));
+        VJF_HIP(hipEventCreateWithFlags(&c->ev_b[i], hipEventDisableTiming));
+    }
     return 0;
 }
 
@@ -1090,6 +1100,7 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     VJF_HIP(hipStreamWaitEvent(sa, c->ev_c, 0));                           // join: the caller's stream sees the final state
     return 0;
 }
+
 }  // namespace
 
 #ifdef VJF_CHAOS
@@ -1120,7 +1131,10 @@ int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, cons
 namespace {
 // The RLS update for feature counts beyond one compute unit's LDS (vjf_rlsb_kernels.h) and the state-noise update, on stream `st`
 // `ta`: the trial-parallel half's arguments when this rank holds every trial, else null
-int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, const VjfTrialArgs* ta = nullptr) {
+// `before_write`: an event the stream waits for before the update's first store to the state (W, then w_chol, w_pchol, P, sigma) --
+// the readers of the previous values on another stream; `resid`: B x dz floats for Phi W (default: the trial chain's DEL rows)
+int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, const VjfTrialArgs* ta = nullptr,
+                hipEvent_t before_write = nullptr, float* resid = nullptr) {
     const VjfPlan& P = c->plan;
     const int nbl = (P.n + 31) / 32;
     float* work = (float*)(c->ws + c->cv.work);
@@ -1152,10 +1166,12 @@ int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, h
             hipLaunchKernelGGL(vjf_rlsc_col_kernel, dim3(grid), dim3(VJF_RLSC_THREADS), 0, st, P, a);
         }
         gemm(a.X, P.n, 0, a.gbuf, P.dz, a.ybuf, P.dz, P.n, P.dz, P.n, a.ok);                                      // y = X g
+        if (before_write) VJF_HIP(hipStreamWaitEvent(st, before_write, 0));
         gemm(a.X, P.n, 1, a.ybuf, P.dz, c->state + P.off[VJF_SLOT_W_MEAN], P.dz, P.n, P.dz, P.n, a.ok);          // W = X^T y
         hipLaunchKernelGGL(vjf_rlsb_final_kernel, dim3(gx), dim3(256), 0, st, P, a);
         VJF_HIP(hipGetLastError());
     }
+    else if (before_write) VJF_HIP(hipStreamWaitEvent(st, before_write, 0));
     VjfResidArgs ra{};
     ra.state = c->state; ra.red = red; ra.partial = (double*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4);
     ra.B_total = B_total; ra.flags = flags;
@@ -1163,7 +1179,7 @@ int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, h
         // state-noise update (model.py:373-377) from the residual itself: R = Phi W with the GEMM kernel into the DEL buffer (free
         // once the gradient sums -- and a replay's -- are formed), then sum (dx - R)^2
         VjfWideGemm g{};
-        float* R = ta->DEL;
+        float* R = resid ? resid : ta->DEL;
         g.A = ta->E; g.lda = P.ldE; g.Bm = c->state + P.off[VJF_SLOT_W_MEAN]; g.ldb = P.dz; g.C = R; g.ldc = P.dz;
         g.M = ta->B; g.N = P.dz; g.K = P.n; g.epi = WEPI_NONE;
         launch_wide_gemm(g, st);
@@ -1185,7 +1201,7 @@ int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, h
 // After the SGD pass of a one-rank step: the backward half with the seeds of the dropped loss components at zero, the gradient
 // sums, and the SGD pass from them -- every launch returns at once unless the first pass found a non-finite component
 // (vjf/model.py:138-149; the one-launch route does the same inside its grid).
-int launch_replay(vjf_ctx* c, const VjfTrialArgs& a0, int32_t B_total, uint32_t flags, hipStream_t st) {
+int launch_replay(vjf_ctx* c, const VjfTrialArgs& a0, int32_t B_total, uint32_t flags, hipStream_t st, int gen = 0) {
     VjfTrialArgs a = a0;
     a.replay = 1;
     a.replay_mask = (const unsigned*)(c->ws + c->cv.flags) + kReplayMaskWord;
@@ -1193,7 +1209,7 @@ int launch_replay(vjf_ctx* c, const VjfTrialArgs& a0, int32_t B_total, uint32_t 
     int rc = launch_trial(c, a, 2, st);
     if (rc) return rc;
     float* red = (float*)(c->ws + c->cv.red);
-    if ((rc = launch_gram(c, a.B, c->n_ejobs, c->njobs - c->n_ejobs, 0u, red, st, 0, a.replay_mask))) return rc;
+    if ((rc = launch_gram(c, a.B, c->n_ejobs, c->njobs - c->n_ejobs, 0u, red, st, gen, a.replay_mask))) return rc;
     return launch_prep(c, B_total, nullptr, flags, red, 2, st, nullptr, 0, nullptr, 0, 2);
 }
 
@@ -1237,8 +1253,70 @@ int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags)
 }
 
 namespace {
+// Plans whose RLS update is a sequence of launches (n_rbf beyond one compute unit's LDS: BASELINE config E has 1000 features, 33
+// column launches a step), single rank, T > 1: the update of step t on a stream of its own beside the trial chain.  Nothing in it
+// reads what the backward half of step t or the forward half of step t + 1 writes, and those read none of its results:
+//   sa (the caller's stream):  [W, w_chol, sigma of t-1 there] predictive moments, losses, backward half(t) -> gradient sums ->
+//                              clip + SGD (+ the replay of a step with a non-finite loss component) -> forward half(t+1)
+//   sb:                        [forward half(t) there] G, Phi^T dx -> P W, P + G/v -> the column launches -> y, [backward half(t)
+//                              done: it read the previous W, w_chol, sigma] W, w_chol, w_pchol, P, state-noise update
+// Cross-stream order through events only (recorded before the wait that names them, in host order); the rows of E alternate
+// between two buffers (the update's residual Phi W reads step t's rows while step t + 1 writes its own), the statistics of the
+// two chains have buffers of their own, Phi W of the residual too.  Same kernels, same arithmetic as the one-stream order.
+int filter_seq_two(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
+                   const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
+    int rc = ensure_stream2(c);
+    if (rc) return rc;
+    const VjfPlan& P = c->plan;
+    const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
+    hipStream_t sa = c->stream, sb = c->stream2;
+    float* redg = (float*)(c->ws + c->cv.red);
+    float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};
+    float* resid = (float*)(c->ws + c->cv.resid);
+    auto args = [&](int t) {
+        return trial_args(c, B, y + t * sy, u ? u + t * su : nullptr, t ? mu + (t - 1) * sz : mu0, t ? lv + (t - 1) * sz : lv0,
+                          eps + (size_t)t * 2 * sz, eps + (size_t)t * 2 * sz + sz, mu + t * sz, lv + t * sz, flags, t & 1);
+    };
+    rc = check_step_args(c, B, y, u, mu0, lv0, eps, eps + sz, mu, lv);
+    if (rc) return rc;
+    const int ne = c->n_ejobs, ng = c->njobs - ne;
+    const bool replay = (flags & VJF_FLAG_SGD) != 0;
+    VJF_HIP(hipEventRecord(c->ev_s, sa));                                  // (sb: behind whatever the caller's stream holds already)
+    VJF_HIP(hipStreamWaitEvent(sb, c->ev_s, 0));
+    if ((rc = refresh_aux(c))) return rc;
+    if ((rc = launch_trial(c, args(0), 1, sa))) return rc;
+    VJF_HIP(hipEventRecord(c->ev_f[0], sa));
+    for (int t = 0; t < T; ++t) {
+        const int g = t & 1;
+        const VjfTrialArgs ta = args(t);
+        VJF_HIP(hipStreamWaitEvent(sb, c->ev_f[g], 0));
+        if ((rc = launch_gram(c, B, 0, ne, 0u, rede[g], sb, g))) return rc;
+        if (t > 0) VJF_HIP(hipStreamWaitEvent(sa, c->ev_r[g ^ 1], 0));
+        if ((rc = launch_trial(c, ta, 2, sa))) return rc;
+        if ((rc = launch_gram(c, B, ne, ng, kScAll, redg, sa, g))) return rc;
+        if ((rc = launch_prep(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, nullptr, 0, nullptr, 0, replay ? 1 : 0))) return rc;
+        if (replay && (rc = launch_replay(c, ta, B, flags, sa, g))) return rc;
+        VJF_HIP(hipEventRecord(c->ev_b[g], sa));
+        if ((rc = launch_rlsb(c, B, flags, rede[g], sb, &ta, c->ev_b[g], resid))) return rc;
+        VJF_HIP(hipEventRecord(c->ev_r[g], sb));
+        if (t + 1 < T) {
+            if (c->mfma_trial && (rc = refresh_aux(c))) return rc;        // (this route's SGD pass does not keep the transposed copies)
+            if ((rc = launch_trial(c, args(t + 1), 1, sa))) return rc;
+            VJF_HIP(hipEventRecord(c->ev_f[g ^ 1], sa));
+        }
+    }
+    VJF_HIP(hipEventRecord(c->ev_c, sb));
+    VJF_HIP(hipStreamWaitEvent(sa, c->ev_c, 0));                           // join: the caller's stream sees the final state
+    return 0;
+}
+
 // single rank, the step as the reference runs it (model.py:206-216: gradient step and closed-form updates) on a plan the
 // one-launch route serves
+// the multi-launch RLS plans: their update on a second stream beside the trial chain (filter_seq_two)
+bool two_route(const vjf_ctx* c, uint32_t flags) {
+    return c->overlap && !c->comm_a && c->world == 1 && !c->fast_chol && c->plan.n > 32 * VJF_CHOL_MAXBLK && !c->stamps &&
+           (flags & (VJF_FLAG_UPDATE | VJF_FLAG_WARM_UP)) == VJF_FLAG_UPDATE;
+}
 bool mega_route(const vjf_ctx* c, uint32_t flags) {
     return c->mega_ok && c->overlap && !c->comm_a && !c->force_streams && (!c->stamps || c->stamps_keep_overlap) &&
            (flags & (VJF_FLAG_SGD | VJF_FLAG_UPDATE | VJF_FLAG_WARM_UP)) == (VJF_FLAG_SGD | VJF_FLAG_UPDATE);
@@ -1282,7 +1360,8 @@ int vjf_route(vjf_ctx* c, uint32_t flags) {
     if (mega_route(c, flags)) return 1;
     const bool streams = (c->comm_a || c->force_streams) && c->overlap && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP) &&
                          c->fast_chol && c->post_kernels && c->mfma_trial && (!c->stamps || c->stamps_keep_overlap);
-    return streams ? 3 : 0;
+    if (streams) return 3;
+    return two_route(c, flags) ? 2 : 0;
 }
 
 int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
@@ -1313,6 +1392,8 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
         }
         return 0;
     }
+    if (two_route(c, flags) && T > 1)
+        return filter_seq_two(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
     if (c->world > 1)
         return fail(-24, "vjf_filter_seq: with communicators only the multi-stream schedule exists (update, no warm-up, T > 1, "
                          "fast kernels); use vjf_filter_local / vjf_filter_global around your own all-reduce otherwise");

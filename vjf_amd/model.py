@@ -313,13 +313,14 @@ class VJF(Module):
                 N.check(rc, "vjf_set_overlap")
 
     def route(self, sgd: bool = True, update: bool = True) -> str:
-        """The schedule `filter_sequence` would use now for this batch size: 'one-launch', 'streams' or 'per-step'."""
+        """The schedule `filter_sequence` would use now for this batch size: 'one-launch', 'streams' (three streams: the RCCL
+        path), 'two-stream' (plans whose RLS update is a sequence of launches: that update beside the trial chain) or 'per-step'."""
         if self._ctx is None:
             return "unsized"
         rc = self._backend().vjf_route(self._ctx, (N.FLAG_SGD if sgd else 0) | (N.FLAG_UPDATE if update else 0))
         if rc < 0:
             N.check(rc, "vjf_route")
-        return {1: "one-launch", 3: "streams"}.get(rc, "per-step")
+        return {1: "one-launch", 2: "two-stream", 3: "streams"}.get(rc, "per-step")
 
     # ------------------------------------------------------------------ state I/O (SURVEY 8f-4; the reference has no format)
     _RLS_KEYS = ("w_mean", "w_chol", "w_precision", "w_pchol")
