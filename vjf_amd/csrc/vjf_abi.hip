@@ -290,7 +290,7 @@ struct vjf_ctx {
     unsigned mega_launches; // launches of vjf_mega_kernel so far: launch k counts in counter block k & 1
     hipStream_t stream2, stream3;
     hipEvent_t ev_s, ev_c;
-    hipEvent_t ev_f[2], ev_r[2], ev_b[2];   // two-stream route of the multi-launch RLS plans: forward half / RLS update / backward half of even, odd steps
+    hipEvent_t ev_f[2], ev_r[2], ev_b[2], ev_g[2];   // (ev_g: the RLS statistics) two-stream route of the multi-launch RLS plans: forward half / RLS update / backward half of even, odd steps
     unsigned epoch;        // launches of the Cholesky / post pair so far (the hand-off flags carry it)
     unsigned k1_count;     // workgroups of the matrix-core trial kernel (whole step or backward half) launched so far
     unsigned post_count;   // workgroups of the post kernel launched so far
@@ -389,7 +389,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     }
     c->start_count = 0; c->mega_launches = 0;
     c->stream2 = c->stream3 = nullptr; c->ev_s = c->ev_c = nullptr;
-    for (int i = 0; i < 2; ++i) c->ev_f[i] = c->ev_r[i] = c->ev_b[i] = nullptr;
+    for (int i = 0; i < 2; ++i) c->ev_f[i] = c->ev_r[i] = c->ev_b[i] = c->ev_g[i] = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1; c->fake_world = 1;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
@@ -488,7 +488,7 @@ int vjf_ctx_destroy(vjf_ctx* ctx) {
     if (ctx && ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3);
         (void)hipEventDestroy(ctx->ev_s); (void)hipEventDestroy(ctx->ev_c);
-        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(ctx->ev_f[i]); (void)hipEventDestroy(ctx->ev_r[i]); (void)hipEventDestroy(ctx->ev_b[i]); }
+        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(ctx->ev_f[i]); (void)hipEventDestroy(ctx->ev_r[i]); (void)hipEventDestroy(ctx->ev_b[i]); (void)hipEventDestroy(ctx->ev_g[i]); }
         (void)hipStreamDestroy(ctx->stream2); (void)hipStreamDestroy(ctx->stream3);
     }
     delete ctx;
@@ -585,9 +585,9 @@ int vjf_reduce_buffer(vjf_ctx* ctx, float** ptr, int64_t* n_floats) {
 }
 
 namespace {
-int refresh_aux(vjf_ctx* c) {
+int refresh_aux(vjf_ctx* c, hipStream_t st = nullptr) {
     if (!c->mfma_trial && !c->mega_ok) return 0;
-    hipLaunchKernelGGL(vjf_aux_kernel, dim3(32), dim3(256), 0, c->stream, c->plan, (const float*)c->state, (float*)(c->ws + c->cv.aux));
+    hipLaunchKernelGGL(vjf_aux_kernel, dim3(32), dim3(256), 0, st ? st : c->stream, c->plan, (const float*)c->state, (float*)(c->ws + c->cv.aux));
     VJF_HIP(hipGetLastError());
     return 0;
 }
@@ -895,6 +895,7 @@ int ensure_stream2(vjf_ctx* c) {
         VJF_HIP(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming));
         VJF_HIP(hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming));
         VJF_HIP(hipEventCreateWithFlags(&c->ev_b[i], hipEventDisableTiming));
+        VJF_HIP(hipEventCreateWithFlags(&c->ev_g[i], hipEventDisableTiming));
     }
     return 0;
 }
@@ -1133,8 +1134,9 @@ namespace {
 // `ta`: the trial-parallel half's arguments when this rank holds every trial, else null
 // `before_write`: an event the stream waits for before the update's first store to the state (W, then w_chol, w_pchol, P, sigma) --
 // the readers of the previous values on another stream; `resid`: B x dz floats for Phi W (default: the trial chain's DEL rows)
+// `resident`: the column sequence as one resident launch (vjf_rlsc_loop_kernel) -- for an update that runs beside other streams' kernels
 int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, hipStream_t st, const VjfTrialArgs* ta = nullptr,
-                hipEvent_t before_write = nullptr, float* resid = nullptr) {
+                hipEvent_t before_write = nullptr, float* resid = nullptr, bool resident = false) {
     const VjfPlan& P = c->plan;
     const int nbl = (P.n + 31) / 32;
     float* work = (float*)(c->ws + c->cv.work);
@@ -1160,6 +1162,12 @@ int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, h
         // block column k of L and block row k - 1 of X = L^-1 per launch (the block-upper part of X stays zero: the solves
         // below read all of it)
         VJF_HIP(hipMemsetAsync(a.X, 0, (size_t)P.n * P.n * 4, st));
+        // (alone on the chip the launches are the faster form: 937 against 1017 us a step at config E, a step barrier costs more than
+        //  a dispatch; beside the trial chain both give 770-780 us, the resident form with a third of the host's enqueue time)
+        static const bool per_column = getenv("VJF_RLS_COLUMN_LAUNCHES") != nullptr;   // (A/B)
+        if (resident && !per_column && 2 * nbl - 1 <= c->ncu)
+            hipLaunchKernelGGL(vjf_rlsc_loop_kernel, dim3(2 * nbl - 1), dim3(VJF_RLSC_THREADS), 0, st, P, a, (unsigned*)(a.ok + 4));
+        else
         for (int k = 0; k <= nbl; ++k) {
             a.k = k;
             const int ncol = nbl - k, grid = ncol + (ncol > 1 ? ncol - 1 : 0) + (k > 1 ? k - 1 : 0);
@@ -1258,8 +1266,9 @@ namespace {
 // reads what the backward half of step t or the forward half of step t + 1 writes, and those read none of its results:
 //   sa (the caller's stream):  [W, w_chol, sigma of t-1 there] predictive moments, losses, backward half(t) -> gradient sums ->
 //                              clip + SGD (+ the replay of a step with a non-finite loss component) -> forward half(t+1)
-//   sb:                        [forward half(t) there] G, Phi^T dx -> P W, P + G/v -> the column launches -> y, [backward half(t)
-//                              done: it read the previous W, w_chol, sigma] W, w_chol, w_pchol, P, state-noise update
+//   sc:                        [forward half(t) there] G, Phi^T dx
+//   sb:                        [G, Phi^T dx there; the update of t-1 done: stream order] P W, P + G/v -> the column launches -> y,
+//                              [backward half(t) done: it read the previous W, w_chol, sigma] W, w_chol, w_pchol, P, state-noise update
 // Cross-stream order through events only (recorded before the wait that names them, in host order); the rows of E alternate
 // between two buffers (the update's residual Phi W reads step t's rows while step t + 1 writes its own), the statistics of the
 // two chains have buffers of their own, Phi W of the residual too.  Same kernels, same arithmetic as the one-stream order.
@@ -1283,30 +1292,68 @@ int filter_seq_two(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
     const bool replay = (flags & VJF_FLAG_SGD) != 0;
     VJF_HIP(hipEventRecord(c->ev_s, sa));                                  // (sb: behind whatever the caller's stream holds already)
     VJF_HIP(hipStreamWaitEvent(sb, c->ev_s, 0));
-    if ((rc = refresh_aux(c))) return rc;
+    hipStream_t sc = c->stream3;                                            // (its first launch waits for an event of sa behind this point)
+    if ((rc = refresh_aux(c, sa))) return rc;
     if ((rc = launch_trial(c, args(0), 1, sa))) return rc;
     VJF_HIP(hipEventRecord(c->ev_f[0], sa));
+    // VJF_DEBUG_TWO_TIMELINE=1 (diagnostic): timing events around the phases of every step, printed to stderr behind a synchronisation
+    const bool tl = getenv("VJF_DEBUG_TWO_TIMELINE") != nullptr;
+    enum { TL_A0, TL_A1, TL_A2, TL_A3, TL_G0, TL_G1, TL_R0, TL_R2, TL_N };
+    std::vector<hipEvent_t> tle;
+    auto mark = [&](int t, int k, hipStream_t st) -> int {
+        if (!tl) return 0;
+        VJF_HIP(hipEventRecord(tle[(size_t)t * TL_N + k], st));
+        return 0;
+    };
+    if (tl) {
+        tle.resize((size_t)T * TL_N + 1);
+        for (auto& e : tle) VJF_HIP(hipEventCreate(&e));
+        VJF_HIP(hipEventRecord(tle[(size_t)T * TL_N], sa));
+    }
     for (int t = 0; t < T; ++t) {
         const int g = t & 1;
         const VjfTrialArgs ta = args(t);
-        VJF_HIP(hipStreamWaitEvent(sb, c->ev_f[g], 0));
-        if ((rc = launch_gram(c, B, 0, ne, 0u, rede[g], sb, g))) return rc;
+        // (the statistics on a stream of their own: they need the forward half only, not the previous update, which sb may still be in)
+        VJF_HIP(hipStreamWaitEvent(sc, c->ev_f[g], 0));
+        if ((rc = mark(t, TL_G0, sc))) return rc;
+        if ((rc = launch_gram(c, B, 0, ne, 0u, rede[g], sc, g))) return rc;
+        if ((rc = mark(t, TL_G1, sc))) return rc;
+        VJF_HIP(hipEventRecord(c->ev_g[g], sc));
+        VJF_HIP(hipStreamWaitEvent(sb, c->ev_g[g], 0));
         if (t > 0) VJF_HIP(hipStreamWaitEvent(sa, c->ev_r[g ^ 1], 0));
+        if ((rc = mark(t, TL_A0, sa))) return rc;
         if ((rc = launch_trial(c, ta, 2, sa))) return rc;
+        if ((rc = mark(t, TL_A1, sa))) return rc;
         if ((rc = launch_gram(c, B, ne, ng, kScAll, redg, sa, g))) return rc;
         if ((rc = launch_prep(c, B, loss ? loss + 4 * (size_t)t : nullptr, flags, redg, 2, sa, nullptr, 0, nullptr, 0, replay ? 1 : 0))) return rc;
         if (replay && (rc = launch_replay(c, ta, B, flags, sa, g))) return rc;
         VJF_HIP(hipEventRecord(c->ev_b[g], sa));
-        if ((rc = launch_rlsb(c, B, flags, rede[g], sb, &ta, c->ev_b[g], resid))) return rc;
-        VJF_HIP(hipEventRecord(c->ev_r[g], sb));
-        if (t + 1 < T) {
-            if (c->mfma_trial && (rc = refresh_aux(c))) return rc;        // (this route's SGD pass does not keep the transposed copies)
-            if ((rc = launch_trial(c, args(t + 1), 1, sa))) return rc;
+        if ((rc = mark(t, TL_A2, sa))) return rc;
+        if (t + 1 < T) {                                                   // (enqueued before the update's ~40 launches: the host must not
+            if (c->mfma_trial && (rc = refresh_aux(c, sa))) return rc;    //  hold the trial chain back; this route's SGD pass does not keep
+            if ((rc = launch_trial(c, args(t + 1), 1, sa))) return rc;    //  the transposed copies)
             VJF_HIP(hipEventRecord(c->ev_f[g ^ 1], sa));
         }
+        if ((rc = mark(t, TL_A3, sa))) return rc;
+        if ((rc = mark(t, TL_R0, sb))) return rc;
+        if ((rc = launch_rlsb(c, B, flags, rede[g], sb, &ta, c->ev_b[g], resid, true))) return rc;
+        if ((rc = mark(t, TL_R2, sb))) return rc;
+        VJF_HIP(hipEventRecord(c->ev_r[g], sb));
     }
     VJF_HIP(hipEventRecord(c->ev_c, sb));
     VJF_HIP(hipStreamWaitEvent(sa, c->ev_c, 0));                           // join: the caller's stream sees the final state
+    if (tl) {
+        VJF_HIP(hipStreamSynchronize(sa));
+        static const char* nm[TL_N] = {"sa part2 starts", "sa part2 done", "sa sgd(+replay) done", "sa part1(t+1) done", "sc stats start", "sc stats done",
+                                       "sb update starts", "sb update done"};
+        for (int t = 0; t < T; ++t)
+            for (int k = 0; k < TL_N; ++k) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, tle[(size_t)T * TL_N], tle[(size_t)t * TL_N + k]) == hipSuccess)
+                    fprintf(stderr, "two-timeline %10.1f us  [%d] %s\n", ms * 1e3, t, nm[k]);
+            }
+        for (auto& e : tle) (void)hipEventDestroy(e);
+    }
     return 0;
 }
 

@@ -28,6 +28,28 @@ struct VjfRlsbArgs {
     int k;               // block column (factorisation) or block row (inverse) of this launch
 };
 
+// Loads and stores of the column sequence.  WT = false: plain (one launch per step: the kernel boundary makes them visible);
+// WT = true (the resident form, vjf_rlsc_loop_kernel): write-through stores and sc1 loads -- what another workgroup stored and
+// drained before it counted itself in at the step barrier is read from memory, past this CU's L1 and this XCD's L2, with no
+// cache writeback or invalidate at the barrier (MI355X guide, "sc1 loads in place of the acquire").
+template <bool WT> __device__ __forceinline__ float rlsc_ld(const float* p) {
+    if (WT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool WT> __device__ __forceinline__ void rlsc_st(float* p, float v) {
+    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+typedef unsigned rlsc_u4 __attribute__((ext_vector_type(4)));
+template <bool WT> __device__ __forceinline__ float4 rlsc_ld4(const float* M, size_t off) {      // M: the same for the whole wavefront
+    if (WT) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M), 0, 0x7fffffff, 0x00020000);
+        const rlsc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * 4), 0, 16);       // aux 16 = sc1
+        return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    }
+    return *reinterpret_cast<const float4*>(M + off);
+}
+
 // 32x32 tile (bi, bj) of the n x n row-major matrix M -> XOR-swizzled LDS tile; outside the matrix: the identity
 __device__ __forceinline__ void rlsb_tile_in(float* dst, const float* M, int n, int bi, int bj, int lane) {
 #pragma unroll
@@ -38,12 +60,13 @@ __device__ __forceinline__ void rlsb_tile_in(float* dst, const float* M, int n, 
     }
 }
 // accumulator (row = vrow(reg, half), column = lane & 31) -> tile (bi, bj) of M, inside the matrix only
+template <bool WT = false>
 __device__ __forceinline__ void rlsb_acc_out(const vjf_f32x16& acc, float* M, int n, int bi, int bj, int lane, bool lower_only) {
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = vrow(r, h), gi = bi * 32 + row, gj = bj * 32 + c;
-        if (gi < n && gj < n) M[(size_t)gi * n + gj] = (!lower_only || c <= row) ? acc[r] : 0.f;
+        if (gi < n && gj < n) rlsc_st<WT>(M + (size_t)gi * n + gj, (!lower_only || c <= row) ? acc[r] : 0.f);
     }
 }
 
@@ -56,7 +79,7 @@ __global__ __launch_bounds__(256) void vjf_rlsb_prep_kernel(VjfPlan P, VjfRlsbAr
     const float* G = A.red + P.red_G;
     const float* FDX = A.red + P.red_FDX;
     const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
-    if (gid == 0) A.ok[0] = 1;
+    if (gid == 0) { A.ok[0] = 1; A.ok[4] = 0; }             // (ok[4]: the step counter of vjf_rlsc_loop_kernel)
     for (int e = gid; e < n * dz; e += gsz) A.gbuf[e] = A.gbuf[e] + FDX[e] * inv_v;   // gbuf holds P W (the GEMM before this kernel)
     for (int e = gid; e < n * n; e += gsz) Lm[e] = Pm[e] + G[e] * inv_v;
 }
@@ -77,16 +100,17 @@ __global__ __launch_bounds__(256) void vjf_rlsb_prep_kernel(VjfPlan P, VjfRlsbAr
 // Launch nbl has the inverse role only (the last block row).
 // Operand layout: lane (row, half) of v_mfma_f32_32x32x2_f32 takes k = 8 q + 4 half + e at step (q, e) -- any order of the k
 // indices is a valid product as long as both operands use it -- so a k-contiguous operand row is four 16-byte loads.
+template <bool WT>
 __device__ __forceinline__ void rlsc_ld_kc(float (&v)[16], const float* M, int n, int brow, int bcol, int lane, bool vec) {
     const int row = brow * 32 + (lane & 31), c0 = bcol * 32 + 4 * (lane >> 5);
     if (row < n) {
-        const float* p = M + (size_t)row * n + c0;
+        const size_t o = (size_t)row * n + c0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (vec) { const float4 x = *reinterpret_cast<const float4*>(p + 8 * q); v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+            if (vec) { const float4 x = rlsc_ld4<WT>(M, o + 8 * q); v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
             else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * q + e] = p[8 * q + e];
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = rlsc_ld<WT>(M + o + 8 * q + e);
             }
         }
     } else {
@@ -95,21 +119,31 @@ __device__ __forceinline__ void rlsc_ld_kc(float (&v)[16], const float* M, int n
     }
 }
 // B operand from a row-major (k, column) tile: lane (column, half), same k order
+template <bool WT>
 __device__ __forceinline__ void rlsc_ld_rc(float (&v)[16], const float* M, int n, int brow, int bcol, int lane) {
     const float* p = M + (size_t)(brow * 32 + 4 * (lane >> 5)) * n + bcol * 32 + (lane & 31);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * q + e] = p[(size_t)(8 * q + e) * n];
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = rlsc_ld<WT>(p + (size_t)(8 * q + e) * n);
 }
 
 #define VJF_RLSC_THREADS 512
-__global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_col_kernel(VjfPlan P, VjfRlsbArgs A) {
-    __shared__ __attribute__((aligned(16))) float s_p[4][2][1024];
-    __shared__ __attribute__((aligned(16))) float s_d[1024], s_i[1024], s_t[1024];
-    __shared__ int s_good;
-    if (A.ok[0] == 0) return;
-    const int n = P.n, nbl = (n + 31) / 32, k = A.k, ncol = nbl - k, nahead = ncol > 1 ? ncol - 1 : 0;
+struct VjfRlscLds {
+    float p[4][2][1024];
+    float d[1024], i[1024], t[1024];
+    int good;
+};
+// step k of the sequence for workgroup `bid` (see above); every path ends in a return, no thread of the workgroup is left behind
+// at a barrier
+template <bool WT>
+__device__ __forceinline__ void rlsc_col_step(const VjfPlan& P, const VjfRlsbArgs& A, const int k, const int bid, VjfRlscLds& L) {
+    float (&s_p)[4][2][1024] = L.p;
+    float (&s_d)[1024] = L.d;
+    float (&s_i)[1024] = L.i;
+    float (&s_t)[1024] = L.t;
+    int& s_good = L.good;
+    const int n = P.n, nbl = (n + 31) / 32, ncol = nbl - k, nahead = ncol > 1 ? ncol - 1 : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool vec = (n & 3) == 0;
     float* Lm = A.Lw;
@@ -132,8 +166,8 @@ __global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_col_kernel(VjfPlan 
         }
         __syncthreads();
     };
-    if ((int)blockIdx.x < ncol) {
-        const int i = k + (int)blockIdx.x;
+    if (bid < ncol) {
+        const int i = k + bid;
         const bool below = i != k;
         // the tiles the sums are taken from and the sums launch k - 1 left (this thread's two elements of each), and the operands
         // of the one term formed here, all requested before anything waits
@@ -143,14 +177,14 @@ __global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_col_kernel(VjfPlan 
         for (int q = 0; q < 2; ++q) {
             const int e = tid + 512 * q, row = vrow(e >> 6, (e >> 5) & 1), col = e & 31;
             const int gk = k * 32 + row, gi = i * 32 + row, gj = k * 32 + col;
-            dkk[q] = (gk < n && gj < n) ? Lm[(size_t)gk * n + gj] : (gk == gj ? 1.f : 0.f);
-            aik[q] = (below && gi < n && gj < n) ? Lm[(size_t)gi * n + gj] : 0.f;
-            if (k > 0) { pkk[q] = pc[(size_t)k * 1024 + e]; if (below) pik[q] = pc[(size_t)i * 1024 + e]; }
+            dkk[q] = (gk < n && gj < n) ? rlsc_ld<WT>(Lm + (size_t)gk * n + gj) : (gk == gj ? 1.f : 0.f);
+            aik[q] = (below && gi < n && gj < n) ? rlsc_ld<WT>(Lm + (size_t)gi * n + gj) : 0.f;
+            if (k > 0) { pkk[q] = rlsc_ld<WT>(pc + (size_t)k * 1024 + e); if (below) pik[q] = rlsc_ld<WT>(pc + (size_t)i * 1024 + e); }
         }
         if (k > 0 && wave < 2) {                            // wavefront 0: L_k,k-1 L_k,k-1^T; wavefront 1: L_i,k-1 L_k,k-1^T
             float lk[16], li[16];
-            rlsc_ld_kc(lk, Lm, n, k, k - 1, lane, vec);
-            if (wave == 1 && below) rlsc_ld_kc(li, Lm, n, i, k - 1, lane, vec);
+            rlsc_ld_kc<WT>(lk, Lm, n, k, k - 1, lane, vec);
+            if (wave == 1 && below) rlsc_ld_kc<WT>(li, Lm, n, i, k - 1, lane, vec);
             if (wave == 0) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lk[t], lk[t], acc0, 0, 0, 0);
@@ -176,29 +210,29 @@ __global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_col_kernel(VjfPlan 
             if (lane == 0) s_good = good ? 1 : 0;
         }
         __syncthreads();
-        if (!s_good) { if (!below && tid == 0) A.ok[0] = 0; return; }
+        if (!s_good) { if (!below && tid == 0) __hip_atomic_store(A.ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
         if (!below) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int e = tid + 512 * q, r = e >> 5, c = e & 31;
                 const int gi = k * 32 + r, gj = k * 32 + c;
                 const float x = s_i[vsw(r, c)];
-                if (gi < n && gj < n) A.X[(size_t)gi * n + gj] = x;
-                A.Dinv[(size_t)k * 1024 + e] = x;
-                A.Ld[(size_t)k * 1024 + e] = c <= r ? s_d[vsw(r, c)] : 0.f;
+                if (gi < n && gj < n) rlsc_st<WT>(A.X + (size_t)gi * n + gj, x);
+                rlsc_st<WT>(A.Dinv + (size_t)k * 1024 + e, x);
+                rlsc_st<WT>(A.Ld + (size_t)k * 1024 + e, c <= r ? s_d[vsw(r, c)] : 0.f);
             }
         } else if (wave == 0) {
             vjf_f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
             blk_mma<true>(acc, s_t, s_i, 1.f, lane);               // T L_kk^-T
-            rlsb_acc_out(acc, Lm, n, i, k, lane, false);
+            rlsb_acc_out<WT>(acc, Lm, n, i, k, lane, false);
         }
         return;
     }
-    if ((int)blockIdx.x < ncol + nahead) {
+    if (bid < ncol + nahead) {
         // ahead role: the sums over the finished columns j <= k - 1 for column k + 1, rows i >= k + 1
-        const int c1 = k + 1, i = c1 + ((int)blockIdx.x - ncol);
+        const int c1 = k + 1, i = c1 + (bid - ncol);
         // block columns j = wave, wave + 8, ..: the tiles come from other compute units' launches (memory-side latency), so the
         // operands of FOUR block columns are requested before the first MFMA
         for (int jb = wave; jb < k; jb += 32) {
@@ -206,8 +240,8 @@ __global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_col_kernel(VjfPlan 
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (jb + 8 * u < k) {
-                    rlsc_ld_kc(lk[u], Lm, n, c1, jb + 8 * u, lane, vec);
-                    rlsc_ld_kc(li[u], Lm, n, i, jb + 8 * u, lane, vec);
+                    rlsc_ld_kc<WT>(lk[u], Lm, n, c1, jb + 8 * u, lane, vec);
+                    rlsc_ld_kc<WT>(li[u], Lm, n, i, jb + 8 * u, lane, vec);
                 }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -221,25 +255,25 @@ __global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_col_kernel(VjfPlan 
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = tid + 512 * q;
-            pn[e] = ((s_p[0][0][e] + s_p[1][0][e]) + s_p[2][0][e]) + s_p[3][0][e];
+            rlsc_st<WT>(pn + e, ((s_p[0][0][e] + s_p[1][0][e]) + s_p[2][0][e]) + s_p[3][0][e]);
         }
         return;
     }
     // inverse role
-    const int r = k - 1, j = (int)blockIdx.x - ncol - nahead;
+    const int r = k - 1, j = bid - ncol - nahead;
     if (r < 1 || j >= r) return;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = tid + 512 * q;
-        s_i[vsw(e >> 5, e & 31)] = A.Dinv[(size_t)r * 1024 + e];
+        s_i[vsw(e >> 5, e & 31)] = rlsc_ld<WT>(A.Dinv + (size_t)r * 1024 + e);
     }
     for (int mb = j + wave; mb < r; mb += 32) {
         float a[4][16], b[4][16];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (mb + 8 * u < r) {
-                rlsc_ld_kc(a[u], Lm, n, r, mb + 8 * u, lane, vec);
-                rlsc_ld_rc(b[u], A.X, n, mb + 8 * u, j, lane);
+                rlsc_ld_kc<WT>(a[u], Lm, n, r, mb + 8 * u, lane, vec);
+                rlsc_ld_rc<WT>(b[u], A.X, n, mb + 8 * u, j, lane);
             }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -260,7 +294,50 @@ __global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_col_kernel(VjfPlan 
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
         blk_mma<false>(acc, s_i, s_t, -1.f, lane);                 // -L_rr^-1 S
-        rlsb_acc_out(acc, A.X, n, r, j, lane, false);
+        rlsb_acc_out<WT>(acc, A.X, n, r, j, lane, false);
+    }
+}
+
+__global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_col_kernel(VjfPlan P, VjfRlsbArgs A) {
+    __shared__ __attribute__((aligned(16))) VjfRlscLds L;
+    if (A.ok[0] == 0) return;
+    rlsc_col_step<false>(P, A, A.k, (int)blockIdx.x, L);
+}
+
+// The whole sequence k = 0 .. nbl as ONE launch of 2 nbl - 1 workgroups (the widest step's count) that stay resident: between two
+// steps every workgroup drains its write-through stores, counts itself in at a word in memory and waits for all the others; what
+// it reads of the others' results it reads with sc1 loads (see rlsc_ld).  [Fences instead -- a release and an acquire at agent
+// scope per step, i.e. a writeback and an invalidate of the XCD's L2 by every wavefront -- cost 12 us a step: measured, dropped.]  A sequence of short launches of few workgroups, each waiting
+// for the one before it, is at the mercy of whatever else the chip runs: beside the trial chain's chip-filling kernels on another
+// stream (filter_seq_two) every one of them waited for compute units to come free (config E: the update took 770 us beside the
+// trial chain, 330 us alone).  Resident workgroups are placed once.  The grid fits the chip many times over (63 workgroups at
+// n = 1000) and nothing that is launched before it waits for it, so the workgroups that are placed later than others are placed.
+// A failed pivot: every column workgroup finds it (each factors the block itself), one of them clears A.ok before the step's
+// barrier, and all workgroups leave behind that barrier.  bar: a word the launch before this one (vjf_rlsb_prep_kernel) zeroed.
+__global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_loop_kernel(VjfPlan P, VjfRlsbArgs A, unsigned* bar) {
+    __shared__ __attribute__((aligned(16))) VjfRlscLds L;
+    __shared__ int s_go;
+    if (A.ok[0] == 0) return;
+    const int nbl = (P.n + 31) / 32, tid = threadIdx.x;
+    for (int k = 0; k <= nbl; ++k) {
+        rlsc_col_step<true>(P, A, k, (int)blockIdx.x, L);
+        if (k == nbl) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (every thread: its write-through stores are in memory)
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)(k + 1) * gridDim.x;
+            bool there = false;
+            for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
+                if ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { there = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_go = there ? 1 : 0;
+        }
+        __syncthreads();
+        // (a wait that ran out: a workgroup of this launch was never placed -- the update is dropped like one with a failed pivot)
+        if (!s_go) { if (tid == 0) __hip_atomic_store(A.ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        if (__hip_atomic_load(A.ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     }
 }
 
