@@ -295,6 +295,7 @@ struct vjf_ctx {
     unsigned k1_count;     // workgroups of the matrix-core trial kernel (whole step or backward half) launched so far
     unsigned post_count;   // workgroups of the post kernel launched so far
     unsigned fwd_count;    // workgroups of forward halves launched with a completion count
+    unsigned stats_count;  // steps whose RLS statistics the three-stream route has launched (host mirror of flag word kStatsWord)
     unsigned start_count;  // host mirror of the post kernel's "workgroups started" count
     void* comm_a; void* comm_b;   // RCCL communicators of the two chains of the three-stream route (null: single rank)
     int world;
@@ -390,7 +391,7 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->start_count = 0; c->mega_launches = 0;
     c->stream2 = c->stream3 = nullptr; c->ev_s = c->ev_c = nullptr;
     for (int i = 0; i < 2; ++i) c->ev_f[i] = c->ev_r[i] = c->ev_b[i] = c->ev_g[i] = nullptr;
-    c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0;
+    c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0; c->stats_count = 0;
     c->comm_a = c->comm_b = nullptr; c->world = 1; c->fake_world = 1;
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
@@ -600,6 +601,7 @@ struct DeviceGuard {
 };
 
 constexpr int kReplayMaskWord = 56, kReplayRhoWord = 57;   // words of the flag block no hand-off uses
+constexpr int kStatsWord = 58;                            // three-stream route: RLS statistics (summed over ranks) of how many steps are in memory
 constexpr unsigned kScAll = (1u << RS_N) - 1u;
 constexpr unsigned kScRls = 1u << RS_SDX2;                 // the one loss sum the RLS chain reads
 
@@ -736,7 +738,8 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
 }
 
 // Gram tiles of jobs [job0, job0 + njobs) and their slab reduction into `red`
-int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, int gen = 0, const unsigned* run_if = nullptr) {
+int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float* red, hipStream_t st, int gen = 0, const unsigned* run_if = nullptr,
+                unsigned* done_count = nullptr) {   // done_count: see VjfReduceArgs (njobs + (sc_mask ? 1 : 0) arrivals)
     const VjfPlan& P = c->plan;
     const int nsplit = split_for(B);
     VjfGramArgs g{};
@@ -751,6 +754,7 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
     VjfReduceArgs r{};
     r.jobs = g.jobs; r.slabs = g.slabs; r.partial = (const float*)(c->ws + (gen ? c->cv.partial2 : c->cv.partial)); r.red = red;
     r.njobs = njobs; r.nsplit = nsplit; r.nblocks_k1 = trial_blocks(c, B); r.job0 = job0; r.sc_mask = sc_mask; r.run_if = run_if;
+    r.done_count = done_count;
     hipLaunchKernelGGL(vjf_gram_reduce_kernel, dim3(njobs + (sc_mask ? 1 : 0)), dim3(VJF_REDUCE_THREADS), 0, st, P, r);
     VJF_HIP(hipGetLastError());
     return 0;
@@ -759,7 +763,8 @@ int launch_gram(vjf_ctx* c, int B, int job0, int njobs, unsigned sc_mask, float*
 // which: 0 whole prep grid, 1 RLS operand rows only, 2 SGD + scalars only
 int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const float* red, int which, hipStream_t st,
                 const unsigned* run_word = nullptr, unsigned run_epoch = 0, const unsigned* start_count = nullptr, unsigned start_target = 0,
-                int replay = 0) {                               // replay: 1 first pass with a replay behind it, 2 the pass behind the replay
+                int replay = 0,                                 // replay: 1 first pass with a replay behind it, 2 the pass behind the replay
+                const unsigned* wait_count = nullptr, unsigned wait_target = 0) {   // the operand kernel waits in-kernel for *wait_count
     const VjfPlan& P = c->plan;
     VjfPrepArgs p{};
     p.state = c->state; p.red = red; p.gbuf = (float*)(c->ws + c->cv.work);
@@ -768,6 +773,7 @@ int launch_prep(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags, const
     p.n_rowblk = (P.n + VJF_PREP_ROWS - 1) / VJF_PREP_ROWS;
     p.n_sgdblk = (P.train_len + 1023) / 1024;
     p.run_word = run_word; p.run_epoch = run_epoch; p.start_count = start_count; p.start_target = start_target;
+    p.wait_count = wait_count; p.wait_target = wait_target;
     if (replay) {
         p.replay_mask = (unsigned*)(c->ws + c->cv.flags) + kReplayMaskWord; p.replay_rho = (float*)(c->ws + c->cv.flags) + kReplayRhoWord;
         p.replay_pass = replay == 2 ? 1 : 0;
@@ -1012,7 +1018,7 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     if (rc) return rc;
     const VjfPlan& P = c->plan;
     const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
-    hipStream_t sa = c->stream, sb = c->stream2;
+    hipStream_t sa = c->stream, sb = c->stream2, sc = c->stream3;
     float* redg = (float*)(c->ws + c->cv.red);                             // gradients + loss sums (chain A)
     float* rede[2] = {(float*)(c->ws + c->cv.red2), (float*)(c->ws + c->cv.red3)};   // RLS statistics of even / odd steps (chain B)
     const int fw = c->fake_world;
@@ -1041,8 +1047,8 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
         VJF_NCCL(nccl().all_reduce(tok, tok, 1, kNcclFloat, kNcclSum, c->comm_a, sa));
         VJF_HIP(hipStreamSynchronize(sa));
         if (c->comm_b) {
-            VJF_NCCL(nccl().all_reduce(tok + 1, tok + 1, 1, kNcclFloat, kNcclSum, c->comm_b, sb));
-            VJF_HIP(hipStreamSynchronize(sb));
+            VJF_NCCL(nccl().all_reduce(tok + 1, tok + 1, 1, kNcclFloat, kNcclSum, c->comm_b, sc));   // (comm_b lives on sc)
+            VJF_HIP(hipStreamSynchronize(sc));
         }
     }
     rc = refresh_aux(c);
@@ -1054,12 +1060,19 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     float* stw = c->state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     if ((rc = launch_trial(c, args(0), 1, sa, true))) return rc;          // prologue: forward half of step 0
     for (int t = 0; t < T; ++t) {
-        const unsigned post_before = c->post_count;                      // workgroups of the RLS updates of steps 0 .. t-1
         // sb: RLS statistics of step t as soon as its forward half is done (a one-wavefront gate on the workgroup count: no
         //     cross-stream event inside the loop), then -- behind W, sigma of t-1 -- P += G/v, g, and the RLS update
-        hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, (const unsigned*)fdone, c->fwd_count, stw);
-        if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sb, t & 1))) return rc;
-        if ((rc = all_reduce(rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), c->comm_b, sb))) return rc;   // [G | FDX | sums]
+        // sc: the statistics have a stream of their own -- they need the forward half of step t only, and sb is still inside the
+        //     update of step t-1 when that is done (behind it they cost the chain sb a sixth of its step: 15 of 96 us)
+        hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sc, (const unsigned*)fdone, c->fwd_count, stw);
+        // (the operand kernel of sb waits in-kernel for the statistics -- a cross-stream event costs 6-13 us on this stack: for the
+        //  reduction's own workgroups on a single rank, for one more launch behind the sum over ranks otherwise)
+        if ((rc = launch_gram(c, B, 0, ne, kScRls, rede[t & 1], sc, t & 1, nullptr, c->comm_b ? nullptr : fl + kStatsWord))) return rc;
+        if (c->comm_b) {
+            if ((rc = all_reduce(rede[t & 1] + P.red_G, (size_t)(P.red_len - P.red_G), c->comm_b, sc))) return rc;   // [G | FDX | sums]
+            hipLaunchKernelGGL(vjf_count_kernel, dim3(1), dim3(64), 0, sc, fl + kStatsWord);
+            ++c->stats_count;
+        } else c->stats_count += (unsigned)(ne + 1);
         // sa: backward half(t) waits in-kernel for the RLS update of step t-1, behind the reloads of its forward half's rows
         if ((rc = launch_trial(c, args(t), 2, sa, false, t > 0 ? pdone : nullptr, c->post_count))) return rc;
         if (t == 0) {
@@ -1069,8 +1082,8 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
             hipLaunchKernelGGL(vjf_triclean_done_kernel, dim3(1), dim3(1), 0, sa, P, c->state);
             VJF_HIP(hipGetLastError());
         }
-        if (t > 0) hipLaunchKernelGGL(vjf_gate_kernel, dim3(1), dim3(64), 0, sb, pdone, post_before, stw);
-        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb))) return rc;
+        // (P += G/v and g behind W, sigma of step t-1: the update of t-1 precedes them in sb)
+        if ((rc = launch_prep(c, Bt, nullptr, flags, rede[t & 1], 1, sb, nullptr, 0, nullptr, 0, 0, fl + kStatsWord, c->stats_count))) return rc;
         if (exact) c->k1_count += (unsigned)trial_blocks(c, B);           // (the replayed backward half of this step reads W, w_chol, sigma too)
         if ((rc = launch_rls(c, Bt, flags, rede[t & 1], sb, true, nullptr, true))) return rc;
         if ((rc = launch_gram(c, B, ne, ng, kScAll & ~kScRls, redg, sa, t & 1))) return rc;

@@ -97,6 +97,8 @@ struct VjfReduceArgs {
     int job0;                 // first job of this launch; njobs = jobs in this launch
     unsigned sc_mask;         // which of K1's loss sums the extra workgroup reduces (bit per RS_* index)
     const unsigned* run_if;   // non-null: nothing is done when the word is 0
+    unsigned* done_count;     // non-null: the sums leave as write-through stores and every workgroup counts itself in here once its own
+                              // are in memory -- a kernel on another stream waits for the count in-kernel (three-stream route)
 };
 
 // grid = njobs + 1 workgroups of 1024 threads (one tile element each: all of a thread's slab loads are in flight at once);
@@ -105,6 +107,14 @@ struct VjfReduceArgs {
 __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(VjfPlan P, VjfReduceArgs A) {
     const int tid = threadIdx.x;
     if (A.run_if && __hip_atomic_load(A.run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    const bool wt = A.done_count != nullptr;
+    auto put = [&](float* p, float v) { if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
+    auto arrive = [&]() {
+        if (!wt) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(A.done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     if ((int)blockIdx.x == A.njobs) {
         // RS_N scalars; 32 threads per scalar accumulate strided partials in double, then a fixed xor tree over the 32
         const int sc = (tid >> 5) & 7, l = tid & 31;
@@ -120,8 +130,9 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
             }
             for (; b < A.nblocks_k1; b += 32) v += (double)A.partial[(size_t)b * RS_N + sc];
             v = vjf_sum32(v);
-            if (l == 0 && ((A.sc_mask >> sc) & 1u)) A.red[(sc < RS_SDX2 ? P.red_SCA : P.red_SC) + sc] = (float)v;   // (loss sums behind the gradients)
+            if (l == 0 && ((A.sc_mask >> sc) & 1u)) put(A.red + (sc < RS_SDX2 ? P.red_SCA : P.red_SC) + sc, (float)v);   // (loss sums behind the gradients)
         }
+        arrive();
         return;
     }
     const VjfJob job = A.jobs[A.job0 + blockIdx.x];
@@ -149,13 +160,14 @@ __global__ __launch_bounds__(VJF_REDUCE_THREADS) void vjf_gram_reduce_kernel(Vjf
         if (job.kind == 0) {
             const int gr = job.ti * VJF_TILE + i, gc = job.tj * VJF_TILE + j;   // gr: X column, gc: Y column of E
             if (gr < P.n) {
-                if (gc < P.n && gc <= gr) { A.red[P.red_G + (size_t)gr * P.n + gc] = v; A.red[P.red_G + (size_t)gc * P.n + gr] = v; }
+                if (gc < P.n && gc <= gr) { put(A.red + P.red_G + (size_t)gr * P.n + gc, v); put(A.red + P.red_G + (size_t)gc * P.n + gr, v); }
             } else if (gr < P.n + P.dz && gc < P.n) {
-                A.red[P.red_FDX + (size_t)gc * P.dz + (gr - P.n)] = v;
+                put(A.red + P.red_FDX + (size_t)gc * P.dz + (gr - P.n), v);
             }
         } else {
-            if (j < job.ncol_w) A.red[job.dst + (size_t)i * job.ld + j] = v;
-            else if (j == job.ncol_w && job.dst_b >= 0) A.red[job.dst_b + i] = v;
+            if (j < job.ncol_w) put(A.red + job.dst + (size_t)i * job.ld + j, v);
+            else if (j == job.ncol_w && job.dst_b >= 0) put(A.red + job.dst_b + i, v);
         }
     }
+    arrive();
 }

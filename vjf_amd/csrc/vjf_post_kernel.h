@@ -658,6 +658,11 @@ __global__ __launch_bounds__(64) void vjf_gate_kernel(const unsigned* count, uns
     vjf_status_or(status, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
 }
 
+// The other half of such a hand-off: one more arrival at `count`, behind everything its stream has run so far (a kernel of its own,
+// so the results of the kernels before it are in memory: a kernel's end writes them back)
+__global__ __launch_bounds__(64) void vjf_count_kernel(unsigned* count) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct VjfResidArgs {
     float* state;
