@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--no-elbo-check", action="store_true")
     ap.add_argument("--elbo-steps", type=int, default=10)
     ap.add_argument("--no-overlap", action="store_true", help="A/B: the per-step kernels in the one-stream order")
+    ap.add_argument("--no-call-cost", action="store_true", help="skip the fixed-cost-of-a-call measurement behind the timed regions (profiler runs)")
     ap.add_argument("--streams-route", action="store_true", help="A/B: the per-step three-stream route instead of the one-launch route")
     ap.add_argument("--config", default="B", choices=sorted(CFGS),
                     help="B: the headline workload (BASELINE configs[1]); A / C / E: configs[0] / [2] / [4], extra lines, not the headline")
@@ -215,8 +216,9 @@ def main():
         model.set_overlap(False)
     if a.streams_route:
         model.set_overlap(3)
-    y = synth_data(c, T, 1234 + rank, dev, a.config)            # each rank filters its own trials
-    eps = torch.randn(T, 2, c["B"], c["dz"], device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + rank))
+    Td = max(T, 100) if a.config == "B" else T                  # (the call-cost measurement behind the timed regions takes 100 steps)
+    y = synth_data(c, Td, 1234 + rank, dev, a.config)           # each rank filters its own trials
+    eps = torch.randn(Td, 2, c["B"], c["dz"], device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + rank))
 
     def barrier():
         torch.cuda.synchronize()
@@ -310,7 +312,7 @@ def main():
         try:                                                    # HBM-side bytes per step from the committed PMC passes of this build
             if a.config != "B" or world != 1 or a.no_overlap or a.streams_route or a.force_dist:
                 raise LookupError("the committed PMC passes are of the headline configuration on the one-launch route")
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
             traffic, traffic_note = float(tj["bytes_per_step_corrected"]), tj.get("note")
         except Exception:
             pass
@@ -318,18 +320,18 @@ def main():
         try:                                                    # the committed rocprofv3 --kernel-trace --stats summary of this build
             import csv
             if a.config == "E":                                 # (tools/profile_configE.sh: every kernel of the per-step route)
-                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_configE_kernel_stats.csv"))))
+                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_configE_kernel_stats.csv"))))
                 nst = 23
-                kstats = {"file": "profiles/r02_configE_kernel_stats.csv",
+                kstats = {"file": "profiles/r03_configE_kernel_stats.csv",
                           "command": "rocprofv3 --kernel-trace --stats -- python bench.py --config E --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-elbo-check",
                           "steps_in_profile": nst,
                           "kernels": [{"name": r_["Name"].split("(")[0].replace("void ", ""), "calls": int(r_["Calls"]), "avg_us": float(r_["AverageNs"]) / 1e3,
                                        "us_per_step": float(r_["TotalDurationNs"]) / 1e3 / nst} for r_ in rows if "vjf_" in r_["Name"]]}
             elif a.config == "B":
-                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv"))))
-                meta = json.load(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_meta.json")))
+                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_kernel_stats.csv"))))
+                meta = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_stats_meta.json")))
                 nst = meta.get("steps_in_all_launches")
-                kstats = {"file": "profiles/r02_kernel_stats.csv", "command": meta.get("command"), "steps_per_launch": meta.get("steps_per_launch"),
+                kstats = {"file": "profiles/r03_kernel_stats.csv", "command": meta.get("command"), "steps_per_launch": meta.get("steps_per_launch"),
                           "note": meta.get("note"), "mega_launches_us": meta.get("mega_launches_us"),
                           "kernels": [{"name": r_["Name"].split("(")[0].replace("void ", ""), "calls": int(r_["Calls"]), "avg_us": float(r_["AverageNs"]) / 1e3,
                                        "max_us": float(r_["MaxNs"]) / 1e3,
@@ -339,6 +341,36 @@ def main():
             pass
         one_launch = world == 1 and not a.no_overlap and not a.streams_route and not a.force_dist and model.route() == "one-launch"
         spl = K if one_launch else 1
+        # the fixed cost of a call (one-launch route: host shim + launch + filling and draining the roles' pipeline + the wake-up of
+        # the synchronising host), measured BEHIND the timed regions: synchronised calls of 20 and of 100 steps -- the slope is the
+        # steady step, the intercept the fixed cost -- and single `filter` calls, each followed by a synchronisation
+        call_cost = None
+        if one_launch and a.config == "B" and y.shape[0] >= 100 and not a.no_call_cost:
+            def timed_calls(nst, reps):
+                ts = []
+                qq = q
+                for _ in range(reps):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    m_, l_, _ = model.filter_sequence(y[:nst], qs=qq, eps=eps[:nst])
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                    qq = vjf_amd.Gaussian(m_[-1], l_[-1])
+                return float(np.median(ts))
+            timed_calls(20, 2)
+            t20, t100 = timed_calls(20, 7), timed_calls(100, 5)
+            steady = (t100 - t20) / 80.0
+            ts, qq = [], q
+            for i in range(24):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                qq, _ = model.filter(y[i], None, qq, eps=(eps[i, 0], eps[i, 1]))
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            call_cost = {"fixed_us_per_call": (t20 - 20.0 * steady) * 1e6, "steady_us_per_step": steady * 1e6,
+                         "call_20_steps_us": t20 * 1e6, "call_100_steps_us": t100 * 1e6,
+                         "single_filter_call_us": float(np.median(ts[4:])) * 1e6,
+                         "note": "wall clock, host synchronised before and after every call; medians of 7 / 5 / 20 calls behind the timed regions"}
         out = {
             "metric": "trial-timesteps/sec", "value": value, "unit": "trial-timesteps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": wall_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -348,11 +380,11 @@ def main():
                                     + (", one Lorenz trial" if a.config == "A" else "")),
                        "global_batch": c["B"] * world, "trials_per_gpu": c["B"], "parallelism": f"trial-shard x{world}"},
             "repeats": R, "ms_per_step_repeats": [w / K * 1e3 for w in walls], "ms_per_step_median": float(np.median(walls)) / K * 1e3,
-            "elbo": elbos[0], "elbo_check": elbo_check, "status_bits": status,
+            "elbo": elbos[0], "elbo_check": elbo_check, "status_bits": status, "call_cost": call_cost,
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": None if traffic is None else traffic * spl, "traffic_note": traffic_note,
-                         "kernel": ("vjf_mega_kernel: ONE cooperative launch carries the K timed steps (the trial, Gram, operand, SGD and RLS "
-                                    "roles are workgroups of one resident grid); a launch processes K x trials trial-timesteps; its duration "
+                         "kernel": ("vjf_mega_kernel: ONE launch carries the K timed steps (the trial, Gram, operand, SGD and RLS "
+                                    "roles are workgroups of one grid that is resident as a whole); a launch processes K x trials trial-timesteps; its duration "
                                     "is measured with HIP events on its stream around the timed region" if one_launch else
                                     "one filter step = the per-step kernels of the route in use (HIP events around the timed region / steps)"),
                          "launch_us": dev_s * 1e6 if one_launch else step_s * 1e6, "steps_per_launch": spl,

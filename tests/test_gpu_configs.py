@@ -281,3 +281,6 @@ def test_bench_line_contract(config):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] == os.cpu_count() and 1 <= c["blas_threads"] <= c["cores"] and c["sample"]
     assert d["elbo_check"]["ok"] and d["status_bits"] == 0
+    if config == "B":                                          # the fixed cost of a call, measured behind the timed regions
+        cc = d["call_cost"]
+        assert 0.0 < cc["fixed_us_per_call"] < 400.0 and 0.0 < cc["single_filter_call_us"] < 600.0 and 20.0 < cc["steady_us_per_step"] < 200.0

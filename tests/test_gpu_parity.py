@@ -387,9 +387,10 @@ def test_nonfinite_component_is_dropped_like_the_reference(vjf, which, route):
 
 
 def test_refused_cooperative_launch_falls_back_to_per_step_kernels(vjf, monkeypatch):
-    """When the runtime refuses the cooperative launch (the grid cannot be resident as a whole: compute units masked off or held
-    by another process; injected here) the context leaves the one-launch route and the same call goes on with the per-step
-    kernels: same results to summation order, status clean."""
+    """When the library's residency check refuses the one-launch grid (it cannot be resident as a whole: the occupancy query times
+    the compute units is less than the grid; injected here -- the name is from round 2, when the launch was a cooperative one and
+    the runtime refused) the context leaves the one-launch route and the same call goes on with the per-step kernels: same results
+    to summation order, status clean."""
     g = torch.Generator().manual_seed(15)
     y, eps = torch.randn(6, 96, 10, generator=g), torch.randn(6, 2, 96, 3, generator=g)
     torch.manual_seed(14)

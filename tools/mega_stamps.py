@@ -8,8 +8,9 @@ torch.manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 cfgC = os.environ.get("CFG", "B") == "C"                   # CFG=C: BASELINE configs[2] (Poisson, d_y = 200)
-dz, dy, n = (10, 200, 200) if cfgC else (10, 50, 200)
-m = vjf_amd.VJF.make_model(dy, dz, 0, n, [128], likelihood="poisson" if cfgC else "gaussian", noise="device")
+cfgA = os.environ.get("CFG", "B") == "A"                   # CFG=A: BASELINE configs[0] (one trial, d_z = 3, RBF(100), hidden [20]): pass B = 1
+dz, dy, n = (10, 200, 200) if cfgC else (3, 10, 100) if cfgA else (10, 50, 200)
+m = vjf_amd.VJF.make_model(dy, dz, 0, n, [20] if cfgA else [128], likelihood="poisson" if cfgC else "gaussian", noise="device")
 y = torch.poisson(torch.rand(T + 8, B, dy, device="cuda")) if cfgC else torch.randn(T + 8, B, dy, device="cuda")
 m.filter_sequence(y[:8])
 N.check(m._backend().vjf_debug_stamps(m._ctx, 2, None))

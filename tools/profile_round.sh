@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round profile of the benchmarked command (run on the GPU box from the repo root):  tools/profile_round.sh r02
+# Round profile of the benchmarked command (run on the GPU box from the repo root):  tools/profile_round.sh r03
 #   1. bench.py (default flags)                                        -> gpurun_out/<tag>_bench.json
 #   2. rocprofv3 --kernel-trace --stats of the same workload           -> gpurun_out/<tag>_kernel_stats.csv (+ _meta.json)
 #   3. rocprofv3 --pmc, one counter set per pass, --kernel-trace only  -> gpurun_out/<tag>_pmc_traffic.json, <tag>_pmc_sq.json
@@ -7,7 +7,7 @@
 # The program itself follows `--` (no env / bash -c hop under the profiler).
 set -o pipefail
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 K=${2:-200}
 W=20
 O=gpurun_out
@@ -15,8 +15,12 @@ mkdir -p $O
 timeout -k 10 400 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || { echo "bench failed"; tail -5 $O/${TAG}_bench.err; exit 1; }
 echo "bench: $(python -c "import json;d=json.load(open('$O/${TAG}_bench.json'));print(d['value'], d['ms_per_step'], d['ms_per_step_repeats'], d['elbo_check'])")"
 rm -rf $O/${TAG}_stats
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python bench.py --steps $K --warmup $W --repeats 1 --no-cpu-baseline --no-elbo-check > $O/${TAG}_stats.json 2> $O/${TAG}_stats.err
-echo "stats exit $? (the profiled process may fault in its exit handlers after the output files are written)"
+# (every profiled run must END cleanly: round 2's runs died in the HIP runtime's exit handler -- the cooperative queue's teardown behind
+#  the profiler's finalisation, DESIGN.md section 6 -- and this script went on regardless; the launch is a plain one now)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python bench.py --steps $K --warmup $W --repeats 1 --no-cpu-baseline --no-elbo-check --no-call-cost > $O/${TAG}_stats.json 2> $O/${TAG}_stats.err
+rc=$?
+echo "stats exit $rc"
+[ $rc -eq 0 ] || { echo "the profiled run did not exit cleanly"; tail -5 $O/${TAG}_stats.err; exit 1; }
 f=$(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1)
 [ -s "$f" ] || { echo "stats failed"; tail -5 $O/${TAG}_stats.err; exit 1; }
 cp "$f" $O/${TAG}_kernel_stats.csv
@@ -28,7 +32,7 @@ if tr:
     for r in csv.DictReader(open(tr[0])):
         if "vjf_mega_kernel" in r["Kernel_Name"]:
             launches.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-json.dump({"mega_launches_us": launches, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps $K --warmup $W --repeats 1 --no-cpu-baseline --no-elbo-check",
+json.dump({"mega_launches_us": launches, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps $K --warmup $W --repeats 1 --no-cpu-baseline --no-elbo-check --no-call-cost",
            "steps_per_launch": $K, "steps_in_all_launches": $K + $W,
            "note": "vjf_mega_kernel: the warm-up steps ($W, in two launches) and ONE launch of the $K timed steps (= MaxNs); AverageNs is over all three launches, TotalDurationNs / ($K + $W) is the time per step",
            "bench_line": json.load(open("$O/${TAG}_stats.json"))}, open("$O/${TAG}_kernel_stats_meta.json", "w"), indent=1)
@@ -36,8 +40,10 @@ PY
 for set in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
   n=$(echo $set | tr ' ' '_')
   rm -rf $O/${TAG}_pmc_$n
-  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/${TAG}_pmc_$n -- python bench.py --steps $K --warmup $W --repeats 1 --no-cpu-baseline --no-elbo-check > $O/${TAG}_pmc_$n.json 2> $O/${TAG}_pmc_$n.err
-  echo "pmc $set exit $?"
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/${TAG}_pmc_$n -- python bench.py --steps $K --warmup $W --repeats 1 --no-cpu-baseline --no-elbo-check --no-call-cost > $O/${TAG}_pmc_$n.json 2> $O/${TAG}_pmc_$n.err
+  rc=$?
+  echo "pmc $set exit $rc"
+  [ $rc -eq 0 ] || { echo "the counter pass '$set' did not exit cleanly"; tail -5 $O/${TAG}_pmc_$n.err; exit 1; }
 done
 python - <<PY
 import csv, glob, json, collections

@@ -198,6 +198,10 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
     if (m->n_sgd > left - g2) m->n_sgd = left - g2;
     if (m->n_sgd < 1) m->n_sgd = 1;
     m->n_gram = (B + 63) / 64;
+    // (at least one Gram workgroup per lower tile of Phi^T Phi, rows or not: the slab sum deals its quads over the role's
+    //  workgroups, two per thread and ROUND TRIP -- one workgroup alone took ten of them for the ten tiles of RBF(100), and at
+    //  one trial that loop, 35 us, was the step; compute units are idle at such batch sizes)
+    { const int ntri = nbl * (nbl + 1) / 2; if (m->n_gram < ntri) m->n_gram = ntri; }
     if (m->n_gram > left - m->n_sgd) m->n_gram = left - m->n_sgd;
     if (m->n_gram > kMegaMaxGramWg) m->n_gram = kMegaMaxGramWg;
     if (m->n_gram < 1) m->n_gram = 1;

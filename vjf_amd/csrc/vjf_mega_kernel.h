@@ -846,6 +846,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     }
                 }
             }
+            // (a look at the RLS hand-off of the previous step by one lane in front of this barrier, where the other wavefronts are
+            //  still storing their slab tiles: see fuse_fwd)
+            if (tid == 0 && first && last && !replay && !rls_in)
+                s_wg[15] = ((int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0) ? 1.f : 0.f;
             __syncthreads(); MG_PHASE();
             if (tid == 0 && !replay) {
                 float v = 0.f;
@@ -854,10 +858,13 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 if (last) mg_st(early + (size_t)16 * ldn + RS_SDX2, s_wg[RS_SDX2]);
             }
             if (first) VJF_MG_STAMP(26);
-            // (one tile per workgroup and the RLS update of the previous step still to be taken in: the early slab's write-through
-            //  stores are not drained here -- their acknowledgements travel beside the round trips of that hand-off, below, and the
-            //  count follows there)
-            const bool fuse_fwd = first && last && !replay && !rls_in;
+            // One tile per workgroup and the RLS update of the previous step still to be taken in, but there by now (config B: it
+            // lands ~5 us before this point): the early slab's write-through stores are not drained here -- their acknowledgements
+            // travel beside the round trips of that hand-off, below, and the "forward done" count follows there (one drain, one
+            // barrier less).  If it is NOT there yet (configs whose RLS loop alone bounds the step, e.g. one trial against RBF(100):
+            // the wait below lasts ~10 us) the count goes out now -- the Gram role's sums of the next step, and with them the next
+            // factorisation, wait for it (measured at configs[0]: 35.2 us a step with the count behind the wait, 30.0 before it).
+            const bool fuse_fwd = first && last && !replay && !rls_in && s_wg[15] != 0.f;
             if (last && !replay && !fuse_fwd) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
             if (first) VJF_MG_STAMP(4);
             if (last) { VJF_MG_STAMPX(28, -1); VJF_MG_STAMPW(1); }
