@@ -572,6 +572,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     s_try[0] = (there ? 1u : 0u) | (rls ? 2u : 0u);
                     s_try[1] = mw;
                     if (!there) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
+                    vjf_s_abort_word = (!there || vjf_abort_seen(SCW + VJF_SC_STATUS)) ? 1 : 0;   // (one verdict for the workgroup: vjf_abort_wg)
                 }
                 __syncthreads(); MG_PHASE();
                 rls_now = (s_try[0] & 2u) != 0u;
@@ -671,14 +672,14 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 if (t == 0) {                                                 // (the row-major copy of L^-1 of this launch: the inverse loops' first act)
                     if (!vjf_wg_wait_sc1(cnt + MG_C_XT, (unsigned)(A.n_rls - 2), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                         vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
-                    if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+                    if (vjf_abort_wg()) return;
                 }
             }
             // ---- theta of the previous step.  Nothing above depends on it: the inputs and the features of a step are ready before the
             //      parameters are
             if (first && !replay) {
                 gate();
-                if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+                if (t > 0 && vjf_abort_wg()) return;
                 if (want_replay) break;                                        // (uniform: every thread read the same word)
                 if (t > 0 && !tl) {
                     mg_warm(A.aux, P.aux_len, wg, tid);                        // (see mg_warm)
@@ -697,7 +698,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (first && tl && !replay && t == 0) {                            // (the image of this launch: the SGD role's first act)
                 if (!vjf_wg_wait_sc1(cnt + MG_C_IMG, (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
-                if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+                if (vjf_abort_wg()) return;
             }
             if (first && tl && !replay) {                                      // (a replayed pass: they are in LDS, untouched since its step)
                 // the parameters of this step into LDS: the image the SGD role keeps has the layout of the region, so this is a flat
@@ -874,7 +875,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (first && !rls_in) {
                 if (!vjf_wg_wait_sc1(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
-                if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+                if (vjf_abort_wg()) return;
                 // (sigma and the triangle flag first, then this workgroup's share of the L2 warm-up with its loads left in flight: the
                 //  variance tiles' own operand loads go out behind them instead of waiting a round trip for them)
                 sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
@@ -1142,7 +1143,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (!(tl ? vjf_wg_wait_sc1(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u)
                      : vjf_wg_wait(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS)))
                 vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
-            if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+            if (vjf_abort_wg()) return;
             replay = false; replayed = true; rbits = 0;
             continue;
         }
@@ -1200,7 +1201,7 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (e > 0 && !vjf_wg_wait_sc1(A.cnt + MG_C_FWD, (unsigned)e * (unsigned)A.n_trial, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
-        if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+        if (e > 0 && vjf_abort_wg()) return;
         { const int wg = hg, t = e; VJF_MG_STAMP(11); }
         vjf_f32x16 acc[VJF_MG_MAXQ];
 #pragma unroll
@@ -1304,7 +1305,7 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
 #endif
         if (!vjf_wg_wait_sc1(A.cnt + MG_C_GRAM, (unsigned)(e + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
             vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
-        if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+        if (vjf_abort_wg()) return;
         // this workgroup's share of the sum over the slabs: a quad of elements per 4 lanes, lane p sums the slabs [p npq, (p+1) npq)
         // (all of them in flight -- for TWO quads at a time: one round trip for the whole share at config B), then
         // (s0 + s1) + (s2 + s3): a fixed order
@@ -1398,8 +1399,9 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
         ok = vjf_wg_wait_sc1(A.cnt + MG_C_STAT, (unsigned)(t + 1) * (unsigned)A.n_gram, tid, SCW + VJF_SC_STATUS) && ok;
         if (t > 0) ok = vjf_wg_wait_sc1(A.cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS) && ok;
         ok = vjf_wg_wait_sc1(runw, (unsigned)(t + 1), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) && ok;      // the Cholesky loop holds its operands (it reads the state's P at step 0)
-        if (!ok) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_OPERAND);
-        if (vjf_abort_seen(SCW + VJF_SC_STATUS)) return;
+        if (tid == 0 && !ok) { vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_OPERAND); vjf_s_abort_word = 1; }
+        __syncthreads();                                                       // (the verdict of lane 0, for every thread alike)
+        if (vjf_abort_wg()) return;
         { const int wg = pw; VJF_MG_STAMP(14); }
         // Phi^T dx rows i0 .. i0 + 15 (16 columns x 4 quads of features: the early slabs hold it transposed): 8 lanes per quad, lane p
         // sums the early slabs [p npq, (p+1) npq) (all in flight), then a fixed xor tree
@@ -1578,7 +1580,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
                 vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
             grad_ok = true;
         }
-        if (vjf_abort_seen(SC + VJF_SC_STATUS)) return;
+        if (vjf_abort_wg()) return;                                            // (behind one of the two waits above)
         { const int wg = sw; VJF_MG_STAMP(16); }
         bool have_sums = pass == 1;
         // one round: the quads q0 + (tid >> 3).  (Uniform over the workgroup: the first round of a pass holds a barrier.)

@@ -215,6 +215,12 @@ __device__ __forceinline__ bool vjf_abort_seen(const float* status) {
     const float f = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return ((unsigned)f & 0x1ff00u) != 0u;
 }
+// The same verdict for a whole workgroup: the lane that polled in the wait just before (vjf_wg_wait / vjf_wg_wait_sc1, given a status
+// word) read the status word once more behind its poll and left what it saw in this LDS word in front of the wait's barrier --
+// every thread of the workgroup takes the SAME decision to leave (a thread-by-thread read could split a workgroup around its later
+// barriers when the bits are raised between two threads' loads).  4 bytes of static LDS in the kernels that wait.
+__shared__ int vjf_s_abort_word;
+__device__ __forceinline__ bool vjf_abort_wg() { return vjf_s_abort_word != 0; }
 // The same for a workgroup whose outputs went out as write-through stores (in memory once vmcnt has drained): no L2 write-back
 // (an agent-scope release by every workgroup of a kernel that runs beside the trial kernel costs that kernel microseconds).
 __device__ __forceinline__ void vjf_wg_signal_wt(unsigned* count, int tid) {
@@ -239,6 +245,7 @@ __device__ __forceinline__ bool vjf_wg_wait_sc1(const unsigned* count, unsigned 
             __builtin_amdgcn_s_sleep(1);
         }
         if (fence) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        vjf_s_abort_word = (!there || vjf_abort_seen(status)) ? 1 : 0;
     }
     __syncthreads();
     return there;
@@ -257,6 +264,7 @@ __device__ __forceinline__ bool vjf_wg_wait(const unsigned* count, unsigned targ
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vjf_s_abort_word = (!there || vjf_abort_seen(status)) ? 1 : 0;
     }
     __syncthreads();
     return there;

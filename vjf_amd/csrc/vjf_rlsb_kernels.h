@@ -144,6 +144,9 @@ __device__ __forceinline__ void rlsc_col_step(const VjfPlan& P, const VjfRlsbArg
     float (&s_t)[1024] = L.t;
     int& s_good = L.good;
     const int n = P.n, nbl = (n + 31) / 32, ncol = nbl - k, nahead = ncol > 1 ? ncol - 1 : 0;
+    // (In the resident form the compiler hoists this function's lane-dependent address arithmetic out of the step loop and keeps
+    //  it: 256 VGPRs + 208 B per lane of scratch instead of 160 VGPRs and none with the thread index made opaque per step -- and
+    //  is the FASTER of the two, 767-771 against 780-787 us per config E step on one box: the hoisted form stays.)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool vec = (n & 3) == 0;
     float* Lm = A.Lw;

@@ -117,23 +117,22 @@ __device__ __forceinline__ bool vjf_chol_blocked(float* A, int n, float* lds) {
         if (!s_flag[0]) return false;
         const int rows = n - k0 - kb;                     // rows below the diagonal block
         // (b) panel: row i of A[:, k0:k0+kb] <- row * L_kk^-T  (forward substitution per row)
+        // (the row lives in LDS, not in 32 registers of a fully unrolled substitution: that form -- 528 multiply-adds with as many
+        //  LDS operands in flight -- cost the three kernels that use this routine 1.3-1.5 KB per lane of scratch; same
+        //  operations in the same order)
         for (int i = tid; i < rows; i += VJF_K2_THREADS) {
             float* arow = A + (size_t)(k0 + kb + i) * n + k0;
-            float o[VJF_NB];
-#pragma unroll
-            for (int c = 0; c < VJF_NB; ++c) o[c] = c < kb ? arow[c] : 0.f;
-#pragma unroll
+            float* prow = s_panel + (size_t)i * (VJF_NB + 1);
+            for (int c = 0; c < VJF_NB; ++c) prow[c] = c < kb ? arow[c] : 0.f;
+#pragma unroll 1
             for (int c = 0; c < VJF_NB; ++c) {
-                float acc = o[c];
-#pragma unroll
-                for (int m = 0; m < c; ++m) acc = fmaf(-o[m], s_diag[c * (VJF_NB + 1) + m], acc);
-                o[c] = acc / s_diag[c * (VJF_NB + 1) + c];
+                const float* drow = s_diag + c * (VJF_NB + 1);
+                float acc = prow[c];
+#pragma unroll 4
+                for (int m = 0; m < c; ++m) acc = fmaf(-prow[m], drow[m], acc);
+                prow[c] = acc / drow[c];
             }
-#pragma unroll
-            for (int c = 0; c < VJF_NB; ++c) {
-                s_panel[i * (VJF_NB + 1) + c] = o[c];
-                if (c < kb) arow[c] = o[c];
-            }
+            for (int c = 0; c < kb; ++c) arow[c] = prow[c];
         }
         __syncthreads();
         // (c) trailing update of the lower triangle: A[i][j] -= sum_m Lp[i][m] Lp[j][m]

@@ -330,6 +330,7 @@ class VJF(Module):
         `transition.velocity` (plain attributes in the reference: vjf/module.py:45-54), the two sample counters, the
         four group learning rates, the decoder-freeze flag and the shape of the model."""
         import numpy as np
+        self.check_status()                  # (raises if a device-side wait of an earlier call timed out: that state is not one to keep)
         st = {k: v.detach().cpu().numpy().copy() for k, v in self.state_dict().items()}
         lr = self.transition.velocity
         for k in self._RLS_KEYS:
@@ -561,6 +562,8 @@ class VJF(Module):
         :param verbose: verbose output
         :param warm_up: do not learn dynamics if True, default=False
         :param eps: optional (eps_s, eps_t) noise, each (batch, xdim); drawn if None
+        (Asynchronous, like `filter_sequence`: the device's status word -- 'RLS failed.', a timed-out hand-off -- is read by
+        `check_status()`, which a caller runs before relying on the outputs or the state; `fit`, `get_state`, `save_state` do.)
         :return:
             qt: posterior
             loss: negative elbo   [, -l_recon, -l_dynamics, entropy if verbose]
@@ -619,7 +622,13 @@ class VJF(Module):
                         warm_up: bool = False, eps: Tensor = None):
         """T successive `filter` steps in one C-ABI call (the inner loop of fit, vjf/model.py:252-261).
         y (T,B,ydim); u (T,B,udim) or None; eps (T,2,B,xdim) or None (drawn in the reference's order).
-        :return: mu (T,B,xdim), logvar (T,B,xdim), loss (T,4) = [loss, -l_recon, -l_dynamics, entropy]"""
+        :return: mu (T,B,xdim), logvar (T,B,xdim), loss (T,4) = [loss, -l_recon, -l_dynamics, entropy]
+
+        The call is ASYNCHRONOUS and does not read the device's status word.  **Call `check_status()` before you rely on the
+        outputs or on the model's state**: it warns 'RLS failed.' as the reference does, and RAISES when a hand-off inside the
+        launch timed out (compute units held by another process for 0.3 s: the outputs and the SGD / RLS state of that call are
+        then not valid -- restore from `get_state()` of an earlier point and run again).  `fit` does this after every sequence;
+        `get_state` / `save_state` do it before they copy anything."""
         y = dev32(y, ndim2=False)
         assert y.ndim == 3 and y.shape[2] == self.ydim
         T, B = y.shape[:2]
