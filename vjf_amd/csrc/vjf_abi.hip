@@ -696,7 +696,7 @@ int launch_trial(vjf_ctx* c, const VjfTrialArgs& a, int part, hipStream_t st, bo
         // part 1: everything up to the decoder (no use of W, w_chol, sigma); part 2: predictive moments, losses, backward; 0: both
         if (!a.replay && part != 2) {                              // (a replay: what the backward half reads stays in place)
         hipLaunchKernelGGL(vjf_wide_in_kernel, dim3(a.B < 2048 ? a.B : 2048), dim3(256), 0, st, P, w);
-        hipLaunchKernelGGL(vjf_wide_rbf_kernel, dim3((P.n + 255) / 256, (a.B + 15) / 16), dim3(256), (size_t)16 * P.dxu * 4, st, P, w);
+        hipLaunchKernelGGL(vjf_wide_rbf_kernel, dim3((P.n + 255) / 256, (a.B + 15) / 16), dim3(256), 0, st, P, w);
         int kin = P.din;
         for (int l = 0; l < P.L; ++l) {                            // h_l = tanh(h_{l-1} W_l^T + b_l)   (recognition.py:31-36)
             gemm(a.ACT + P.colA_act[l], P.ldA, S + P.off[VJF_SLOT_REC_W0 + 2 * l], kin, a.ACT + P.colA_act[l + 1], P.ldA, P.h[l], kin, 1,

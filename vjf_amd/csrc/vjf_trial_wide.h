@@ -368,21 +368,25 @@ __global__ __launch_bounds__(256) void vjf_wide_in_kernel(VjfPlan P, VjfWideArgs
     const bool prior = A.mu_s == nullptr;
     for (size_t b = blockIdx.x; b < (size_t)A.B; b += gridDim.x) {     // one trial row per workgroup and round
         float* arow = A.ACT + b * P.ldA;
-        for (int c = threadIdx.x; c < P.ldA; c += 256) {
-            float v = 0.f;
+        // (only the columns this kernel owns are visited: the inputs, the ones behind every segment -- the bias column of the gradient
+        //  Gram -- and the zeros behind the last one; the hidden activations / xt in between belong to the GEMMs and
+        //  vjf_wide_mid_kernel.  Scanning the whole row with a test per column made this 23 us of config E's step.)
+        for (int c = threadIdx.x; c < din; c += 256) {
+            float v;
             if (c < dy) v = A.y[b * dy + c];
             else if (c < dy + du) v = A.u[b * du + (c - dy)];
             else if (c < dy + du + dz) { const int j = c - dy - du; v = prior ? S[P.off[VJF_SLOT_PRIOR_MEAN] + j] : A.mu_s[b * dz + j]; }
-            else if (c < din) { const int j = c - dy - du - dz; v = prior ? S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j] : A.lv_s[b * dz + j]; }
-            else {
-                // the ones that follow every segment (the bias column of the gradient Gram); everything else is written later
-                bool one = c == din || c == P.colA_xt + dz;
-                for (int l = 0; l < P.L; ++l) one = one || c == P.colA_act[l + 1] + P.h[l];
-                if (!one && c < P.colA_xt + dz) continue;            // hidden activations / xt: by the GEMMs / vjf_wide_mid_kernel
-                v = one ? 1.f : 0.f;
-            }
+            else { const int j = c - dy - du - dz; v = prior ? S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j] : A.lv_s[b * dz + j]; }
             arow[c] = v;
         }
+        if ((int)threadIdx.x <= P.L + 1) {
+            const int i = threadIdx.x;
+            int col = din;
+            if (i == P.L + 1) col = P.colA_xt + dz;
+            else for (int l = 0; l < P.L; ++l) if (i == l + 1) col = P.colA_act[l + 1] + P.h[l];
+            arow[col] = 1.f;
+        }
+        for (int c = P.colA_xt + dz + 1 + threadIdx.x; c < P.ldA; c += 256) arow[c] = 0.f;
         for (int c = threadIdx.x; c < dxu; c += 256) {
             float v;
             if (c < dz) {
@@ -396,17 +400,20 @@ __global__ __launch_bounds__(256) void vjf_wide_in_kernel(VjfPlan P, VjfWideArgs
 }
 
 // RBF features: workgroup = 256 centroids x 16 trials.  Each thread keeps ONE centroid row in registers (read once, 16-byte
-// loads of its own contiguous row) and runs it against the 16 trials' [xs | u] rows staged in LDS (same address on every
-// lane: broadcast).  grid = (ceil(n / 256), ceil(B / 16)).
+// loads of its own contiguous row) and runs it against the 16 trials' [xs | u] rows.  Those are the same for every lane: they
+// are read through the constant address space at wave-uniform addresses -- scalar loads into SGPRs, which the subtract takes as
+// its scalar operand -- so the kernel issues no LDS instruction at all.  (Round 2 staged the rows in LDS and read them back as
+// broadcasts: a broadcast still returns 64 copies, 1 KB per 16-byte read, and the LDS pipe, not the vector unit, bounded the
+// kernel: 27 us of config E's step.)  The rows were written by the kernel before this one and are not written here.
+// grid = (ceil(n / 256), ceil(B / 16)).
 #define VJF_WIDE_RBF_MAXD 96
+typedef const float __attribute__((address_space(4))) vjf_cfloat;
 __global__ __launch_bounds__(256) void vjf_wide_rbf_kernel(VjfPlan P, VjfWideArgs W) {
-    extern __shared__ __attribute__((aligned(16))) float s_x[];   // 16 x dxu
     const VjfTrialArgs& A = W.t;
     const int n = P.n, dxu = P.dxu, tid = threadIdx.x;
     const int k = blockIdx.x * 256 + tid, b0 = blockIdx.y * 16, nb = min(16, A.B - b0);
-    for (int e = tid; e < 16 * dxu; e += 256) s_x[e] = (e / dxu) < nb ? W.XU[(size_t)b0 * dxu + e] : 0.f;
-    __syncthreads();
     if (k >= n) return;
+    vjf_cfloat* xu = (vjf_cfloat*)(W.XU + (size_t)b0 * dxu);
     const float* cen = A.state + P.off[VJF_SLOT_CENTROID] + (size_t)k * dxu;
     const float w = expf(A.state[P.off[VJF_SLOT_LOGWIDTH] + k]);
     const float sc = -0.5f / (w * w);
@@ -423,26 +430,24 @@ __global__ __launch_bounds__(256) void vjf_wide_rbf_kernel(VjfPlan P, VjfWideArg
 #pragma unroll
             for (int q = 0; q < 8; ++q) cv[q] = c0 + q < dxu ? cen[c0 + q] : 0.f;
         }
-        if ((dxu & 3) == 0) {                                  // (c0 + 8 <= dxu or c0 + 4 == dxu: whole 16-byte groups; same order of sums)
+        const int nq = min(8, dxu - c0);
+        if (nq == 8) {                                          // (eight consecutive coordinates of a row: one wide scalar load)
 #pragma unroll
             for (int b = 0; b < 16; ++b) {
-                const float4 x0 = *reinterpret_cast<const float4*>(&s_x[b * dxu + c0]);
-                float d;
-                d = x0.x - cv[0]; d2[b] = fmaf(d, d, d2[b]); d = x0.y - cv[1]; d2[b] = fmaf(d, d, d2[b]);
-                d = x0.z - cv[2]; d2[b] = fmaf(d, d, d2[b]); d = x0.w - cv[3]; d2[b] = fmaf(d, d, d2[b]);
-                if (c0 + 4 < dxu) {
-                    const float4 x1 = *reinterpret_cast<const float4*>(&s_x[b * dxu + c0 + 4]);
-                    d = x1.x - cv[4]; d2[b] = fmaf(d, d, d2[b]); d = x1.y - cv[5]; d2[b] = fmaf(d, d, d2[b]);
-                    d = x1.z - cv[6]; d2[b] = fmaf(d, d, d2[b]); d = x1.w - cv[7]; d2[b] = fmaf(d, d, d2[b]);
-                }
+                vjf_cfloat* xr = xu + (size_t)min(b, nb - 1) * dxu + c0;   // (rows beyond the batch: the last one again, never stored)
+                float x[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = xr[q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const float d = x[q] - cv[q]; d2[b] = fmaf(d, d, d2[b]); }
             }
-            continue;
-        }
+        } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (c0 + q < dxu) {
+            for (int b = 0; b < 16; ++b) {
+                vjf_cfloat* xr = xu + (size_t)min(b, nb - 1) * dxu + c0;
 #pragma unroll
-                for (int b = 0; b < 16; ++b) { const float d = s_x[b * dxu + c0 + q] - cv[q]; d2[b] = fmaf(d, d, d2[b]); }
+                for (int q = 0; q < 8; ++q)
+                    if (q < nq) { const float d = xr[q] - cv[q]; d2[b] = fmaf(d, d, d2[b]); }
             }
         }
     }
