@@ -237,7 +237,8 @@ def main():
             q = vjf_amd.Gaussian(mu[-1], lv[-1])
     # (the allocator's cache holds blocks of the timed regions' output sizes before the first of them runs, as it does in any loop
     #  that has been running for a while: two sets, a region's outputs are alive while the next one's are allocated)
-    prime = [torch.empty(K, c["B"], c["dz"], device=dev) for _ in range(4)] + [torch.empty(K, 4, device=dev) for _ in range(2)]
+    # (filter_sequence makes ONE allocation for its three outputs: blocks of exactly that size)
+    prime = [torch.empty(2 * K * c["B"] * c["dz"] + 4 * K, device=dev) for _ in range(2)]
     del prime
     # the state the timed region starts from, kept on the device (the oracle's copies -- the checker of the ELBO and the CPU
     # baseline; nothing of the timed path goes through them -- are made from it AFTER the timed regions: no host work, and no idle
