@@ -141,7 +141,7 @@ def test_filter_sequence_equals_steps(vjf, name):
 
 
 def test_filter_sequence_in_chunks(vjf, monkeypatch):
-    """Long sequences are enqueued in chunks (one cooperative launch per chunk; a chunk of ONE step is what `filter` runs): same bits as one piece."""
+    """Long sequences are enqueued in chunks (one launch per chunk; a chunk of ONE step is what `filter` runs): same bits as one piece."""
     z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
     y, eps = torch.tensor(z["y"]), torch.tensor(z["eps"])
     outs = []
@@ -161,7 +161,7 @@ def test_filter_sequence_in_chunks(vjf, monkeypatch):
 
 
 def test_filter_sequence_one_launch_vs_per_step_kernels(vjf):
-    """vjf_filter_seq's one-launch route (every role a workgroup of one cooperative grid) against the per-step kernels in
+    """vjf_filter_seq's one-launch route (every role a workgroup of one resident grid) against the per-step kernels in
     the one-stream order (`set_overlap(False)`): different kernels, different summation trees -- every output and the whole
     state agree to fp32 summation-order tolerance, over two calls (the second starts from a posterior, triangles clean)."""
     z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
@@ -252,7 +252,7 @@ def test_filter_vs_oracle(vjf, case):
 
 @pytest.mark.parametrize("case", CASES[:4], ids=lambda c: f"B{c['B']}_dz{c['dz']}_dy{c['dy']}_{c['lik']}")
 def test_filter_sequence_vs_oracle(vjf, case):
-    """The sequence entry point (one cooperative launch) on ragged batches, a control input, three layers, one
+    """The sequence entry point (one launch) on ragged batches, a control input, three layers, one
     trial: every step's posterior and loss, and the final state, against the oracle stepped on the same inputs."""
     torch.manual_seed(6)
     c = dict(case)

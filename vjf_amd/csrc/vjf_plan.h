@@ -232,7 +232,7 @@ __device__ __forceinline__ void vjf_wg_signal_wt(unsigned* count, int tid) {
 // The wait without the acquire: for consumers that read EVERY handed-off byte with sc1 loads (which bypass this CU's vector L1;
 // the producer stored write-through and drained before it signalled) -- MI355X guide, "sc1 loads in place of the acquire".  One
 // lane polls, the workgroup barrier, then the sc1 loads.
-// `fence` = true adds the acquire (the default of the one-launch route; VJF_HANDOFF_ACQUIRE=0 leaves the sc1 loads alone).
+// `fence` = true adds the acquire (VJF_HANDOFF_ACQUIRE=1; the default of the one-launch route is the sc1 loads alone).
 #define VJF_FLAG_HANDOFF_ACQUIRE 0x40000000u      /* internal flag bit of the kernels' `flags` words */
 __device__ __forceinline__ bool vjf_wg_wait_sc1(const unsigned* count, unsigned target, int tid, const float* status = nullptr, bool fence = false) {
     bool there = true;
