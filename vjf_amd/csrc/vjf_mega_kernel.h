@@ -337,6 +337,69 @@ __device__ __forceinline__ void mg_mma2x(vjf_f32x4& acc0, vjf_f32x4& acc1, __amd
     }
 }
 
+// The predictive variance's share of one wavefront: sum over its (at most two) 16-row tiles of L^-1 of the squares of
+// (rows j0 .. j0 + 15 of Xt) . Xs, into v2a / v2b (the two 16-trial column groups).  The tiles' k-batches (4 blocks of 16 k each,
+// operands as in mg_mma2x) form ONE stream with three batches in flight: the second tile's first loads are out while the first
+// tile still multiplies (one call of mg_mma2x per tile drained the pipeline in between: an exposed L2 round trip per tile).
+// Same products in the same order as two calls of mg_mma2x followed by the sums of squares: the same bits.
+// j0B < 0: no second tile; j0A < 0: none at all.
+__device__ __forceinline__ void mg_var2(float& v2a, float& v2b, __amdgpu_buffer_rsrc_t rx, int n, int j0A, int KA, int j0B, int KB,
+                                        const float* Xs, int lane) {
+    constexpr int LD = VJF_MG_LD;
+    if (j0A < 0) return;
+    const int i = lane & 15, kk = lane >> 4;
+    const bool rvA = (j0A + i) < n, rvB = j0B >= 0 && (j0B + i) < n;
+    const int offA = (rvA ? j0A + i : 0) * n + 4 * kk, offB = (rvB ? j0B + i : 0) * n + 4 * kk;
+    const float* xp = Xs + i;
+    const int ntA = (KA + 15) >> 4, ntB = j0B >= 0 ? (KB + 15) >> 4 : 0;
+    const int SA = (ntA + 3) >> 2, SB = (ntB + 3) >> 2, S = SA + SB;
+    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto fold = [&]() {
+        v2a = fmaf(acc0[0], acc0[0], fmaf(acc0[1], acc0[1], fmaf(acc0[2], acc0[2], fmaf(acc0[3], acc0[3], v2a))));
+        v2b = fmaf(acc1[0], acc1[0], fmaf(acc1[1], acc1[1], fmaf(acc1[2], acc1[2], fmaf(acc1[3], acc1[3], v2b))));
+    };
+    auto ldb = [&](float4 (&a)[4], int sb) {
+        const bool inB = sb >= SA;                                            // (uniform)
+        const int t0 = 4 * (inB ? sb - SA : sb), off = inB ? offB : offA;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int kq = 16 * (t0 + q) + 4 * kk; a[q] = mg_ld4(rx, off + (kq + 3 < n ? 16 * (t0 + q) : 0)); }
+    };
+    auto mmb = [&](const float4 (&a)[4], int sb) {
+        const bool inB = sb >= SA;
+        const int t0 = 4 * (inB ? sb - SA : sb), nt = inB ? ntB : ntA, ke = inB ? KB : KA;
+        const bool rv = inB ? rvB : rvA;
+        if (sb == SA && SA > 0) {                                             // the first batch of the second tile
+            fold();
+            acc0 = vjf_f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = vjf_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (t0 + q < nt) {                                                // (uniform)
+                const int k0 = 16 * (t0 + q) + 4 * kk;
+                const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = k0 + c, kc = min(k, ke - 1);
+                    const float v = (rv && k < ke) ? av[c] : 0.f;             // (masked at use: see mg_mma2)
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v, xp[kc * LD], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v, xp[kc * LD + 16], acc1, 0, 0, 0);
+                }
+            }
+        }
+    };
+    float4 a0[4], a1[4], a2[4];
+    ldb(a0, 0);
+    if (S > 1) ldb(a1, 1);
+    if (S > 2) ldb(a2, 2);
+    for (int sb = 0; sb < S; sb += 3) {
+        mmb(a0, sb);
+        if (sb + 3 < S) ldb(a0, sb + 3);
+        if (sb + 1 < S) { mmb(a1, sb + 1); if (sb + 4 < S) ldb(a1, sb + 4); }
+        if (sb + 2 < S) { mmb(a2, sb + 2); if (sb + 5 < S) ldb(a2, sb + 5); }
+    }
+    fold();
+}
+
 // The same product with the A operand in LDS: Ws is a matrix [rows][ldw] as torch stores it.
 //   TR = false: A[m][k] = Ws[(m0 + m) * ldw + k]       (out = W x:  forward products)
 //   TR = true : A[m][k] = Ws[k * ldw + m0 + m]         (out = W^T x: backward products)
@@ -907,16 +970,19 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
                 float am[16];
                 if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
-                // tiles in descending cost, dealt to the wavefronts in a snake so that the triangular work balances
-                for (int r = 0;; ++r) {
-                    const int idx = (r & 1) ? r * NW + NW - 1 - wave : r * NW + wave;
-                    if (idx >= ntile) { if (r * NW >= ntile) break; else continue; }
-                    const int tt = ntile - 1 - idx, j0 = tt * 16;
-                    const int K = tri ? min(n, j0 + 16) : n;
-                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mg_mma2x(acc0, acc1, r_xt, n, n, j0, s_phi, K, lane);       // rows j0 .. j0 + 15 of L^-1 = columns of w_chol
-                    v2a = fmaf(acc0[0], acc0[0], fmaf(acc0[1], acc0[1], fmaf(acc0[2], acc0[2], fmaf(acc0[3], acc0[3], v2a))));
-                    v2b = fmaf(acc1[0], acc1[0], fmaf(acc1[1], acc1[1], fmaf(acc1[2], acc1[2], fmaf(acc1[3], acc1[3], v2b))));
+                // tiles in descending cost, dealt to the wavefronts in a snake so that the triangular work balances; a wavefront's tiles of
+                // two rounds go through mg_var2 as one stream of operand batches
+                for (int r = 0; r * NW < ntile; r += 2) {
+                    int j0p[2], Kp[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int rr = r + h, idx = (rr & 1) ? rr * NW + NW - 1 - wave : rr * NW + wave;
+                        const int tt = ntile - 1 - idx;
+                        j0p[h] = (idx < ntile) ? tt * 16 : -1;                  // rows j0 .. j0 + 15 of L^-1 = columns of w_chol
+                        Kp[h] = tri ? min(n, tt * 16 + 16) : n;
+                    }
+                    if (j0p[0] < 0) { j0p[0] = j0p[1]; Kp[0] = Kp[1]; j0p[1] = -1; }
+                    mg_var2(v2a, v2b, r_xt, n, j0p[0], Kp[0], j0p[1], Kp[1], s_phi, lane);
                 }
                 if (first) VJF_MG_STAMP(22);
                 v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
