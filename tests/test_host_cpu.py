@@ -193,6 +193,32 @@ def test_state_io_roundtrip_cpu(fake, tmp_path):
         pass
 
 
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the stand-in backend works on CPU tensors")
+def test_get_state_reads_the_status_word_first(fake):
+    """`filter` / `filter_sequence` are asynchronous and do not read the device's status word; `get_state` (and `save_state`)
+    must, before they copy anything: a timed-out hand-off (VJF_STATUS_WAIT_* bits) means the state is not one to keep -- it
+    raises; an RLS failure is warned about as the reference does ('RLS failed.', vjf/module.py:112) and the (unchanged) state
+    is returned."""
+    import warnings
+    import vjf_amd as vjf
+    from vjf_amd import _native as N
+    torch.manual_seed(3)
+    m = vjf.VJF.make_model(6, 2, 0, 8, [5], likelihood="gaussian")
+    g = torch.Generator().manual_seed(1)
+    y, eps = torch.randn(2, 4, 6, generator=g), torch.randn(2, 2, 4, 2, generator=g)
+    m.filter_sequence(y, eps=eps)
+    assert len(m.get_state()) == 13 + 4 + 5
+    m._scalars[N.SC_STATUS] = float(N.STATUS_RLS_FAILED)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        st = m.get_state()
+    assert any("RLS failed" in str(x.message) for x in w) and len(st) == 13 + 4 + 5
+    m._scalars[N.SC_STATUS] = float(0x100)                    # a hand-off wait that ran out
+    with pytest.raises(RuntimeError):
+        m.get_state()
+    assert m.status() == 0                                    # (read and cleared)
+
+
 def test_lorenz_generator_is_the_surveyed_system():
     """sigma = 10, rho = 28, beta = 8/3, RK4 with dt = 0.01, 500 burn-in steps, z-scored."""
     from vjf_amd.data import lorenz, observe, rbf_system
