@@ -8,7 +8,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # VJF_LIB=chaos loads the diagnostic build of the same sources (-DVJF_CHAOS, vjf_plan.h: workgroups are held at random in front of
 # their hand-offs; tools/chaos_handoffs.py) -- same ABI, same kernels otherwise
-LIB_PATH = os.path.join(HERE, "libvjf_hip_chaos.so" if os.environ.get("VJF_LIB") == "chaos" else "libvjf_hip.so")
+#  (any other VJF_LIB=name: libvjf_hip_name.so, a hand-built experiment of the same sources)
+_variant = os.environ.get("VJF_LIB", "")
+LIB_PATH = os.path.join(HERE, f"libvjf_hip_{_variant}.so" if _variant.isalnum() else "libvjf_hip.so")
 
 ABI_VERSION = 1
 MAX_HIDDEN = 8

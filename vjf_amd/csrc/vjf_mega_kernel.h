@@ -1082,6 +1082,9 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             }
             __syncthreads(); MG_PHASE();
             if (first) VJF_MG_STAMP(31);
+#ifdef VJF_EXPERIMENT_SLOW_TRIAL   /* sensitivity experiment: every trial workgroup held for this many 10-ns ticks per step */
+            { const unsigned long long t0_ = wall_clock64(); while (wall_clock64() - t0_ < VJF_EXPERIMENT_SLOW_TRIAL) __builtin_amdgcn_s_sleep(1); }
+#endif
             if (tid < RS_SDX2 && !replay) {                                    // (RS_LRECON, RS_LDYN, RS_ENT, RS_SSEY)
                 float v = 0.f;
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + tid];

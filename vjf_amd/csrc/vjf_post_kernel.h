@@ -518,6 +518,9 @@ __device__ __forceinline__ void vjf_rls_post_body(const VjfPlan& P, const VjfPos
         }
         __syncthreads();
         VJF_POST_STAMP(20);
+#ifdef VJF_EXPERIMENT_SLOW_RLS     /* sensitivity experiment: the state-noise tail held for this many 10-ns ticks per step */
+        { const unsigned long long t0_ = wall_clock64(); while (wall_clock64() - t0_ < VJF_EXPERIMENT_SLOW_RLS) __builtin_amdgcn_s_sleep(1); }
+#endif
         double part = 0.0;
         const int c = lane & 31, h = lane >> 5;
 #pragma unroll
