@@ -36,25 +36,28 @@
 #define VJF_MG_GROWS 96              // rows of Phi formed per pass of the Gram role
 #define VJF_MG_MAXQ 4                // 32x32 tiles of Phi^T Phi per wavefront of a Gram workgroup (28 lower tiles / 8)
 
-// counters: one per 64-byte line of the block that the host zeroes before every launch
+// counters: one per 64-byte line of the block -- times MG_C_SPREAD (experiment: 64 puts every counter into a 4-KB page of its own)
+#ifndef MG_C_SPREAD
+#define MG_C_SPREAD 1
+#endif
 enum {
-    MG_C_FWD = 16,       // trial workgroups whose early slab of step t is in memory           target (t + 1) n_trial
-    MG_C_K1 = 32,        // trial workgroups that have read W, w_chol, sigma of step t - 1      target (t + 1) n_trial
-    MG_C_BWD = 48,       // trial workgroups whose late slab of step t is in memory            target (t + 1) n_trial
-    MG_C_GRAM = 64,      // Gram workgroups whose partial tiles of event e are in memory       target (e + 1) n_gram
-    MG_C_STAT = 80,      // Gram workgroups whose share of Phi^T Phi of event e is reduced      target (e + 1) n_gram
-    MG_C_PREP = 96,      // operand workgroups done with step t                                target (t + 1) n_prep
-    MG_C_SGD = 112,      // SGD workgroups done with step t                                    target (t + 1) n_sgd
-    MG_C_PDONE = 128,    // RLS workgroups (y / W loop + inverse loops) done with step t       target (t + 1) (2 nbl + 1)
-    MG_C_STARTED = 144,
-    MG_C_REDO_B = 0,     // trial workgroups whose REPLAYED late slab is in memory             target (replays so far) n_trial
-    MG_C_REDO_S = 176,   // SGD workgroups done with a replayed step                         target (replays so far) n_sgd
-    MG_C_IMG = 208,      // SGD workgroups whose share of the parameter image is in memory (start of the launch)  target n_sgd
-    MG_C_SIGW = 224,     // 8 bytes: {epoch, sigma} from the y / W loop to the Cholesky loop of the next step
-    MG_C_XT = 240,       // inverse workgroups whose share of xt = w_chol^T is in memory (start of the launch)              target 2 nbl
-    MG_C_MASK = 192,     // (step + 1) << 8 | non-finite loss components (1 recon, 2 dynamics, 4 entropy) of the last step that had one
-    MG_C_COLFLAGS = 160, // [0 .. VJF_CHOL_MAXBLK]: column flags of the Cholesky loop; [VJF_CHOL_MAXBLK + 2]: its "operands loaded" word
-    MG_C_WORDS = 256
+    MG_C_FWD = 16 * MG_C_SPREAD,       // trial workgroups whose early slab of step t is in memory           target (t + 1) n_trial
+    MG_C_K1 = 32 * MG_C_SPREAD,        // trial workgroups that have read W, w_chol, sigma of step t - 1      target (t + 1) n_trial
+    MG_C_BWD = 48 * MG_C_SPREAD,       // trial workgroups whose late slab of step t is in memory            target (t + 1) n_trial
+    MG_C_GRAM = 64 * MG_C_SPREAD,      // Gram workgroups whose partial tiles of event e are in memory       target (e + 1) n_gram
+    MG_C_STAT = 80 * MG_C_SPREAD,      // Gram workgroups whose share of Phi^T Phi of event e is reduced      target (e + 1) n_gram
+    MG_C_PREP = 96 * MG_C_SPREAD,      // operand workgroups done with step t                                target (t + 1) n_prep
+    MG_C_SGD = 112 * MG_C_SPREAD,      // SGD workgroups done with step t                                    target (t + 1) n_sgd
+    MG_C_PDONE = 128 * MG_C_SPREAD,    // RLS workgroups (y / W loop + inverse loops) done with step t       target (t + 1) (2 nbl + 1)
+    MG_C_STARTED = 144 * MG_C_SPREAD,
+    MG_C_REDO_B = 0 * MG_C_SPREAD,     // trial workgroups whose REPLAYED late slab is in memory             target (replays so far) n_trial
+    MG_C_REDO_S = 176 * MG_C_SPREAD,   // SGD workgroups done with a replayed step                         target (replays so far) n_sgd
+    MG_C_IMG = 208 * MG_C_SPREAD,      // SGD workgroups whose share of the parameter image is in memory (start of the launch)  target n_sgd
+    MG_C_SIGW = 224 * MG_C_SPREAD,     // 8 bytes: {epoch, sigma} from the y / W loop to the Cholesky loop of the next step
+    MG_C_XT = 240 * MG_C_SPREAD,       // inverse workgroups whose share of xt = w_chol^T is in memory (start of the launch)              target 2 nbl
+    MG_C_MASK = 192 * MG_C_SPREAD,     // (step + 1) << 8 | non-finite loss components (1 recon, 2 dynamics, 4 entropy) of the last step that had one
+    MG_C_COLFLAGS = 160 * MG_C_SPREAD, // [0 .. VJF_CHOL_MAXBLK]: column flags of the Cholesky loop; [VJF_CHOL_MAXBLK + 2]: its "operands loaded" word
+    MG_C_WORDS = 256 * MG_C_SPREAD
 };
 
 struct VjfMegaArgs {
@@ -624,7 +627,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
                         if ((int)(__hip_atomic_load(cnt + MG_C_SGD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * (unsigned)A.n_sgd) >= 0) { there = true; break; }
                         if ((spins & 255u) == 255u && vjf_abort_seen(SCW + VJF_SC_STATUS)) break;
-                        __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
                     }
                     const bool rls = !rls_in && (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
                     const unsigned mw = __hip_atomic_load(cnt + MG_C_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -173,6 +173,14 @@ struct VjfJob {
 // host that is late with its launches, or a peer rank that is late with its half of a collective; short enough that a sequence
 // that really is stuck (a launch held behind a resident kernel's hardware queue) is given up quickly.
 #define VJF_WAIT_SPINS (1u << 21)
+// s_sleep argument (units of 64 cycles) between two polls of a hand-off word in memory.  The polls of a launch -- 256 workgroups, most
+// of them waiting most of the time -- all go to the few memory-side lines of the counter block, and they delay each other AND the
+// write-through traffic of the step: with back-to-back polls (1) config B ran 56.3 us a step, with 12: 55.1, 24: 53.4-53.8,
+// 40: 52.3-52.8, 64: 53.2 (same box, two runs each; a poll every ~1 us costs less in detection latency than the contention of
+// faster ones; four out-of-phase pollers per workgroup: 60.4).  Spreading the counters over 4-KB pages of their own changed nothing.
+#ifndef VJF_POLL_SLEEP
+#define VJF_POLL_SLEEP 40
+#endif
 #ifdef __HIPCC__
 // Hand-offs between kernels that run beside each other on different streams (no kernel boundary between producer and
 // consumer).  Producer, whole workgroup: every storing wavefront drains its stores, the workgroup barrier, one lane releases
@@ -242,7 +250,7 @@ __device__ __forceinline__ bool vjf_wg_wait_sc1(const unsigned* count, unsigned 
         for (unsigned spins = 0; spins < (1u << 21); ++spins) {
             if ((int)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { there = true; break; }
             if ((spins & 255u) == 255u && status && ((unsigned)__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x1ff00u)) break;
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
         }
         if (fence) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         vjf_s_abort_word = (!there || vjf_abort_seen(status)) ? 1 : 0;
@@ -260,7 +268,7 @@ __device__ __forceinline__ bool vjf_wg_wait(const unsigned* count, unsigned targ
         for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
             if ((int)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { there = true; break; }
             if ((spins & 255u) == 255u && vjf_abort_seen(status)) break;
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
