@@ -129,6 +129,9 @@ __device__ __forceinline__ void rlsc_ld_rc(float (&v)[16], const float* M, int n
 }
 
 #define VJF_RLSC_THREADS 512
+#ifndef VJF_RLSC_BARRIER_SLEEP
+#define VJF_RLSC_BARRIER_SLEEP 40     /* s_sleep argument between two polls of the step barrier's counter (vjf_rlsc_loop_kernel): 63 pollers beside the trial chain -- with 2 config E ran 763 us a step, with 24 ... 100: 722-739 */
+#endif
 struct VjfRlscLds {
     float p[4][2][1024];
     float d[1024], i[1024], t[1024];
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_loop_kernel(VjfPlan
             bool there = false;
             for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
                 if ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { there = true; break; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(VJF_RLSC_BARRIER_SLEEP);
             }
             s_go = there ? 1 : 0;
         }

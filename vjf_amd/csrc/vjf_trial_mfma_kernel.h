@@ -330,7 +330,7 @@ __global__ __launch_bounds__(VJF_K1M_THREADS) __attribute__((amdgpu_waves_per_eu
             for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
                 if ((int)(__hip_atomic_load(AA.rls_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - AA.rls_target) >= 0) { there = true; break; }
                 if ((spins & 255u) == 255u && vjf_abort_seen(A.state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS)) break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
             }
             if (!there) vjf_status_or(const_cast<float*>(A.state) + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
