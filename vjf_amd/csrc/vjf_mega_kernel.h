@@ -854,11 +854,29 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 s_xt[j * LD + b] = xt;
                 s_dx[j * LD + b] = b < nb ? xt - s_xu[j * LD + b] : 0.f;
             }
-            if (!replay)
-            for (int e = tid; e < nb * dz; e += NT) {                          // coalesced posterior stores
-                const int b = mg_div(e, m_dz), j = e - b * dz;
-                mg_st(mu_t + (size_t)(b0 + b) * dz + j, s_mu[j * LD + b]);         // (write-through: the Gram role forms the next step's
-                mg_st(lv_t + (size_t)(b0 + b) * dz + j, s_lv[j * LD + b]);         //  features from them)
+            if (!replay) {
+                // posterior out (write-through: the Gram role forms the next step's features from it).  The tile's rows are contiguous
+                // in memory: four consecutive elements per 16-byte store where the tile starts on a 16-byte boundary (a quarter of
+                // the fabric writes: 82 k scalar ones per step at config B before), scalar stores for what is left over
+                float* mrow = mu_t + (size_t)b0 * dz;
+                float* lrow = lv_t + (size_t)b0 * dz;
+                const int ne = nb * dz;
+                const int n4 = ((((size_t)mrow | (size_t)lrow) & 15u) == 0) ? (ne >> 2) : 0;
+                for (int e4 = tid; e4 < n4; e4 += NT) {
+                    float vm[4], vl[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int e = 4 * e4 + c, b = mg_div(e, m_dz), j = e - b * dz;
+                        vm[c] = s_mu[j * LD + b]; vl[c] = s_lv[j * LD + b];
+                    }
+                    mg_st4(mrow + 4 * e4, vm[0], vm[1], vm[2], vm[3]);
+                    mg_st4(lrow + 4 * e4, vl[0], vl[1], vl[2], vl[3]);
+                }
+                for (int e = 4 * n4 + tid; e < ne; e += NT) {
+                    const int b = mg_div(e, m_dz), j = e - b * dz;
+                    mg_st(mrow + e, s_mu[j * LD + b]);
+                    mg_st(lrow + e, s_lv[j * LD + b]);
+                }
             }
             __syncthreads(); MG_PHASE();
             {
