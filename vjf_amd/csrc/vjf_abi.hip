@@ -1041,7 +1041,7 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
     rc = check_step_args(c, B, y, u, mu0, lv0, eps, eps + sz, mu, lv);
     if (rc) return rc;
     if (c->comm_a) {
-        // The ranks enter the sequence together: kernels of this route wait in-kernel (bounded, ~0.3 s) for kernels that sit behind
+        // The ranks enter the sequence together: kernels of this route wait in-kernel (bounded, seconds) for kernels that sit behind
         // an all-reduce, and an all-reduce waits for the slowest rank -- one that is late with this CALL by more than the bound
         // (data loading, a first call) must not run its peers' waits out.  One tiny all-reduce and a host synchronisation per
         // call; inside the sequence the per-step collectives keep the ranks in step.

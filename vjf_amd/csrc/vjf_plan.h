@@ -169,7 +169,7 @@ struct VjfJob {
     int tw, tb;        // kind 1: rows of the plan's trainable-tensor table that the weight / the bias belong to (tb -1: none)
 };
 
-// Bound of every wait of one kernel for another (polls; ~0.15 us each when the word is not contended: ~0.3 s).  Long enough for a
+// Bound of every wait of one kernel for another (polls; ~2 us each with the sleep between them, VJF_POLL_SLEEP: ~4 s).  Long enough for a
 // host that is late with its launches, or a peer rank that is late with its half of a collective; short enough that a sequence
 // that really is stuck (a launch held behind a resident kernel's hardware queue) is given up quickly.
 #define VJF_WAIT_SPINS (1u << 21)

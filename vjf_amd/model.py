@@ -626,7 +626,7 @@ class VJF(Module):
 
         The call is ASYNCHRONOUS and does not read the device's status word.  **Call `check_status()` before you rely on the
         outputs or on the model's state**: it warns 'RLS failed.' as the reference does, and RAISES when a hand-off inside the
-        launch timed out (compute units held by another process for 0.3 s: the outputs and the SGD / RLS state of that call are
+        launch timed out (compute units held by another process for seconds: the outputs and the SGD / RLS state of that call are
         then not valid -- restore from `get_state()` of an earlier point and run again).  `fit` does this after every sequence;
         `get_state` / `save_state` do it before they copy anything."""
         y = dev32(y, ndim2=False)
