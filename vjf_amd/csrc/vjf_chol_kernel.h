@@ -630,12 +630,16 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
     if (tid == 0) s_flag[0] = 1;
     if (tid < 16) s_flag[128 + tid] = 0;                // the column loop's hand-off words (below)
     __syncthreads();
-    // (the statistics of the step: the Gram role's write-through stores, read below with sc1 loads behind this count -- an acquire
-    //  as well only in the VJF_HANDOFF_ACQUIRE=1 form)
-    if (A.stat_count && (!vjf_wg_wait_sc1(A.stat_count, it_stat_target, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) || (A.inject_epoch && tid == 0 && it_epoch == A.inject_epoch))) {
-        vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_STATS);
-        *s_dead = 1;
-    }
+    // (the statistics of the step: the Gram role's write-through stores, read with sc1 loads behind their count -- an acquire as
+    //  well only in the VJF_HANDOFF_ACQUIRE=1 form.  The wait sits below, between this thread's loads of P, which do not depend on
+    //  the statistics, and its loads of G: at the first step of a launch nothing else hides the 108 KB of P)
+    auto stat_wait = [&]() {
+        if (A.stat_count && (!vjf_wg_wait_sc1(A.stat_count, it_stat_target, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) || (A.inject_epoch && tid == 0 && it_epoch == A.inject_epoch))) {
+            vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_STATS);
+            *s_dead = 1;
+        }
+    };
+    if (warm) stat_wait();
 
     if (!warm) {
         // ---- load the lower block triangle of P_new (vjf_prep_kernel already added Phi^T Phi / v).  Wavefront 0 takes the
@@ -704,7 +708,17 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                 const int gi = s_bi[b] * 32 + r, gj = s_bj[b] * 32 + c4;
                 if (sp && !it_src_state) v[q] = *reinterpret_cast<const float4*>(A.pscr + (size_t)idx * 4);
                 else v[q] = (gi < n && gj < n) ? *reinterpret_cast<const float4*>(Pm + (size_t)gi * n + gj) : pad4(gi, gj);
-                if (sp) g[q] = g4(gi, gj);
+            }
+        }
+        stat_wait();
+        if (sp) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int idx = idx_of(q);
+                if (idx < ntri * 256) {
+                    const int b = idx >> 8, r = (idx >> 3) & 31, c4 = (idx & 7) * 4;
+                    g[q] = g4(s_bi[b] * 32 + r, s_bj[b] * 32 + c4);
+                }
             }
         }
         if (sp) {
