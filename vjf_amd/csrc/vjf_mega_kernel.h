@@ -1369,18 +1369,26 @@ __device__ __forceinline__ void vjf_mega_gram(const VjfPlan& P, const VjfMegaArg
 #pragma unroll
                         for (int u = 0; u < 2; ++u) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc[q], 0, 0, 0);
                     }
+                    // the last pass of rows: the tile is final and leaves at once, 16-byte write-through stores, beside the next tile's
+                    // multiply-adds.  Accumulator: column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); slab element
+                    // ((j*64 + lane)*4 + r) = register 4 j + r of that lane
+                    if (c0 + VJF_MG_GROWS >= r1) {
+                        float* sl = myslab + (size_t)tt * 1024;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mg_st4(sl + (j * 64 + lane) * 4, acc[q][4 * j], acc[q][4 * j + 1], acc[q][4 * j + 2], acc[q][4 * j + 3]);
+                    }
                 }
             }
         }
-        // partial tiles out, 16-byte write-through stores.  Accumulator: column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
-        // slab element ((j*64 + lane)*4 + r) = register 4 j + r of that lane
+        if (r0 >= r1) {                                                        // (a workgroup without rows: its slab is zeros)
 #pragma unroll
-        for (int q = 0; q < VJF_MG_MAXQ; ++q) {
-            const int tt = wave + VJF_MG_WAVES * q;
-            if (tt < ntri) {
-                float* sl = myslab + (size_t)tt * 1024;
+            for (int q = 0; q < VJF_MG_MAXQ; ++q) {
+                const int tt = wave + VJF_MG_WAVES * q;
+                if (tt < ntri) {
+                    float* sl = myslab + (size_t)tt * 1024;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mg_st4(sl + (j * 64 + lane) * 4, acc[q][4 * j], acc[q][4 * j + 1], acc[q][4 * j + 2], acc[q][4 * j + 3]);
+                    for (int j = 0; j < 4; ++j) mg_st4(sl + (j * 64 + lane) * 4, 0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
         vjf_wg_signal_wt(A.cnt + MG_C_GRAM, tid);
