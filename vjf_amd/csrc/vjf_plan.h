@@ -178,6 +178,7 @@ struct VjfJob {
 // write-through traffic of the step: with back-to-back polls (1) config B ran 56.3 us a step, with 12: 55.1, 24: 53.4-53.8,
 // 40: 52.3-52.8, 64: 53.2 (same box, two runs each; a poll every ~1 us costs less in detection latency than the contention of
 // faster ones; four out-of-phase pollers per workgroup: 60.4).  Spreading the counters over 4-KB pages of their own changed nothing.
+// (Config C, whose trial role takes its operands from L2, would like 64 better: 74.8 against 76.5 us a step; config B 53.2 against 52.5.)
 #ifndef VJF_POLL_SLEEP
 #define VJF_POLL_SLEEP 40
 #endif
