@@ -8,18 +8,18 @@
 //   trial role       n_trial workgroups; workgroup w owns the 32-trial tiles w, w + n_trial, ..  Per tile and step: reparametrise,
 //                    RBF features, recognition network, posterior, decoder (model.py:97-122), Phi^T dx of the tile; then -- behind the
 //                    RLS update of the previous step -- predictive mean / variance, loss terms (model.py:124-154), hand-derived backward
-//                     and the tile's weight / bias gradients on the matrix cores (K = 32 trials); last the features of
-//                    the NEXT step (they depend only on this step's posterior) into the rows the Gram role reads.  A workgroup's sums
+//                     and the tile's weight / bias gradients on the matrix cores (K = 32 trials).  A workgroup's sums
 //                    over its tiles leave as two slabs: early [Phi^T dx | sum dx^2], late [gradients | loss sums].
-//   Gram role        n_gram workgroups: Phi^T Phi (module.py:96) one step AHEAD -- rows staged in LDS, all 28 lower 32x32 tiles per
+//   Gram role        n_gram workgroups: Phi^T Phi (module.py:96) one step AHEAD -- its rows of Phi formed here from the posterior, in LDS, all 28 lower 32x32 tiles per
 //                    workgroup on v_mfma_f32_32x32x2_f32, partial tiles to a slab, then every workgroup sums its share of the slabs
 //   operand role     ceil(n / 16) workgroups: sum of the early slabs -> Phi^T dx, g = P W + Phi^T dx / v, P += Phi^T Phi / v (module.py:94-96)
 //   SGD role         n_sgd workgroups: sum of the late slabs, finite guards and loss (model.py:138-154), clip + SGD (model.py:210-211),
 //                    likelihood running variance (likelihood.py:28-40)
 //
 // Hand-offs are monotone workgroup counters in memory: producer = write-through stores, every storing wavefront drains vmcnt, the
-// workgroup barrier, one relaxed agent-scope add; consumer = one lane polls (bounded), one agent-scope acquire, vmcnt drained,
-// barrier, plain loads (MI355X guide, Guideline 16).  Nothing ever waits for work of a launch that has not been submitted: every
+// workgroup barrier, one relaxed agent-scope add; consumer = one lane polls about once a microsecond (bounded; VJF_POLL_SLEEP,
+// vjf_plan.h), the workgroup barrier, and every handed-off byte is read with an sc1 load (MI355X guide, "sc1 loads in place of the
+// acquire"; VJF_HANDOFF_ACQUIRE=1 adds an agent-scope acquire behind every wait).  Nothing ever waits for work of a launch that has not been submitted: every
 // producer is a workgroup of this grid, and the grid is resident as a whole.  All sums are taken in a fixed order: results do not
 // depend on timing, and a sequence cut into chunks gives the same bits as one piece.
 #pragma once
