@@ -256,8 +256,8 @@ def main():
         lo = W + r * K
         ev0, ev1 = evs[r]
         barrier()
+        ev0.record(stream)                                       # (the stream is empty: the event is the device-side start of the region)
         t0 = time.perf_counter()
-        ev0.record(stream)
         mu, lv, loss = model.filter_sequence(y[lo:lo + K], qs=q, eps=eps[lo:lo + K])
         enq = time.perf_counter() - t0                           # host time to enqueue the K steps (asynchronous)
         ev1.record(stream)
