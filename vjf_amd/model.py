@@ -610,7 +610,8 @@ class VJF(Module):
             self._all_reduce_sum(self._reduce)                        # the ONE collective of a step
             N.check(L.vjf_filter_global(self._ctx, B * world, N.ptr(loss4), flags), "vjf_filter_global")
         if update and not warm_up:
-            self.transition.velocity._w_colmajor = True      # see LinearRegression._draw_weight_noise
+            if not self.transition.velocity._w_colmajor:     # (nn.Module.__setattr__ costs 2.5 us: only when it changes)
+                self.transition.velocity._w_colmajor = True  # see LinearRegression._draw_weight_noise
         qt = Gaussian(mu_t, lv_t)
         if verbose:
             return qt, loss4[0], loss4[1], loss4[2], loss4[3]
@@ -671,7 +672,7 @@ class VJF(Module):
                 self._all_reduce_sum(self._reduce)
                 N.check(L.vjf_filter_global(self._ctx, B * world, N.ptr(loss[t]), flags), "vjf_filter_global")
                 ms, ls = mu[t], lv[t]
-        if update and not warm_up:
+        if update and not warm_up and not self.transition.velocity._w_colmajor:
             self.transition.velocity._w_colmajor = True
         return mu, lv, loss
 
