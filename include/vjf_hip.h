@@ -156,6 +156,10 @@ int vjf_route(vjf_ctx* ctx, uint32_t flags);
  * vjf_filter_global (vjf/model.py has no multi-GPU path: SURVEY 8e). */
 int vjf_comm_unique_id(void* ids256);
 int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world);
+/* What RCCL itself says about the context's two communicators: ranks[0], ranks[1] = ncclCommCount of the gradient chain's and of
+ * the statistics chain's communicator (0, 0 without communicators).  A benchmark line quotes these, not the launcher's
+ * environment. */
+int vjf_comm_ranks(vjf_ctx* ctx, int32_t* ranks2);
 
 /* Diagnostic: enable/disable s_memtime phase stamps in the serial kernel and (out32 != NULL) copy the
  * 32 stamp words of the last step to the host.  Not part of the reference surface. */

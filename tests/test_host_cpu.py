@@ -254,3 +254,42 @@ def test_lorenz_example_plumbing(fake, capsys):
     m, loss = mod.main(["--epochs", "2", "--T", "60", "--n-rbf", "20", "--forecast", "5"])
     assert m.shape == (60, 3) and torch.isfinite(m).all() and np.isfinite(float(loss))
     assert "forecast: (6, 1, 3) (6, 1, 10) finite: True" in capsys.readouterr().out
+
+
+def test_bench_starts_its_own_ranks_only_without_a_launcher(monkeypatch):
+    """`bench.py --gpus N` (N > 1) with no WORLD_SIZE starts a torch.distributed.run child and relays its exit code; with a
+    launcher's environment, or at N = 1, it runs in-process (returns None).  Without a GPU the ranks fail: the code is relayed and
+    no result line is printed."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench._launch_own_ranks(["--gpus", "1", "--steps", "5"]) is None
+    assert bench._launch_own_ranks(["--steps", "5"]) is None
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert bench._launch_own_ranks(["--gpus", "2"]) is None
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    if not torch.cuda.is_available():
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus=2", "--steps", "2", "--warmup", "1"], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode != 0 and r.stdout.strip() == b""
+        assert b"needs a GPU" in r.stderr
+
+
+def test_bench_algorithmic_work_is_the_surveys():
+    """230,200 FLOP and 440 B per trial-timestep at config B (+ 762,472 B shared per step); the other flag sets
+    drop terms, never add any."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f, bt, bs, ser = bench.algorithmic_work(bench.CFGS["B"])
+    assert (f, bt, bs) == (230200, 440, 762472) and ser == (2 * 200 ** 3) // 3 + 4 * 200 * 200 * 10
+    for fl in ("warmup", "sgd-only", "infer"):
+        f2, _, _, s2 = bench.algorithmic_work(bench.CFGS["B"], fl)
+        assert 0 < f2 < f and s2 == 0
+    assert bench.CFGS["D1"]["B"] == 8 * bench.CFGS["B"]["B"]

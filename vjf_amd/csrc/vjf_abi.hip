@@ -62,10 +62,12 @@ typedef int (*nccl_comm_init_rank_t)(void**, int, VjfNcclId, int);
 typedef int (*nccl_comm_destroy_t)(void*);
 typedef int (*nccl_all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*nccl_group_t)();
+typedef int (*nccl_comm_count_t)(void*, int*);
 typedef const char* (*nccl_err_t)(int);
 struct VjfNccl {
     nccl_get_unique_id_t get_unique_id; nccl_comm_init_rank_t comm_init_rank; nccl_comm_destroy_t comm_destroy;
     nccl_all_reduce_t all_reduce; nccl_group_t group_start, group_end; nccl_err_t err;
+    nccl_comm_count_t comm_count;
     bool ok;
 };
 constexpr int kNcclFloat = 7, kNcclSum = 0;        // ncclFloat32, ncclSum (rccl.h)
@@ -83,6 +85,7 @@ const VjfNccl& nccl() {
         v.group_start = (nccl_group_t)dlsym(h, "ncclGroupStart");
         v.group_end = (nccl_group_t)dlsym(h, "ncclGroupEnd");
         v.err = (nccl_err_t)dlsym(h, "ncclGetErrorString");
+        v.comm_count = (nccl_comm_count_t)dlsym(h, "ncclCommCount");
         v.ok = v.get_unique_id && v.comm_init_rank && v.comm_destroy && v.all_reduce && v.group_start && v.group_end;
         return v;
     }();
@@ -532,6 +535,18 @@ int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world)
     ctx->comm_a = ca; ctx->comm_b = cb; ctx->world = world;
     ctx->fake_world = 1;
     if (const char* fw = getenv("VJF_DEBUG_FAKE_WORLD")) { const int k = atoi(fw); if (world == 1 && k > 1 && k <= 64) ctx->fake_world = k; }
+    return 0;
+}
+
+int vjf_comm_ranks(vjf_ctx* ctx, int32_t* ranks2) {
+    if (!ctx || !ranks2) return fail(-1, "vjf_comm_ranks: null argument");
+    ranks2[0] = ranks2[1] = 0;
+    if (!ctx->comm_a) return 0;
+    if (!nccl().comm_count) return fail(-111, "vjf_comm_ranks: ncclCommCount is not available in this process");
+    int na = 0, nb = 0;
+    VJF_NCCL(nccl().comm_count(ctx->comm_a, &na));
+    VJF_NCCL(nccl().comm_count(ctx->comm_b, &nb));
+    ranks2[0] = na; ranks2[1] = nb;
     return 0;
 }
 

@@ -312,12 +312,13 @@ class VJF(Module):
             if rc < 0:
                 N.check(rc, "vjf_set_overlap")
 
-    def route(self, sgd: bool = True, update: bool = True) -> str:
+    def route(self, sgd: bool = True, update: bool = True, warm_up: bool = False) -> str:
         """The schedule `filter_sequence` would use now for this batch size: 'one-launch', 'streams' (three streams: the RCCL
         path), 'two-stream' (plans whose RLS update is a sequence of launches: that update beside the trial chain) or 'per-step'."""
         if self._ctx is None:
             return "unsized"
-        rc = self._backend().vjf_route(self._ctx, (N.FLAG_SGD if sgd else 0) | (N.FLAG_UPDATE if update else 0))
+        rc = self._backend().vjf_route(self._ctx, (N.FLAG_SGD if sgd else 0) | (N.FLAG_UPDATE if update else 0)
+                                       | (N.FLAG_WARM_UP if warm_up else 0))
         if rc < 0:
             N.check(rc, "vjf_route")
         return {1: "one-launch", 2: "two-stream", 3: "streams"}.get(rc, "per-step")
@@ -486,6 +487,15 @@ class VJF(Module):
         N.check(L.vjf_comm_init(self._ctx, buf, dist.get_rank(), world), "vjf_comm_init")
         self._comm_ok = True
         return True
+
+    def comm_ranks(self):
+        """[ranks of the gradient chain's communicator, of the statistics chain's] as RCCL reports them (ncclCommCount);
+        [0, 0] when the context has none (single rank, or the sums over ranks on the caller's side)."""
+        if self._ctx is None:
+            return [0, 0]
+        r = (ctypes.c_int32 * 2)()
+        N.check(self._backend().vjf_comm_ranks(self._ctx, r), "vjf_comm_ranks")
+        return [int(r[0]), int(r[1])]
 
     def _overlap_flag(self) -> bool:
         return bool(getattr(self, "_overlap", 1))
