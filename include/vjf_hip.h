@@ -13,7 +13,12 @@
  *   - the library never allocates device memory: the caller owns `state` and `workspace`
  *     (sizes from vjf_state_size / vjf_workspace_size) and may alias `state` as tensors;
  *   - calls are asynchronous on the context's HIP stream and ordered on it; one context is not
- *     re-entrant, several contexts may coexist (SURVEY.md 8b "Threading").
+ *     re-entrant, several contexts may coexist (SURVEY.md 8b "Threading"): the launches of the one-launch route -- a grid that
+ *     must be resident as a whole -- are chained across the contexts of a process (each waits for the completion of the
+ *     previous one, whichever context and stream it came from), and a grid that shares the device with ANOTHER process's
+ *     ends within a quarter of a second with VJF_STATUS_NOT_RESIDENT, the state untouched;
+ *   - besides the caller's `state` and `workspace` the library holds one page of pinned HOST memory per process and device:
+ *     the words through which a launch that has given up a wait tells the host (read at the start of the next call).
  */
 #ifndef VJF_HIP_H
 #define VJF_HIP_H
@@ -58,6 +63,12 @@ extern "C" {
 #define VJF_STATUS_WAIT_G 0x4000u        /* y / W loop: operands (g)                                               */
 #define VJF_STATUS_WAIT_COLUMN 0x8000u   /* y / W and inverse loops: a column of L, or the trial role's readers    */
 #define VJF_STATUS_WAIT_K1 0x10000u      /* trial role / kernel: previous step's RLS update                        */
+#define VJF_STATUS_NOT_RESIDENT 0x20000u /* one-launch route: not every workgroup of the grid was placed on the device in time (another
+                                          * process's kernels hold compute units): the launch ended before it touched the state; the
+                                          * context leaves the one-launch route */
+#define VJF_STATUS_WAIT_MASK 0x3ff00u    /* any of the above: the outputs of the call that raised it are not to be used.  The NEXT
+                                          * vjf_filter_* call of the context fails (it would chain invalid results) until
+                                          * vjf_get_status has been called. */
 
 /* Slots of the state blob, in the reference's state_dict order followed by the plain-attribute
  * RLS tensors and the scalars the reference keeps as Python numbers. */

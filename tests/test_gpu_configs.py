@@ -284,3 +284,23 @@ def test_bench_line_contract(config):
     if config == "B":                                          # the fixed cost of a call, measured behind the timed regions
         cc = d["call_cost"]
         assert 0.0 < cc["fixed_us_per_call"] < 400.0 and 0.0 < cc["single_filter_call_us"] < 600.0 and 20.0 < cc["steady_us_per_step"] < 200.0
+
+
+def test_resident_column_loop_barrier_timeout_raises(vjf, monkeypatch):
+    """The resident column loop of the multi-launch RLS update (vjf_rlsc_loop_kernel, the two-stream route) with one workgroup that
+    never arrives at the step barrier (injected): the update is dropped like one with a failed pivot AND the status word carries a
+    wait bit -- check_status() raises instead of the sequence going on with a stale W."""
+    c = dict(B=64, dz=3, dy=10, n=256, hidden=[8], lik="gaussian")
+    torch.manual_seed(3)
+    m = _model(vjf, c)
+    y, eps = _data(c, 3, 5)
+    m.filter_sequence(y[:2].cuda(), eps=eps[:2].cuda())
+    assert m.route() == "two-stream" and m.check_status() == 0
+    w_before = m.transition.velocity.w_mean.clone()
+    monkeypatch.setenv("VJF_DEBUG_RLSC_ABSENT", "2")
+    m.filter_sequence(y[1:].cuda(), eps=eps[1:].cuda())
+    monkeypatch.delenv("VJF_DEBUG_RLSC_ABSENT")
+    torch.cuda.synchronize()
+    assert torch.equal(m.transition.velocity.w_mean, w_before)        # (no update was applied)
+    with pytest.raises(RuntimeError, match="timed out"):
+        m.check_status()

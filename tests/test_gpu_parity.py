@@ -425,9 +425,100 @@ def test_timed_out_handoff_ends_the_launch_and_raises(vjf, monkeypatch):
     monkeypatch.setenv("VJF_DEBUG_INJECT", "4")
     model.filter_sequence(y, eps=eps)
     monkeypatch.delenv("VJF_DEBUG_INJECT")
+    # the NEXT call of the context does not chain on the invalid results: it fails at once (the device told the host through the
+    # pinned page; no synchronisation on the usual path) until the status has been read
+    torch.cuda.synchronize()
+    with pytest.raises(vjf._native.VjfError, match="timed out"):
+        model.filter_sequence(y[:2], eps=eps[:2])
+    with pytest.raises(vjf._native.VjfError, match="timed out"):
+        model.filter(y[0], eps=(eps[0, 0], eps[0, 1]))
     with pytest.raises(RuntimeError, match="timed out"):
         model.check_status()
     assert model.status() == 0                                   # (cleared by the read)
+    # ... and the context has left the route on which the wait ran out: it goes on with the per-step kernels
+    assert model.route() == "per-step"
+    model.filter_sequence(y[:2], eps=eps[:2])
+    assert model.check_status() == 0
+
+
+def test_grid_that_is_not_resident_as_a_whole_leaves_the_state_untouched(vjf, monkeypatch):
+    """Another process's kernels holding compute units (injected: the grid's residency count waits for one workgroup more than the
+    launch has): the launch ends within its short bound before any role has written to the state, VJF_STATUS_NOT_RESIDENT is
+    raised, the next call fails instead of chaining, and after the status has been read the context runs on the per-step kernels
+    from the SAME state -- the result equals a model that never tried."""
+    import time
+    g = torch.Generator().manual_seed(21)
+    y, eps = torch.randn(4, 64, 10, generator=g), torch.randn(4, 2, 64, 3, generator=g)
+    torch.manual_seed(20)
+    ref = vjf.VJF.make_model(10, 3, 0, 40, [8], likelihood="gaussian")
+    ref.set_overlap(False)
+    torch.manual_seed(20)
+    m = vjf.VJF.make_model(10, 3, 0, 40, [8], likelihood="gaussian")
+    m.filter_sequence(y[:1], eps=eps[:1]); ref.filter_sequence(y[:1], eps=eps[:1])
+    assert m.route() == "one-launch" and m.check_status() == 0
+    before = m._blob.clone()
+    monkeypatch.setenv("VJF_DEBUG_ABSENT", "1")
+    t0 = time.perf_counter()
+    m.filter_sequence(y[1:], eps=eps[1:])
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 2.0                         # (a quarter of a second's bound, not the 4 s of a hand-off)
+    monkeypatch.delenv("VJF_DEBUG_ABSENT")
+    st = m._blob.clone()
+    st[m._scalars.storage_offset() + 7] = 0.0                     # (everything but the status word)
+    assert torch.equal(st, before)
+    with pytest.raises(vjf._native.VjfError, match="not resident"):
+        m.filter_sequence(y[1:], eps=eps[1:])
+    with pytest.raises(RuntimeError, match="timed out"):
+        m.check_status()
+    assert m.route() == "per-step"
+    a = m.filter_sequence(y[1:], eps=eps[1:])
+    b = ref.filter_sequence(y[1:], eps=eps[1:])
+    for u_, v_ in zip(a, b):
+        close(u_, v_, rtol=2e-5, atol=2e-5)
+    assert m.check_status() == 0
+
+
+def test_two_models_on_two_streams_interleaved(vjf):
+    """Several contexts coexist (include/vjf_hip.h): two models, each on a torch stream of its own, their `filter_sequence` calls
+    interleaved without a synchronisation in between.  Every call is a grid that wants every compute unit's LDS; the library
+    chains them (each launch waits for the completion of the previous one of ANY context): results bitwise equal to the two
+    models run one after the other, no wait gives up."""
+    g = torch.Generator().manual_seed(31)
+    T, B = 6, 256
+    ya, ea = torch.randn(T, B, 10, generator=g).cuda(), torch.randn(T, 2, B, 3, generator=g).cuda()
+    yb, eb = torch.randn(T, B, 10, generator=g).cuda(), torch.randn(T, 2, B, 3, generator=g).cuda()
+
+    def pair():
+        torch.manual_seed(30)
+        ma = vjf.VJF.make_model(10, 3, 0, 40, [8], likelihood="gaussian", lr=1e-3)
+        mb = vjf.VJF.make_model(10, 3, 0, 40, [8], likelihood="gaussian", lr=1e-3)
+        return ma, mb
+    ra, rb = pair()
+    outs_ref = []
+    for k in range(3):
+        outs_ref.append((ra.filter_sequence(ya, eps=ea, qs=None if k == 0 else vjf.Gaussian(outs_ref[-1][0][0][-1], outs_ref[-1][0][1][-1])),
+                         rb.filter_sequence(yb, eps=eb, qs=None if k == 0 else vjf.Gaussian(outs_ref[-1][1][0][-1], outs_ref[-1][1][1][-1]))))
+        torch.cuda.synchronize()
+    ma, mb = pair()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for k in range(3):
+        with torch.cuda.stream(sa):
+            oa = ma.filter_sequence(ya, eps=ea, qs=None if k == 0 else vjf.Gaussian(outs[-1][0][0][-1], outs[-1][0][1][-1]))
+        with torch.cuda.stream(sb):
+            ob = mb.filter_sequence(yb, eps=eb, qs=None if k == 0 else vjf.Gaussian(outs[-1][1][0][-1], outs[-1][1][1][-1]))
+        outs.append((oa, ob))
+    torch.cuda.synchronize()
+    assert ma.route() == "one-launch" and mb.route() == "one-launch"
+    for (xa, xb), (wa, wb) in zip(outs, outs_ref):
+        for u_, v_ in zip(xa + xb, wa + wb):
+            assert torch.equal(u_, v_)
+    assert torch.equal(ma._blob, ra._blob) and torch.equal(mb._blob, rb._blob)
+    with torch.cuda.stream(sa):
+        assert ma.check_status() == 0
+    with torch.cuda.stream(sb):
+        assert mb.check_status() == 0
 
 
 def test_rls_failure_is_flagged_and_leaves_rls_state(vjf):
@@ -566,7 +657,7 @@ def test_nonfinite_component_on_the_sharded_route(vjf, monkeypatch):
     finally:
         os.environ.pop("VJF_FORCE_DIST", None)
         dist.destroy_process_group()
-    assert st & 2 and not (st & 0x1ff00), hex(st)                  # VJF_STATUS_NONFINITE_DYN, no time-out
+    assert st & 2 and not (st & 0x3ff00), hex(st)                  # VJF_STATUS_NONFINITE_DYN, no time-out
     y2, e2 = torch.cat([y, y], 1), torch.cat([eps, eps], 2)       # the two "ranks" hold the same trials
     om, ol = torch.cat([mu0[-1], mu0[-1]]).cpu().numpy(), torch.cat([lv0[-1], lv0[-1]]).cpu().numpy()
     with warnings.catch_warnings():
@@ -911,7 +1002,7 @@ def test_last_step_without_a_gradient_keeps_the_earlier_steps(vjf):
         mu, lv, loss = m.filter_sequence(y, eps=eps)
         assert m.route() == "one-launch"
         st = m.status()
-        assert (st & 7) == 7 and not (st & 0x1ff00), hex(st)
+        assert (st & 7) == 7 and not (st & 0x3ff00), hex(st)
         om = ol = None
         for t in range(T - 1):
             o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
@@ -960,3 +1051,96 @@ def test_operator_kernels_odd_shapes_against_fp64(vjf):
         smp = blr(x, sampling=True, noise=noise)
         w = blr.w_mean.cpu().double() + blr.w_chol.cpu().double() @ noise.double()
         close(smp, (phi @ w).float(), rtol=5e-5, atol=5e-6)
+
+
+# ------------------------------------------------------------------ the one-launch route for the other flag sets of VJF.filter
+FLAG_SETS = {"warmup": dict(sgd=True, update=True, warm_up=True), "infer": dict(sgd=False, update=False, warm_up=False),
+             "sgd-only": dict(sgd=True, update=False, warm_up=False), "infer-warm": dict(sgd=False, update=True, warm_up=True)}
+
+
+@pytest.mark.parametrize("flags", sorted(FLAG_SETS))
+@pytest.mark.parametrize("name", ["g5_gaussian_du2_wu1_f32", "g5_poisson_du0_wu1_f32", "g5_medium_gaussian_f32"])
+def test_flag_sets_on_the_one_launch_route(vjf, name, flags):
+    """warm_up=True (the first epochs of fit: vjf/model.py:243-259), sgd=False / update=False (a deployed filter: model.py:180, 206,
+    215) run as ONE launch of trial + SGD roles (vjf_mega_lite_kernel): (1) the route says so; (2) `filter_sequence` == stepwise
+    `filter`, bit for bit, outputs and blob; (3) against the per-step kernels of the one-stream order; (4) every step against the
+    fp64 oracle; (5) a second call continues from the first one's posterior."""
+    kw = FLAG_SETS[flags]
+    z, info, _ = gio.traj_case(name)
+    m1, m2, m3 = (_model_for(vjf, info, lr=1e-3) for _ in range(3))
+    for m in (m1, m2, m3):
+        load_fixture_state(m, z, "s0")
+    m3.set_overlap(False)
+    s = load_oracle_state(m1, np.float64)
+    u = torch.tensor(z["u"]) if info["du"] else None
+    y, eps = torch.tensor(z["y"]), torch.tensor(z["eps"])
+    T, k = info["T"], info["T"] // 2
+    mu_a, lv_a, loss_a = m1.filter_sequence(y[:k], None if u is None else u[:k], None, eps=eps[:k], **kw)
+    assert m1.route(**kw) == "one-launch"
+    mu_b, lv_b, loss_b = m1.filter_sequence(y[k:], None if u is None else u[k:], vjf.Gaussian(mu_a[-1], lv_a[-1]), eps=eps[k:], **kw)
+    mu, lv, loss = torch.cat([mu_a, mu_b]), torch.cat([lv_a, lv_b]), torch.cat([loss_a, loss_b])
+    o3 = m3.filter_sequence(y, u, None, eps=eps, **kw)
+    assert m3.route(**kw) == "per-step"
+    q = None
+    om = ol = None
+    for t in range(T):
+        q, l, *c = m2.filter(y[t], None if u is None else u[t], q, verbose=True, eps=(eps[t, 0], eps[t, 1]), **kw)
+        assert torch.equal(q.mean, mu[t]) and torch.equal(q.logvar, lv[t])
+        assert torch.equal(torch.stack([l, *c]), loss[t])
+        o = orc.filter_step(s, z["y"][t].astype(np.float64), None if u is None else z["u"][t].astype(np.float64), om, ol,
+                            z["eps"][t, 0].astype(np.float64), z["eps"][t, 1].astype(np.float64), **kw)
+        om, ol = o.mu_t, o.lv_t
+        close(mu[t], o.mu_t, **POST)
+        close(lv[t], o.lv_t, **POST)
+        close(loss[t], [o.loss, o.recon, o.dyn, o.entropy], rtol=3e-5, atol=3e-5)
+    assert torch.equal(m1._blob, m2._blob)
+    for a, b in zip((mu, lv, loss), o3):
+        close(a, b, rtol=2e-5, atol=2e-5)
+    close(m1._blob, m3._blob, rtol=2e-3, atol=2e-5)
+    state_close(m1, s, rtol=2e-4, atol=2e-5, rls_rtol=2e-3)
+    if not kw["update"]:
+        assert m1.transition.n_sample == int(z["s0.n_tr"])
+    assert m1.status() == 0 and m2.status() == 0 and m3.status() == 0
+
+
+def test_update_without_sgd_stays_on_the_per_step_kernels(vjf):
+    """sgd=False, update=True, no warm-up (nobody's usual call) is the one flag set the one-launch route leaves to the per-step
+    kernels; it still matches the oracle."""
+    z, info, _ = gio.traj_case("g5_gaussian_du0_wu0_f32")
+    m = _model_for(vjf, info)
+    load_fixture_state(m, z, "s0")
+    s = load_oracle_state(m, np.float64)
+    kw = dict(sgd=False, update=True, warm_up=False)
+    mu, lv, loss = m.filter_sequence(torch.tensor(z["y"]), None, None, eps=torch.tensor(z["eps"]), **kw)
+    assert m.route(**kw) == "per-step"
+    ro = orc.filter_sequence(s, z["y"].astype(np.float64), None, z["eps"].astype(np.float64), **kw)
+    close(mu, ro[0], **POST)
+    state_close(m, s, rtol=2e-4, atol=2e-5, rls_rtol=2e-3)
+
+
+@pytest.mark.parametrize("flags", ["warmup", "infer"])
+def test_flag_sets_at_bench_size(vjf, flags):
+    """`bench.py --flags warmup|infer` at its size (B = 4096, config B): more steps than the ring of loss sums holds (the launch
+    without parameter updates has no gate between its steps), against the fp64 oracle on the first steps, bitwise against two chunks."""
+    kw = FLAG_SETS[flags]
+    torch.manual_seed(5)
+    m1 = vjf.VJF.make_model(50, 10, 0, 200, [128], likelihood="gaussian", lr=1e-3)
+    torch.manual_seed(5)
+    m2 = vjf.VJF.make_model(50, 10, 0, 200, [128], likelihood="gaussian", lr=1e-3)
+    s = load_oracle_state(m1, np.float64)
+    g = torch.Generator().manual_seed(9)
+    T, B = 80, 4096
+    y, eps = torch.randn(T, B, 50, generator=g).cuda(), torch.randn(T, 2, B, 10, generator=g).cuda()
+    mu, lv, loss = m1.filter_sequence(y, eps=eps, **kw)
+    assert m1.route(**kw) == "one-launch" and m1.status() == 0
+    a = m2.filter_sequence(y[:47], eps=eps[:47], **kw)
+    b = m2.filter_sequence(y[47:], qs=vjf.Gaussian(a[0][-1], a[1][-1]), eps=eps[47:], **kw)
+    assert torch.equal(torch.cat([a[0], b[0]]), mu) and torch.equal(torch.cat([a[2], b[2]]), loss) and torch.equal(m1._blob, m2._blob)
+    om = ol = None
+    yc, ec = y[:6].cpu().numpy().astype(np.float64), eps[:6].cpu().numpy().astype(np.float64)
+    for t in range(6):
+        o = orc.filter_step(s, yc[t], None, om, ol, ec[t, 0], ec[t, 1], **kw)
+        om, ol = o.mu_t, o.lv_t
+        close(mu[t], o.mu_t, rtol=3e-5, atol=3e-5)
+        close(loss[t], [o.loss, o.recon, o.dyn, o.entropy], rtol=3e-5, atol=3e-5)
+    assert torch.isfinite(loss).all()

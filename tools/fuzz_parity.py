@@ -95,15 +95,26 @@ def run_case(case, desc, verbose=False, T=3):
             if verbose and not seq:
                 for nm in ("w_mean", "w_chol", "w_precision", "w_pchol"):
                     judge(f"t={t} {nm}", getattr(m.transition.velocity, nm), getattr(s, nm), getattr(s32, nm), 0.0, 5e-5)
+    step_notes = list(judge.notes)
     try:
         state_close(m, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3)
         assert not verbose
     except AssertionError:
-        vel = m.transition.velocity
-        for nm, tg in (("w_mean", vel.w_mean), ("w_chol", vel.w_chol), ("w_precision", vel.w_precision), ("w_pchol", vel.w_pchol)):
-            judge(nm, tg, getattr(s, nm), getattr(s32, nm), 0.0, 5e-5)
-        if not judge.notes and not verbose:
-            raise
+        # state_close's tolerances do not hold in the ill-conditioned cases: EVERY state tensor -- trained parameters, the two
+        # log-variances, the RLS tensors -- is then judged against the fp32 oracle's own distance from fp64 (the judge raises on a
+        # tensor beyond the slack), with a list of notes of its own: the per-step notes above excuse nothing here
+        from tests import goldenio as gio
+        from tests.helpers import model_arrays
+        judge.notes = []
+        got, w64, w32 = model_arrays(m), gio.state_arrays(s), gio.state_arrays(s32)
+        for nm in sorted(got):
+            if nm in w64 and w64[nm] is not None:
+                rls = nm in ("w_mean", "w_chol", "w_precision", "w_pchol")
+                judge("state " + nm, got[nm], np.asarray(w64[nm]).reshape(got[nm].shape), np.asarray(w32[nm]).reshape(got[nm].shape),
+                      0.0 if rls else 5e-4, 5e-5)
+        state_notes, judge.notes = judge.notes, step_notes + judge.notes
+        if not state_notes and not verbose:
+            raise                                          # (state_close failed, yet no tensor is out of its tolerance: not explained)
     st = m.status()
     assert st == 0, hex(st)
     return m.route(), list(judge.notes)

@@ -17,6 +17,7 @@ MAX_HIDDEN = 8
 LIK_GAUSSIAN, LIK_POISSON = 0, 1
 FLAG_SGD, FLAG_UPDATE, FLAG_WARM_UP, FLAG_EXACT_NONFINITE = 1, 2, 4, 8
 STATUS_NONFINITE_RECON, STATUS_NONFINITE_DYN, STATUS_NONFINITE_ENT, STATUS_RLS_FAILED = 1, 2, 4, 8
+STATUS_NOT_RESIDENT, STATUS_WAIT_MASK = 0x20000, 0x3ff00
 
 # enum vjf_slot
 SLOT_PRIOR_MEAN, SLOT_PRIOR_LOGVAR, SLOT_LIK_LOGVAR, SLOT_TR_LOGVAR, SLOT_CENTROID, SLOT_LOGWIDTH = range(6)

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <ctime>
 #include <atomic>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -99,6 +100,27 @@ const VjfNccl& nccl() {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
+// ---- what the contexts of a process share, per device
+//  * the chain of one-launch grids: such a grid must be resident as a whole (every workgroup wants a whole compute unit's LDS), so
+//    two of them -- two models on two streams -- must never be dispatched side by side: each launch waits for the completion event
+//    of the previous one, whatever context and stream that came from.  While a device has a single context with the route the
+//    stream's own order does this and no event is used; the second context's creation synchronises the device once and switches
+//    the chain on for good.
+//  * a page of pinned host memory through which a launch that has given up a wait tells the host (vjf_plan.h, vjf_status_or).
+struct DevShared {
+    std::mutex mu;
+    int mega_ctxs = 0;          // live contexts whose plan the one-launch route serves
+    bool chained = false;
+    hipEvent_t last = nullptr;  // completion of the most recent one-launch grid on this device
+    hipStream_t last_stream = nullptr;
+    bool last_valid = false;
+    unsigned* mirror_h = nullptr;   // the page of pinned host memory (VJF_MIRROR_WORDS words) ...
+    unsigned* mirror_d = nullptr;   // ... as the device addresses it
+};
+constexpr int kMaxDevices = 64;
+DevShared g_dev[kMaxDevices];
+DevShared* dev_shared(int device) { return device >= 0 && device < kMaxDevices ? &g_dev[device] : nullptr; }
+
 int split_for(int B) {
     int s = B / 256;
     if (s < 1) s = 1;
@@ -172,15 +194,30 @@ bool mega_plan_ok(const VjfPlan& P) {
     return true;
 }
 
-bool mega_shape(const VjfPlan& P, int B, int ncu, MegaShape* m) {
+bool mega_shape(const VjfPlan& P, int B, int ncu, uint32_t flags, MegaShape* m) {
     // one workgroup per compute unit: the RLS loops and the operand role have fixed sizes; the trial role gets 128 / 227 of the
     // rest (one 32-trial tile per workgroup at 256 CUs and 4096 trials), then the SGD role (below), the Gram role whatever remains
     const int nbl = (P.n + 31) / 32;
-    m->n_rls = 2 + 2 * nbl;
-    m->n_prep = (P.n + 15) / 16;
+    const bool rls = (flags & (VJF_FLAG_UPDATE | VJF_FLAG_WARM_UP)) == VJF_FLAG_UPDATE;   // (else: no RLS, Gram, operand roles)
+    m->n_rls = rls ? 2 + 2 * nbl : 0;
+    m->n_prep = rls ? (P.n + 15) / 16 : 0;
     m->ntiles = (B + VJF_MG_TR - 1) / VJF_MG_TR;
     const int rest = ncu - m->n_rls - m->n_prep;
     if (rest < 3) return false;
+    if (!rls) {
+        // trial + SGD roles only: the SGD role as many workgroups as its fewest rounds of slab loads need (they also build the
+        // parameter image at the start of the launch), the trial role the rest
+        const int quads = vjf_mega_slab_layout(P).len / 4, gpw = VJF_MG_THREADS / 8;
+        int want = (quads + gpw - 1) / gpw;
+        if (want > rest / 4) want = rest / 4;
+        if (want < 1) want = 1;
+        m->n_sgd = want;
+        int cap = rest - m->n_sgd;
+        if (cap > kMegaMaxTrialWg) cap = kMegaMaxTrialWg;
+        m->n_trial = m->ntiles < cap ? m->ntiles : cap;
+        m->n_gram = 0; m->gram_rows = 0;
+        return true;
+    }
     int cap_t = rest * 128 / 227;
     if (cap_t < 1) cap_t = 1;
     if (cap_t > kMegaMaxTrialWg) cap_t = kMegaMaxTrialWg;
@@ -242,7 +279,7 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
         const int nbl = (P.n + 31) / 32;
         const size_t slab_len = (size_t)vjf_mega_slab_layout(P).len;
         c.mg_early = take((size_t)2 * kMegaMaxTrialWg * ((size_t)((P.n + 3) & ~3) * 16 + 8) * 4);   // (two sets: even / odd steps)
-        c.mg_late = take((size_t)kMegaMaxTrialWg * (slab_len + 8) * 4);
+        c.mg_late = take((size_t)kMegaMaxTrialWg * (slab_len + 8 * VJF_MG_RING) * 4);
         c.mg_gslab = take((size_t)kMegaMaxGramWg * (nbl * (nbl + 1) / 2) * 1024 * 4);
         c.mg_cnt = take((size_t)2 * MG_C_WORDS * 4);           // two counter blocks: a launch runs on one and zeroes the other for the next
         c.mg_stamps = take((32 * 32 + kMegaMaxTrialWg * 8) * 8);   // ring of role stamps | 8 words per trial workgroup (last step)
@@ -294,6 +331,7 @@ struct vjf_ctx {
     bool mega_ok;          // the plan fits the one-launch route (vjf_mega_kernel.h)
     int ncu;               // compute units of the device: the one-launch grid has one workgroup per CU
     int mega_wg_per_cu;    // workgroups of vjf_mega_kernel a compute unit can hold (occupancy query): the residency check of the route
+    int lite_wg_per_cu;    // the same for vjf_mega_lite_kernel (the launches without an RLS update)
     unsigned mega_launches; // launches of vjf_mega_kernel so far: launch k counts in counter block k & 1
     hipStream_t stream2, stream3;
     hipEvent_t ev_s, ev_c;
@@ -304,6 +342,8 @@ struct vjf_ctx {
     unsigned fwd_count;    // workgroups of forward halves launched with a completion count
     unsigned stats_count;  // steps whose RLS statistics the three-stream route has launched (host mirror of flag word kStatsWord)
     unsigned start_count;  // host mirror of the post kernel's "workgroups started" count
+    bool mega_counted;     // counted in its device's DevShared::mega_ctxs
+    bool on_mega;          // the context's last sequence ran on the one-launch route (a timed-out wait then makes it leave the route)
     void* comm_a; void* comm_b;   // RCCL communicators of the two chains of the three-stream route (null: single rank)
     int world;
     int fake_world;        // test hook (VJF_DEBUG_FAKE_WORLD=k at vjf_comm_init, one-rank communicators): behave as rank 0 of k ranks that
@@ -393,9 +433,9 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
         int v = 0;
         VJF_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device));
         c->ncu = v;
-        c->mega_wg_per_cu = 0;
+        c->mega_wg_per_cu = 0; c->lite_wg_per_cu = 0;
     }
-    c->start_count = 0; c->mega_launches = 0;
+    c->start_count = 0; c->mega_launches = 0; c->on_mega = false; c->mega_counted = false;
     c->stream2 = c->stream3 = nullptr; c->ev_s = c->ev_c = nullptr;
     for (int i = 0; i < 2; ++i) c->ev_f[i] = c->ev_r[i] = c->ev_b[i] = c->ev_g[i] = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0; c->stats_count = 0;
@@ -481,12 +521,39 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, vjf_mega_kernel, VJF_MG_THREADS, kMegaLds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
         c->mega_wg_per_cu = nb;
         if (nb < 1) c->mega_ok = false;
+        allow_lds(vjf_mega_lite_kernel, kMegaLds);
+        nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, vjf_mega_lite_kernel, VJF_MG_THREADS, kMegaLds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        c->lite_wg_per_cu = nb;
+    }
+    if (DevShared* d = dev_shared(cfg->device)) {
+        std::lock_guard<std::mutex> lk(d->mu);
+        if (!d->mirror_h) {
+            unsigned* h = nullptr; unsigned* dp = nullptr;
+            if (hipHostMalloc((void**)&h, VJF_MIRROR_WORDS * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+                hipHostGetDevicePointer((void**)&dp, h, 0) == hipSuccess) {
+                memset(h, 0, VJF_MIRROR_WORDS * sizeof(unsigned));
+                d->mirror_h = h; d->mirror_d = dp;
+            }
+            (void)hipGetLastError();                                // (without the page: no early notice, the status word still tells)
+        }
+        if (c->mega_ok) c->mega_counted = true;
+        if (c->mega_ok && ++d->mega_ctxs == 2 && !d->chained) {
+            (void)hipDeviceSynchronize();                           // (the first context's launches so far carry no event)
+            if (!d->last) (void)hipEventCreateWithFlags(&d->last, hipEventDisableTiming);
+            d->chained = d->last != nullptr;
+        }
     }
     *out = c;
     return 0;
 }
 
 int vjf_ctx_destroy(vjf_ctx* ctx) {
+    if (ctx)
+        if (DevShared* d = dev_shared(ctx->cfg.device)) {
+            std::lock_guard<std::mutex> lk(d->mu);
+            if (ctx->mega_counted && d->mega_ctxs > 0) --d->mega_ctxs;
+        }
     if (ctx && ctx->comm_a) {
         if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream3); }
         (void)hipStreamSynchronize(ctx->stream);
@@ -556,6 +623,25 @@ int vjf_set_stream(vjf_ctx* ctx, void* stream) {
     return 0;
 }
 
+namespace {
+// A wait of an earlier call of this context gave up (the device said so through the host page, vjf_plan.h): this call must not
+// build on its results.  One plain load of host memory in the usual case.
+int refuse_if_poisoned(vjf_ctx* c, const char* who) {
+    DevShared* d = dev_shared(c->cfg.device);
+    float* p = c->state + c->plan.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
+    if (!d || !d->mirror_h || __atomic_load_n(d->mirror_h + VJF_MIRROR_SLOT(p), __ATOMIC_RELAXED) == 0u) return 0;
+    float v = 0.f;                                                 // (this context's own word: the slot may be another's)
+    VJF_HIP(hipMemcpyAsync(&v, p, 4, hipMemcpyDeviceToHost, c->stream));
+    VJF_HIP(hipStreamSynchronize(c->stream));
+    const unsigned st = (unsigned)v;
+    if (!(st & VJF_STATUS_WAIT_MASK)) return 0;
+    if (c->on_mega) c->mega_ok = false;                            // (the one-launch route did not hold on this device: per-step kernels from here)
+    return fail(-30, "%s: a device-side wait of an earlier call of this context timed out (status 0x%x%s); its outputs and what it left "
+                     "of the state are not to be used -- read the status (vjf_get_status), restore the state, run again", who, st,
+                (st & VJF_STATUS_NOT_RESIDENT) ? ": the grid was not resident as a whole, the state is untouched" : "");
+}
+}  // namespace
+
 int vjf_get_status(vjf_ctx* ctx, uint32_t* status) {
     if (!ctx || !status) return fail(-1, "vjf_get_status: null argument");
     float* p = ctx->state + ctx->plan.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
@@ -564,6 +650,11 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status) {
     VJF_HIP(hipMemsetAsync(p, 0, 4, ctx->stream));
     VJF_HIP(hipStreamSynchronize(ctx->stream));
     *status = (uint32_t)v;
+    if (*status & VJF_STATUS_WAIT_MASK) {
+        if (ctx->on_mega) ctx->mega_ok = false;                    // (see refuse_if_poisoned)
+        if (DevShared* d = dev_shared(ctx->cfg.device))
+            if (d->mirror_h) __atomic_store_n(d->mirror_h + VJF_MIRROR_SLOT(p), 0u, __ATOMIC_RELAXED);   // acknowledged
+    }
     return 0;
 }
 
@@ -903,6 +994,7 @@ int launch_local(vjf_ctx* c, int32_t B, const float* y, const float* u, const fl
                  const float* eps_s, const float* eps_t, float* mu_t, float* lv_t, uint32_t flags, bool aux_fresh) {
     int rc = check_step_args(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t);
     if (rc) return rc;
+    c->on_mega = false;
     if (c->mfma_trial && !aux_fresh) { rc = refresh_aux(c); if (rc) return rc; }
     rc = launch_trial(c, trial_args(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags), 0, c->stream);
     if (rc) return rc;
@@ -934,7 +1026,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     int rc = check_step_args(c, B, y, u, mu0, lv0, eps, eps + sz, mu, lv);
     if (rc) return rc;
     MegaShape m{};
-    if (!mega_shape(P, B, c->ncu, &m)) return fail(-26, "vjf_filter_seq: %d compute units are too few for the one-launch route", c->ncu);
+    if (!mega_shape(P, B, c->ncu, flags, &m)) return fail(-26, "vjf_filter_seq: %d compute units are too few for the one-launch route", c->ncu);
     VJF_HIP(hipSetDevice(c->cfg.device));
     // (parameters that fit the trial role's LDS: it reads the image the SGD role builds at the start of the launch; else the state
     //  and its transposed copies, refreshed here)
@@ -950,6 +1042,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     VjfMegaArgs A{};
     A.T = T; A.B = B; A.ntiles = m.ntiles;
     A.n_rls = m.n_rls; A.n_trial = m.n_trial; A.n_gram = m.n_gram; A.n_prep = m.n_prep; A.n_sgd = m.n_sgd;
+    A.n_sgd_live = (flags & VJF_FLAG_SGD) ? m.n_sgd : 1;
     A.y = y; A.u = u; A.eps = eps; A.mu0 = mu0; A.lv0 = lv0; A.mu = mu; A.lv = lv; A.loss = loss;
     A.state = c->state; A.aux = (float*)(c->ws + c->cv.aux);
     A.img = (const float*)(c->ws + c->cv.mg_img);
@@ -962,7 +1055,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     const bool acq = c->handoff_acquire;                                   // (VJF_HANDOFF_ACQUIRE, read when the context is created)
     if (acq) A.flags |= VJF_FLAG_HANDOFF_ACQUIRE;
     A.slab_len = vjf_mega_slab_layout(P).len;
-    A.early_len = ((P.n + 3) & ~3) * 16 + 8; A.late_len = A.slab_len + 8;
+    A.early_len = ((P.n + 3) & ~3) * 16 + 8; A.late_len = A.slab_len + 8 * VJF_MG_RING;
     A.gram_rows = m.gram_rows;
     A.lds_floats = (int)(kMegaLds / 4) - 8;               // (a few static words beside the dynamic region)
     A.sl_pidx = (const int*)(c->ws + c->cv.mg_pidx); A.sl_cidx = (const int*)(c->ws + c->cv.mg_cidx); A.sl_grp = (const int*)(c->ws + c->cv.mg_grp);
@@ -1007,12 +1100,28 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     // context leaves this route for good and the caller's entry point goes on with the per-step kernels (nothing of the state
     // has been touched yet).
     const char* refuse = getenv("VJF_DEBUG_REFUSE_COOP");                  // (test hook)
-    if ((refuse && atoi(refuse)) || c->mega_wg_per_cu < 1 || grid > c->mega_wg_per_cu * c->ncu) {
+    const bool full = m.n_rls > 0;                                         // (else: trial and SGD roles only, vjf_mega_lite_kernel)
+    const int per_cu = full ? c->mega_wg_per_cu : c->lite_wg_per_cu;
+    if ((refuse && atoi(refuse)) || per_cu < 1 || grid > per_cu * c->ncu) {
         c->mega_ok = false;
         return kMegaRefused;
     }
-    hipLaunchKernelGGL(vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), kMegaLds, c->stream, Pk, A, C, Q);
+    { const char* ab = getenv("VJF_DEBUG_ABSENT"); A.alive_extra = ab ? atoi(ab) : 0; }
+    if (DevShared* dm = dev_shared(c->cfg.device)) A.host_word = dm->mirror_d ? dm->mirror_d + VJF_MIRROR_SLOT(stw) : nullptr;   // (test hook: the grid waits for workgroups that never come)
+    // the chain of resident grids of this process and device (DevShared): behind the previous one's completion, whichever context's
+    DevShared* d = dev_shared(c->cfg.device);
+    std::unique_lock<std::mutex> chain;
+    hipEvent_t done = nullptr;
+    if (d && d->chained) {
+        chain = std::unique_lock<std::mutex>(d->mu);
+        if (d->last_valid && d->last_stream != c->stream) VJF_HIP(hipStreamWaitEvent(c->stream, d->last, 0));
+        done = d->last;
+    }
+    if (full) VJF_LAUNCH(vjf_mega_kernel, dim3(grid), dim3(VJF_MG_THREADS), kMegaLds, c->stream, done, Pk, A, C, Q);
+    else VJF_LAUNCH(vjf_mega_lite_kernel, dim3(grid), dim3(VJF_MG_THREADS), kMegaLds, c->stream, done, Pk, A);
     const hipError_t le = hipGetLastError();
+    if (done && le == hipSuccess) { d->last_stream = c->stream; d->last_valid = true; }
+    c->on_mega = true;
     if (le == hipErrorLaunchOutOfResources) {
         c->mega_ok = false;
         return kMegaRefused;
@@ -1035,6 +1144,7 @@ int filter_seq_streams(vjf_ctx* c, int32_t T, int32_t B, const float* y, const f
                        const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
     int rc = ensure_stream2(c);
     if (rc) return rc;
+    c->on_mega = false;
     const VjfPlan& P = c->plan;
     const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
     hipStream_t sa = c->stream, sb = c->stream2, sc = c->stream3;
@@ -1158,6 +1268,7 @@ int vjf_filter_local(vjf_ctx* c, int32_t B, const float* y, const float* u, cons
     DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
     VJF_CHAOS_REFRESH(c);
     VJF_HIP(hipSetDevice(c->cfg.device));
+    if (int rp = refuse_if_poisoned(c, "vjf_filter_local")) return rp;
     return launch_local(c, B, y, u, mu_s, lv_s, eps_s, eps_t, mu_t, lv_t, flags, false);
 }
 
@@ -1179,6 +1290,7 @@ int launch_rlsb(vjf_ctx* c, int32_t B_total, uint32_t flags, const float* red, h
     a.Ld = (float*)(c->ws + c->cv.tbig);
     a.Pacc = a.Ld + (size_t)nbl * 1024;
     a.ok = (int*)(c->ws + c->cv.post + (size_t)nbl * 1024 * 4 + VJF_RESID_BLOCKS * 8);
+    { const char* ab = getenv("VJF_DEBUG_RLSC_ABSENT"); a.absent_wg = ab ? atoi(ab) : 0; }
     const bool rls = !(flags & VJF_FLAG_WARM_UP);
     if (rls) {
         const int gx = 512;
@@ -1397,8 +1509,12 @@ bool two_route(const vjf_ctx* c, uint32_t flags) {
            (flags & (VJF_FLAG_UPDATE | VJF_FLAG_WARM_UP)) == VJF_FLAG_UPDATE;
 }
 bool mega_route(const vjf_ctx* c, uint32_t flags) {
-    return c->mega_ok && c->overlap && !c->comm_a && !c->force_streams && (!c->stamps || c->stamps_keep_overlap) &&
-           (flags & (VJF_FLAG_SGD | VJF_FLAG_UPDATE | VJF_FLAG_WARM_UP)) == (VJF_FLAG_SGD | VJF_FLAG_UPDATE);
+    // (every flag set of VJF.filter: sgd + update is the training step; warm-up and update=False drop the RLS, Gram and operand
+    //  roles from the grid; sgd=False the backward pass and the gradient steps)
+    const bool rls = (flags & (VJF_FLAG_UPDATE | VJF_FLAG_WARM_UP)) == VJF_FLAG_UPDATE;
+    if (rls && !(flags & VJF_FLAG_SGD)) return false;                      // (update without sgd, no warm-up: the per-step kernels)
+    if (!rls && c->lite_wg_per_cu < 1) return false;
+    return c->mega_ok && c->overlap && !c->comm_a && !c->force_streams && (!c->stamps || c->stamps_keep_overlap);
 }
 int seq_chunk() {
     // Long sequences go in chunks: the workgroups of one launch stay resident for its whole length, and a compute kernel that
@@ -1413,6 +1529,7 @@ int vjf_filter_step(vjf_ctx* c, int32_t B, const float* y, const float* u, const
     if (!c) return fail(-1, "vjf_filter_step: null context");
     DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
     VJF_CHAOS_REFRESH(c);
+    if (int rp = refuse_if_poisoned(c, "vjf_filter_step")) return rp;
     if (mega_route(c, flags) && eps_s && eps_t && eps_t == eps_s + (size_t)B * c->plan.dz) {        // (the sequence layout of eps: (2, B, dz))
         const int rc = filter_seq_mega(c, 1, B, y, u, eps_s, mu_s, lv_s, mu_t, lv_t, loss4, flags);
         if (rc != kMegaRefused) return rc;
@@ -1449,6 +1566,7 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
     DeviceGuard on_device(c->cfg.device);                   // (every launch below goes to the context's device, whatever is current)
     VJF_CHAOS_REFRESH(c);
     if (T < 1) return fail(-23, "vjf_filter_seq: T=%d", T);
+    if (int rp = refuse_if_poisoned(c, "vjf_filter_seq")) return rp;
     if (!y || !eps || !mu || !lv) return fail(-1, "vjf_filter_seq: null tensor");
     const size_t sy = (size_t)B * c->plan.dy, su = (size_t)B * c->plan.du, sz = (size_t)B * c->plan.dz;
     const bool streams = (c->comm_a || c->force_streams) && c->overlap && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP) &&

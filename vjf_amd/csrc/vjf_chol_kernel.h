@@ -926,7 +926,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                     const int gi = s_bi[b] * 32 + r, gj = s_bj[b] * 32 + c4;
                     if (gi < n && gj < n) {
                         float4 pv = *reinterpret_cast<const float4*>(A.pscr + (size_t)idx * 4);
-                        const float4 gv = *reinterpret_cast<const float4*>(G + (size_t)gi * n + gj);
+                        const float4 gv = g4(gi, gj);          // (another role's stores on the one-launch route: an sc1 load there, found by tools/audit_plain_loads.py)
                         pv.x = fmaf(-gv.x, inv_v, pv.x); pv.y = fmaf(-gv.y, inv_v, pv.y); pv.z = fmaf(-gv.z, inv_v, pv.z); pv.w = fmaf(-gv.w, inv_v, pv.w);
                         *reinterpret_cast<float4*>(A.pscr + (size_t)idx * 4) = pv;
                     }

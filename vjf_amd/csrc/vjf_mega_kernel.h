@@ -35,6 +35,10 @@
 #define VJF_MG_LD 33                 // LDS matrices are feature-major [feature][32 trials + 1 pad]
 #define VJF_MG_GROWS 96              // rows of Phi formed per pass of the Gram role
 #define VJF_MG_MAXQ 4                // 32x32 tiles of Phi^T Phi per wavefront of a Gram workgroup (28 lower tiles / 8)
+#define VJF_MG_RING 32               // loss sums of a late slab: a ring over the steps (a launch without parameter updates has no gate
+                                     // between its steps: the trial role may run this many steps ahead of the role that sums them)
+#define RS_RESID 5                   // late slab only: sum |dx - Phi W|^2 of a workgroup's trials (warm-up: the state-noise update
+                                     // without an RLS update, model.py:373-377 with the old W)
 
 // counters: one per 64-byte line of the block -- times MG_C_SPREAD (experiment: 64 puts every counter into a 4-KB page of its own)
 #ifndef MG_C_SPREAD
@@ -57,12 +61,52 @@ enum {
     MG_C_XT = 240 * MG_C_SPREAD,       // inverse workgroups whose share of xt = w_chol^T is in memory (start of the launch)              target 2 nbl
     MG_C_MASK = 192 * MG_C_SPREAD,     // (step + 1) << 8 | non-finite loss components (1 recon, 2 dynamics, 4 entropy) of the last step that had one
     MG_C_COLFLAGS = 160 * MG_C_SPREAD, // [0 .. VJF_CHOL_MAXBLK]: column flags of the Cholesky loop; [VJF_CHOL_MAXBLK + 2]: its "operands loaded" word
-    MG_C_WORDS = 256 * MG_C_SPREAD
+    MG_C_ALIVE = 256 * MG_C_SPREAD,    // workgroups of the grid that have started (all of them: the launch goes on; else it ends untouched)  target gridDim.x
+    MG_C_WORDS = 272 * MG_C_SPREAD
 };
+
+// The last act of every workgroup of a one-launch grid: if a wait of the launch has been given up (by this workgroup or another),
+// say so where the host sees it without a synchronisation (vjf_plan.h, VJF_MIRROR_SLOT).
+__device__ __forceinline__ void mg_tell_host(const float* status, unsigned* host_word) {
+#ifdef VJF_CHAOS
+    // (the diagnostic build goes without: with this routine behind the roles hipcc (ROCm 7.2.0) fails in its backend -- "Illegal
+    //  instruction detected: Operand has incorrect register class.  V_CMP_NE_U32_e32 0, $src_shared_base" -- as it did for two other
+    //  harmless edits of this kernel, DESIGN.md section 3 "Toolchain note"; the status word itself still carries the bits)
+    (void)status; (void)host_word;
+#else
+    if (threadIdx.x == 0 && host_word && vjf_abort_seen(status)) __hip_atomic_store(host_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+
+// The first act of every workgroup of a one-launch grid: count itself in and wait until the WHOLE grid has -- every wait of the
+// launch is for a workgroup of the same grid.  Within a process the launches of this route are chained (vjf_abi.hip), so a grid
+// never shares the device with another one of its kind; a grid of ANOTHER process can hold compute units (each of these
+// workgroups wants a whole unit's LDS), and then neither would ever be placed as a whole.  The bound is short (2^17 polls, about a
+// quarter of a second: a grid starts within a microsecond on a free device): the launch ends before any role has written to the
+// state, VJF_STATUS_NOT_RESIDENT says so, and the context takes the per-step kernels from its next call on.
+__device__ __forceinline__ bool mg_grid_resident(unsigned* cnt, float* status, int extra) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt + MG_C_ALIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool there = false;
+        for (unsigned spins = 0; spins < (1u << 17); ++spins) {
+            if (__hip_atomic_load(cnt + MG_C_ALIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x + (unsigned)extra) { there = true; break; }
+            if ((spins & 255u) == 255u && vjf_abort_seen(status)) break;
+            __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
+        }
+        if (!there && !vjf_abort_seen(status)) vjf_status_or(status, VJF_STATUS_RLS_FAILED | VJF_STATUS_NOT_RESIDENT);
+        vjf_s_abort_word = there ? 0 : 1;
+    }
+    __syncthreads();
+    return vjf_s_abort_word == 0;
+}
 
 struct VjfMegaArgs {
     int T, B, ntiles;
     int n_rls, n_trial, n_gram, n_prep, n_sgd;        // grid = their sum
+    unsigned* host_word;                              // this context's word of the pinned host page (null: none), see mg_tell_host
+    int alive_extra;                                  // test hook (VJF_DEBUG_ABSENT=1): workgroups the residency count waits for beyond the grid's own
+    int n_sgd_live;                                   // SGD workgroups that stay for the steps (all of them; ONE when flags has no VJF_FLAG_SGD:
+                                                      // the others only help to build the parameter image at the start of the launch)
     const float* y; const float* u; const float* eps; const float* mu0; const float* lv0;
     float* mu; float* lv; float* loss;
     float* state; float* aux;
@@ -532,13 +576,24 @@ __device__ __forceinline__ void mg_grad_tile(const float* D, int M, int m0, cons
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);                  \
     } while (0)
 
+// RLS = true: the training step (sgd + update, no warm-up) beside the RLS, Gram and operand roles -- every mode switch below is a
+// compile-time constant and the code is what it was before the other flag sets existed.  RLS = false (vjf_mega_lite_kernel: trial
+// and SGD roles only): warm-up, update=False, sgd=False, read from the launch's flags.
+template <bool RLS>
 __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaArgs& A, float* smem, const int wg) {
     constexpr int LD = VJF_MG_LD, NW = VJF_MG_WAVES, NT = VJF_MG_THREADS, TR = VJF_MG_TR;
     const int tid0 = threadIdx.x;
     const int dz = P.dz, dy = P.dy, du = P.du, n = P.n, din = P.din, dxu = P.dxu;
     const float* S = A.state;
     float* SCW = A.state + P.off[VJF_SLOT_SCALARS];
-    const bool warm = false;                           // (this launch only runs sgd + update without warm-up)
+    // what the steps of this launch do (vjf/model.py:179-221: the flags of VJF.filter).  mode_rls: the RLS roles, the Gram and the
+    // operand role exist; without them (warm-up, update=False) W, w_chol are constants of the launch and sigma -- if it moves at all
+    // (warm-up) -- comes from the SGD role with the parameters
+    const bool do_sgd = RLS || (A.flags & VJF_FLAG_SGD) != 0u, do_upd = RLS || (A.flags & VJF_FLAG_UPDATE) != 0u;
+    const bool warm = !RLS && (A.flags & VJF_FLAG_WARM_UP) != 0u;
+    constexpr bool mode_rls = RLS;                     // (the host sends a launch with do_upd && !warm to the full kernel only)
+    const bool gated = RLS || do_sgd || do_upd;        // something another role produces changes between steps
+    const bool want_resid = !RLS && do_upd && warm;
     const unsigned m_dy = mg_magic(dy), m_dz = mg_magic(dz), m_du = mg_magic(du > 0 ? du : 1);
     const VjfMegaTrialLds Lo = vjf_mega_trial_lds<false>(P, A.lds_floats);
     const bool tl = Lo.theta != 0;                    // the optimised parameters are staged in LDS once per step
@@ -625,7 +680,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 if (tid == 0) {
                     bool there = false;
                     for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
-                        if ((int)(__hip_atomic_load(cnt + MG_C_SGD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * (unsigned)A.n_sgd) >= 0) { there = true; break; }
+                        if ((int)(__hip_atomic_load(cnt + MG_C_SGD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * (unsigned)(RLS ? A.n_sgd : A.n_sgd_live)) >= 0) { there = true; break; }
                         if ((spins & 255u) == 255u && vjf_abort_seen(SCW + VJF_SC_STATUS)) break;
                         __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
                     }
@@ -646,7 +701,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 if (!replayed && (mw >> 8) == (unsigned)t) { rbits = mw & 7u; want_replay = true; }
             }
         };
-        if (ts >= A.T) gate();                         // (behind the last step: only that)
+        if (ts >= A.T && gated) gate();                // (behind the last step: only that)
         int it = 0;
         for (int tile = wg; tile < A.ntiles && ts < A.T; tile += A.n_trial, ++it) {
             const bool first = it == 0, last = it == ntl - 1;
@@ -720,8 +775,15 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             //      already: its acquire and the L2 warm-up then cost nothing on the path parameters -> forward -> backward.  If not,
             //      the same happens behind the forward pass (below): the values read are the same either way.
             if (first && !replay) {
-                rls_in = t == 0;
-                if (t > 0) {
+                rls_in = t == 0 || !mode_rls;
+                // (no parameter updates at all: nothing holds this role back between steps but the ring of loss sums -- the role
+                //  that sums them must be through with the slot this step will write)
+                if (!gated && t >= VJF_MG_RING) {
+                    if (!vjf_wg_wait_sc1(cnt + MG_C_SGD, (unsigned)(t - VJF_MG_RING + 1) * (unsigned)A.n_sgd_live, tid, SCW + VJF_SC_STATUS))
+                        vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
+                    if (vjf_abort_wg()) return;
+                }
+                if (t > 0 && mode_rls) {
                     if (tid == 0) {
                         const bool there = (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
                         if (there && (A.flags & VJF_FLAG_HANDOFF_ACQUIRE)) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -736,16 +798,98 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;               // w_chol known upper triangular
                 }
                 if (t == 0) {                                                 // (the row-major copy of L^-1 of this launch: the inverse loops' first act)
-                    if (!vjf_wg_wait_sc1(cnt + MG_C_XT, (unsigned)(A.n_rls - 2), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                    if (!mode_rls) {
+                        // no RLS roles in this launch: w_chol is a constant of it, and the trial workgroups transpose a share each
+                        const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
+                        float* xtw = const_cast<float*>(A.xt);
+                        for (int e = wg * NT + tid; e < n * n; e += A.n_trial * NT) {
+                            const int k = e / n, j = e - k * n;
+                            mg_st(xtw + (size_t)j * n + k, Wc[e]);
+                        }
+                        // (a launch without a gate: the step tags of this workgroup's ring start at 0 -- the role that polls them
+                        //  waits for this count first, so it never meets a tag of an earlier launch)
+                        if (!gated && tid < VJF_MG_RING) mg_st(late + A.slab_len + 8 * tid + 7, 0.f);
+                        vjf_wg_signal_wt(cnt + MG_C_XT, tid);
+                    }
+                    if (!vjf_wg_wait_sc1(cnt + MG_C_XT, (unsigned)(mode_rls ? A.n_rls - 2 : A.n_trial), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                         vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
                     if (vjf_abort_wg()) return;
                 }
             }
+            // (the two halves of stage 2 as routines: the training kernel runs them behind the RLS hand-off, where they always were;
+            //  a launch without an RLS update has W, w_chol as constants and runs them BEFORE the gate, in the shadow of the SGD role)
+            auto moments_a = [&]() {
+            // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
+            if (!replay) {
+                const __amdgpu_buffer_rsrc_t r_xt = mg_rsrc(A.xt);
+                const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
+                const int ntile = (n + 15) >> 4;
+                float v2a = 0.f, v2b = 0.f;
+                // pt.mean: dz <= 16 rows = one tile, K = n: every wavefront takes a K slice behind its variance tiles; the slice's
+                // operand loads (at most 16 k-steps when n <= 512) go out now, in front of the variance tiles' own
+                const int nsl = min(NW, part_rows / 16);
+                const int msl = nsl - 1 - wave;                                // (the last wavefronts have the lightest variance shares)
+                const int mper = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
+                const int mkb = msl * mper, mke = min(n, (msl + 1) * mper);
+                const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
+                float am[16];
+                if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
+                // tiles in descending cost, dealt to the wavefronts in a snake so that the triangular work balances; a wavefront's tiles of
+                // two rounds go through mg_var2 as one stream of operand batches
+                for (int r = 0; r * NW < ntile; r += 2) {
+                    int j0p[2], Kp[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int rr = r + h, idx = (rr & 1) ? rr * NW + NW - 1 - wave : rr * NW + wave;
+                        const int tt = ntile - 1 - idx;
+                        j0p[h] = (idx < ntile) ? tt * 16 : -1;                  // rows j0 .. j0 + 15 of L^-1 = columns of w_chol
+                        Kp[h] = tri ? min(n, tt * 16 + 16) : n;
+                    }
+                    if (j0p[0] < 0) { j0p[0] = j0p[1]; Kp[0] = Kp[1]; j0p[1] = -1; }
+                    mg_var2(v2a, v2b, r_xt, n, j0p[0], Kp[0], j0p[1], Kp[1], s_phi, lane);
+                }
+                if (first) VJF_MG_STAMP(22);
+                v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
+                v2b += __shfl_xor(v2b, 16, 64); v2b += __shfl_xor(v2b, 32, 64);
+                if (lane < 16) { s_red[wave * TR + lane] = v2a; s_red[wave * TR + 16 + lane] = v2b; }
+                if (wave < nsl) {
+                    const int sl = msl;
+                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, dz, 0, mkb, mke, 0, lane); }
+                    else mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, mkb, mke, lane);
+                    float* pr = s_part + (size_t)(sl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
+                }
+                mean_nsl = nsl;
+            }
+            __syncthreads(); MG_PHASE();
+            };
+            auto moments_b = [&]() {
+            if (!replay) {
+                if (tid < TR) {
+                    float v = 0.f;
+                    for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
+                    s_plv[tid] = logf(v);
+                }
+                for (int e = tid; e < TR * dz; e += NT) {
+                    const int j = e >> 5, b = e & 31;
+                    float v = 0.f;
+                    for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
+                    s_pm[j * LD + b] = s_xu[j * LD + b] + v;
+                    // warm-up: Phi W for the residual dx - Phi W of the state-noise update (model.py:373-374; W is the launch's constant),
+                    // parked in the dmu rows until the loss stage, which has dx, sums the squares
+                    if (want_resid) s_dmu[j * LD + b] = v;
+                }
+            }
+            __syncthreads(); MG_PHASE();
+            };
+            if (!RLS && !replay) { moments_a(); moments_b(); }
             // ---- theta of the previous step.  Nothing above depends on it: the inputs and the features of a step are ready before the
             //      parameters are
             if (first && !replay) {
-                gate();
-                if (t > 0 && vjf_abort_wg()) return;
+                if (gated) gate();
+                if (gated && t > 0 && vjf_abort_wg()) return;
                 if (want_replay) break;                                        // (uniform: every thread read the same word)
                 if (t > 0 && !tl) {
                     mg_warm(A.aux, P.aux_len, wg, tid);                        // (see mg_warm)
@@ -755,6 +899,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             float4 wv[2];
             const bool warm_now = first && !replay && rls_now && !rls_in;      // the RLS update landed while this workgroup waited for the parameters
             if (first && !replay) rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);  // (the SGD role's)
+            if (first && !replay && !mode_rls) sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);   // (warm-up: the SGD role's too; else a constant)
             if (warm_now) {
                 mg_warm_issue(A.xt, P.n * P.n, wg, tid, wv);
                 sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
@@ -905,7 +1050,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             }
             if (first) VJF_MG_STAMP(25);
             // early slab: Phi^T dx of this tile (module.py:94), 16 features x 16 columns per MFMA tile, K = 32 trials
-            if (!replay) {
+            if (!replay && mode_rls) {
                 const int mt = (n + 15) >> 4;
                 for (int tt = NW - 1 - wave; tt < mt; tt += NW) {
                     const int m0 = tt * 16, i = lane & 15, kk = lane >> 4;
@@ -936,7 +1081,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (tid == 0 && first && last && !replay && !rls_in)
                 s_wg[15] = ((int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0) ? 1.f : 0.f;
             __syncthreads(); MG_PHASE();
-            if (tid == 0 && !replay) {
+            if (tid == 0 && !replay && mode_rls) {
                 float v = 0.f;
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + RS_SDX2];
                 s_wg[RS_SDX2] += v;
@@ -950,7 +1095,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             // the wait below lasts ~10 us) the count goes out now -- the Gram role's sums of the next step, and with them the next
             // factorisation, wait for it (measured at configs[0]: 35.2 us a step with the count behind the wait, 30.0 before it).
             const bool fuse_fwd = first && last && !replay && !rls_in && s_wg[15] != 0.f;
-            if (last && !replay && !fuse_fwd) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
+            if (last && !replay && !fuse_fwd && mode_rls) vjf_wg_signal_wt(cnt + MG_C_FWD, tid);
             if (first) VJF_MG_STAMP(4);
             if (last) { VJF_MG_STAMPX(28, -1); VJF_MG_STAMPW(1); }
             // ---- the RLS update of the previous step, if it had not landed before the forward pass
@@ -976,68 +1121,12 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 warm_late = true;
             }
             if (first) { VJF_MG_STAMP(5); VJF_MG_STAMPW(2); }
-            // ---- stage 2: predictive variance sum_j (Phi w_chol)_j^2 (module.py:75-76) and pt.mean = xs + Phi W (module.py:77)
-            if (!replay) {
-                const __amdgpu_buffer_rsrc_t r_xt = mg_rsrc(A.xt);
-                const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
-                const int ntile = (n + 15) >> 4;
-                float v2a = 0.f, v2b = 0.f;
-                // pt.mean: dz <= 16 rows = one tile, K = n: every wavefront takes a K slice behind its variance tiles; the slice's
-                // operand loads (at most 16 k-steps when n <= 512) go out now, in front of the variance tiles' own
-                const int nsl = min(NW, part_rows / 16);
-                const int msl = nsl - 1 - wave;                                // (the last wavefronts have the lightest variance shares)
-                const int mper = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
-                const int mkb = msl * mper, mke = min(n, (msl + 1) * mper);
-                const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
-                float am[16];
-                if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
-                // tiles in descending cost, dealt to the wavefronts in a snake so that the triangular work balances; a wavefront's tiles of
-                // two rounds go through mg_var2 as one stream of operand batches
-                for (int r = 0; r * NW < ntile; r += 2) {
-                    int j0p[2], Kp[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int rr = r + h, idx = (rr & 1) ? rr * NW + NW - 1 - wave : rr * NW + wave;
-                        const int tt = ntile - 1 - idx;
-                        j0p[h] = (idx < ntile) ? tt * 16 : -1;                  // rows j0 .. j0 + 15 of L^-1 = columns of w_chol
-                        Kp[h] = tri ? min(n, tt * 16 + 16) : n;
-                    }
-                    if (j0p[0] < 0) { j0p[0] = j0p[1]; Kp[0] = Kp[1]; j0p[1] = -1; }
-                    mg_var2(v2a, v2b, r_xt, n, j0p[0], Kp[0], j0p[1], Kp[1], s_phi, lane);
-                }
-                if (first) VJF_MG_STAMP(22);
-                v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
-                v2b += __shfl_xor(v2b, 16, 64); v2b += __shfl_xor(v2b, 32, 64);
-                if (lane < 16) { s_red[wave * TR + lane] = v2a; s_red[wave * TR + 16 + lane] = v2b; }
-                if (wave < nsl) {
-                    const int sl = msl;
-                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, dz, 0, mkb, mke, 0, lane); }
-                    else mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, mkb, mke, lane);
-                    float* pr = s_part + (size_t)(sl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
-                }
-                mean_nsl = nsl;
-            }
-            __syncthreads(); MG_PHASE();
+            if (RLS) moments_a();
             if (warm_late) mg_warm_retire(wv_late);
-            if (last && tid == 0 && !replay) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
-            if (!replay) {
-                if (tid < TR) {
-                    float v = 0.f;
-                    for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
-                    s_plv[tid] = logf(v);
-                }
-                for (int e = tid; e < TR * dz; e += NT) {
-                    const int j = e >> 5, b = e & 31;
-                    float v = 0.f;
-                    for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
-                    s_pm[j * LD + b] = s_xu[j * LD + b] + v;
-                }
-            }
-            __syncthreads(); MG_PHASE();
+            if (last && tid == 0 && !replay && mode_rls) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
+            if (RLS) moments_b();
             // pt.mean | pt.logvar of the tile's trials: kept for a replay of this step (by then W and w_chol have moved on)
+            if (do_sgd)
             for (int e = tid; e < TR * (dz + 1); e += NT) {
                 const int j = e >> 5, b = e & 31;
                 if (b < nb) {
@@ -1077,11 +1166,12 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
                 lrec = group_sum<LPT>(lrec);
                 ssey = group_sum<LPT>(ssey);
-                float ldyn = 0.f, ent = 0.f;
+                float ldyn = 0.f, ent = 0.f, rsd = 0.f;
                 {
                     const float p = expf(-0.5f * sig), e = expf(-sig), plv = s_plv[b];
                     for (int j = s; j < dz; j += LPT) {                         // model.py:390-391, functional.py:62-75
                         const float mp = s_pm[j * LD + b], mu = s_mu[j * LD + b], lv = s_lv[j * LD + b];
+                        if (want_resid) { const float r = s_dx[j * LD + b] - s_dmu[j * LD + b]; rsd = fmaf(r, r, rsd); }   // (read before dmu goes there)
                         const float dsc = mp * p - mu * p;
                         const float tr = expf(plv + lv - sig);
                         ldyn += 0.5f * (dsc * dsc + sig) + 0.5f * tr;
@@ -1094,7 +1184,9 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
                 ldyn = group_sum<LPT>(ldyn);
                 ent = group_sum<LPT>(ent);
+                if (want_resid) rsd = group_sum<LPT>(rsd);
                 if (s == 0) {
+                    s_sc[b * RS_N + RS_RESID] = ok ? rsd : 0.f;
                     s_sc[b * RS_N + RS_LRECON] = ok ? lrec : 0.f;
                     s_sc[b * RS_N + RS_LDYN] = ok ? ldyn : 0.f;
                     s_sc[b * RS_N + RS_ENT] = ok ? ent : 0.f;
@@ -1106,7 +1198,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
 #ifdef VJF_EXPERIMENT_SLOW_TRIAL   /* sensitivity experiment: every trial workgroup held for this many 10-ns ticks per step */
             { const unsigned long long t0_ = wall_clock64(); while (wall_clock64() - t0_ < VJF_EXPERIMENT_SLOW_TRIAL) __builtin_amdgcn_s_sleep(1); }
 #endif
-            if (tid < RS_SDX2 && !replay) {                                    // (RS_LRECON, RS_LDYN, RS_ENT, RS_SSEY)
+            if ((tid < RS_SDX2 || (tid == RS_RESID && want_resid)) && !replay) {   // (RS_LRECON, RS_LDYN, RS_ENT, RS_SSEY; the residual)
                 float v = 0.f;
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + tid];
                 s_wg[tid] += v;
@@ -1114,6 +1206,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             // ---- stage 6: backward.  dxt = dpy C ; dmu += dxt ; dlv += dxt eps_t exp(lv/2)/2.  Every product whose A
             //      operand comes from memory runs BEFORE the first gradient tile goes out: a load issued behind write-through stores
             //      waits for them to reach memory (vmcnt counts in order).
+            if (do_sgd) {
             int gbase = 0;                                                     // running tile count: gradient tiles go round the wavefronts
             auto grad_tensor = [&](const float* D, int M, const float* Bact, int Kin, int blkid) {
                 int b_off, b_ldm, b_rows;
@@ -1214,12 +1307,17 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     float* tmp = cur; cur = nxt; nxt = tmp;
                 }
             }
+            }
             if (first) { VJF_MG_STAMP(8); VJF_MG_STAMPW(4); }
             if (last) {
                 // the workgroup's late slab is complete: loss sums, then the signal the SGD role waits for
                 __syncthreads(); MG_PHASE();
-                if (tid < RS_SDX2 && !replay) mg_st(late + A.slab_len + tid, s_wg[tid]);
+                if ((tid < RS_SDX2 || (tid == RS_RESID && want_resid)) && !replay) mg_st(late + A.slab_len + 8 * (tc % VJF_MG_RING) + tid, s_wg[tid]);
                 vjf_wg_signal_wt(cnt + (replay ? MG_C_REDO_B : MG_C_BWD), tid);
+                // No gate between the steps of this launch: the trial workgroups are not in step with each other, and the sum of their
+                // arrivals says nothing about any one of them.  Each tags its slot of the ring with the step instead -- behind its sums
+                // (every wavefront's stores are drained and the barrier of the signal above is behind this lane)
+                if (!gated && tid == 0) mg_st(late + A.slab_len + 8 * (tc % VJF_MG_RING) + 7, (float)(tc + 1));
                 VJF_MG_STAMP(9);
                 VJF_MG_STAMPX(29, 30);
                 VJF_MG_STAMPW(5);
@@ -1603,6 +1701,7 @@ __device__ __forceinline__ void vjf_mega_prep(const VjfPlan& P, const VjfMegaArg
 }
 
 // ------------------------------------------------------------------------------------------------ SGD role
+template <bool RLS>
 __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs& A, float* lds, const int sw) {
     constexpr int NT = VJF_MG_THREADS;
     const int tid = threadIdx.x;
@@ -1614,6 +1713,11 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];
     const bool freeze = SC[VJF_SC_FREEZE_DEC] != 0.f;
     const bool tl = vjf_mega_trial_lds<false>(P, A.lds_floats).theta != 0;   // the trial role reads the LDS image (else: the state and its transposed copies)
+    // the flags of VJF.filter for the steps of this launch (vjf/model.py:179-221; see vjf_mega_trial)
+    const bool do_sgd = RLS || (A.flags & VJF_FLAG_SGD) != 0u, do_upd = RLS || (A.flags & VJF_FLAG_UPDATE) != 0u;
+    const bool warm = !RLS && (A.flags & VJF_FLAG_WARM_UP) != 0u;
+    constexpr bool mode_rls = RLS;
+    const int n_live = RLS ? A.n_sgd : A.n_sgd_live;
     // a quad of the slab (four consecutive output units of one input: vjf_mega_slab_layout) per 8 lanes: lane p sums the late slabs [p npq, (p+1) npq) (16-byte loads, all in flight together with
     // the quad's old values, its table entries and the step's loss sums), then a fixed xor tree; lane 0 of the group clips and
     // steps its four parameters (model.py:210-211)
@@ -1662,6 +1766,12 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
         }
         vjf_wg_signal_wt(A.cnt + MG_C_IMG, tid);
     }
+    if (sw >= n_live) return;                          // (no gradient steps in this launch: one workgroup sums the losses and keeps the scalars)
+    if (!RLS && !do_sgd && !do_upd) {                  // (no gate: step tags instead of counts, cleared by their owners before this count)
+        if (!vjf_wg_wait_sc1(A.cnt + MG_C_XT, (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
+            vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
+        if (vjf_abort_wg()) return;
+    }
     unsigned nredo = 0;
     for (int t = 0; t < A.T; ++t) {
       float l_recon = 0.f, l_dyn = 0.f, ent = 0.f;
@@ -1681,6 +1791,24 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
         if (vjf_abort_wg()) return;                                            // (behind one of the two waits above)
         { const int wg = sw; VJF_MG_STAMP(16); }
         bool have_sums = pass == 1;
+        // loss sums of the step: fp64, 32 strided partial sums per scalar, then a fixed xor tree (every SGD workgroup, for the guards)
+        auto take_sums = [&]() {
+            const int ring = 8 * (t % VJF_MG_RING);
+            if (tid < 32 * 5) {
+                const int sc = tid >> 5, l = tid & 31, slot = sc < RS_SDX2 ? sc : RS_RESID;
+                double d = 0.0;
+                if (sc < RS_SDX2 || (do_upd && warm))
+                    for (int w = l; w < A.n_trial; w += 32) d += (double)mg_ld(A.slab_late + (size_t)w * A.late_len + A.slab_len + ring + slot);
+                d = vjf_sum32(d);
+                // (the residual leaves as the mean square: its sum over 32768 x 16 elements has more digits than a float keeps)
+                if (l == 0) s_sc[slot] = slot == RS_RESID ? (float)(d / ((double)Bf * (double)P.dz)) : (float)d;
+            }
+            __syncthreads();
+            l_recon = s_sc[RS_LRECON] * invB; l_dyn = s_sc[RS_LDYN] * invB; ent = s_sc[RS_ENT] * invB;
+            ok_r = isfinite(l_recon); ok_d = isfinite(l_dyn); ok_h = isfinite(ent);
+            grad_ok = ok_r && ok_h && (warm || ok_d);
+            have_sums = true;
+        };
         // one round: the quads q0 + (tid >> 3).  (Uniform over the workgroup: the first round of a pass holds a barrier.)
         auto round = [&](int q0, const int4& pi, const int4& ci, int grp, float (&wold)[4]) {
             const int quad = q0 + (tid >> 3);
@@ -1691,21 +1819,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
 #pragma unroll
             for (int q = 0; q < 16; ++q)
                 tq[q] = (act && part * npq + q < w1) ? mg_ld4(r_late, src + (part * npq + q) * A.late_len) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!have_sums) {
-                // loss sums of the step: fp64, 32 strided partial sums per scalar, then a fixed xor tree (every SGD workgroup, for the guards)
-                if (tid < 32 * RS_SDX2) {
-                    const int sc = tid >> 5, l = tid & 31;
-                    double d = 0.0;
-                    for (int w = l; w < A.n_trial; w += 32) d += (double)mg_ld(A.slab_late + (size_t)w * A.late_len + A.slab_len + sc);
-                    d = vjf_sum32(d);
-                    if (l == 0) s_sc[sc] = (float)d;
-                }
-                __syncthreads();
-                l_recon = s_sc[RS_LRECON] * invB; l_dyn = s_sc[RS_LDYN] * invB; ent = s_sc[RS_ENT] * invB;
-                ok_r = isfinite(l_recon); ok_d = isfinite(l_dyn); ok_h = isfinite(ent);
-                grad_ok = ok_r && ok_h && ok_d;
-                have_sums = true;
-            }
+            if (!have_sums) take_sums();
             for (int wq = part * npq + 16; wq < w1; wq += 16) {                   // (more than 128 trial workgroups: further rounds)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { v.x += tq[q].x; v.y += tq[q].y; v.z += tq[q].z; v.w += tq[q].w; }
@@ -1748,6 +1862,26 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
                 if (cidx[r] >= 0) mg_st(cdst + cidx[r], wn);
             }
         };
+        if (!do_sgd && !do_upd) {
+            // (no gate in this launch, see vjf_mega_trial: every trial workgroup's tag of this step, one lane per workgroup)
+            bool all = true;
+            for (int w = tid; w < A.n_trial; w += NT) {
+                const float* tag = A.slab_late + (size_t)w * A.late_len + A.slab_len + 8 * (t % VJF_MG_RING) + 7;
+                bool there = false;
+                for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
+                    if (mg_ld(tag) == (float)(t + 1)) { there = true; break; }
+                    if ((spins & 255u) == 255u && vjf_abort_seen(SC + VJF_SC_STATUS)) break;
+                    __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
+                }
+                all = all && there;
+            }
+            if (!__syncthreads_and(all ? 1 : 0)) {
+                if (tid == 0) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
+                return;
+            }
+        }
+        if (!do_sgd) take_sums();
+        else
         for (int q0 = q00; q0 < nquad || q0 == q00; q0 += qstride) {
             int4 pi = k_pi, ci = k_ci; int grp = k_grp;
             float w[4] = {k_w[0], k_w[1], k_w[2], k_w[3]};
@@ -1755,26 +1889,27 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
             round(q0, pi, ci, grp, w);
             if (q0 == q00) { k_w[0] = w[0]; k_w[1] = w[1]; k_w[2] = w[2]; k_w[3] = w[3]; }
         }
-        if (pass == 0 && t == 0 && mg_ld(SC + VJF_SC_TRI_CLEAN) == 0.f) {
+        if (pass == 0 && t == 0 && mode_rls && mg_ld(SC + VJF_SC_TRI_CLEAN) == 0.f) {
             // one-time clearing of the halves the inverse loops never write (block-lower part of w_chol, block-upper part of
             // w_pchol): every reader of the dense w_chol of step 0 has signalled its late slab
             float* Wc = S + P.off[VJF_SLOT_W_CHOL];
             float* Lm = S + P.off[VJF_SLOT_W_PCHOL];
             const int n = P.n;
-            for (int e = sw * NT + tid; e < n * n; e += A.n_sgd * NT) {
+            for (int e = sw * NT + tid; e < n * n; e += n_live * NT) {
                 const int i = e / n, j = e - i * n;
                 if ((i >> 5) < (j >> 5)) mg_st(Lm + e, 0.f);
                 if ((i >> 5) > (j >> 5)) { mg_st(Wc + e, 0.f); mg_st(const_cast<float*>(A.xt) + (size_t)j * n + i, 0.f); }   // (and its row-major transpose)
             }
         }
         const unsigned bad = (ok_r ? 0u : 1u) | (ok_d ? 0u : 2u) | (ok_h ? 0u : 4u);
-        const bool redo = pass == 0 && bad != 0u && bad != 7u;
+        // some, not all, of the components IN the loss are non-finite: the reference steps along the gradient of the others
+        const bool redo = pass == 0 && do_sgd && !grad_ok && (ok_r || ok_h || (!warm && ok_d));
         if (pass == 0 && sw == 0 && tid == 0) {                                // ---- scalars: loss, likelihood log-variance
             if (redo) __hip_atomic_store(A.cnt + MG_C_MASK, ((unsigned)(t + 1) << 8) | bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!ok_r) l_recon = 0.f;
             if (!ok_d) l_dyn = 0.f;
             if (!ok_h) ent = 0.f;
-            const float loss = l_recon - ent + l_dyn;
+            const float loss = warm ? l_recon - ent : l_recon - ent + l_dyn;      // model.py:146-149
             if (A.loss) { float* l4 = A.loss + 4 * (size_t)t; l4[0] = loss; l4[1] = -l_recon; l4[2] = -l_dyn; l4[3] = ent; }
             const unsigned st = (ok_r ? 0u : VJF_STATUS_NONFINITE_RECON) | (ok_d ? 0u : VJF_STATUS_NONFINITE_DYN) |
                                 (ok_h ? 0u : VJF_STATUS_NONFINITE_ENT);
@@ -1782,16 +1917,26 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
             if (P.lik == VJF_LIK_GAUSSIAN) {
                 const float sse_y = s_sc[RS_SSEY];
                 float rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);
-                if (ok_r) {                                                    // (its gradient comes from the reconstruction term alone)
+                if (do_sgd && ok_r) {                                          // (its gradient comes from the reconstruction term alone)
                     float g = 0.5f * ((float)P.dy - expf(-rho) * sse_y * invB);
                     g = fminf(fmaxf(g, -1.f), 1.f);
                     rho -= SC[VJF_SC_LR_LIK] * g;
                 }
-                const float mse = sse_y / (Bf * (float)P.dy);
-                const float acc = fminf(mg_ld(SC + VJF_SC_N_LIK), 1000.f), tot = acc + Bf;
-                rho = logf((acc / tot) * expf(rho) + (Bf / tot) * mse);
-                mg_st(SC + VJF_SC_N_LIK, tot);
-                mg_st(S + P.off[VJF_SLOT_LIK_LOGVAR], rho);
+                if (do_upd) {                                                  // likelihood.py:28-40
+                    const float mse = sse_y / (Bf * (float)P.dy);
+                    const float acc = fminf(mg_ld(SC + VJF_SC_N_LIK), 1000.f), tot = acc + Bf;
+                    rho = logf((acc / tot) * expf(rho) + (Bf / tot) * mse);
+                    mg_st(SC + VJF_SC_N_LIK, tot);
+                }
+                if (do_sgd || do_upd) mg_st(S + P.off[VJF_SLOT_LIK_LOGVAR], rho);
+            }
+            if (do_upd && warm) {
+                // warm-up: no RLS update, the state-noise running variance from the residual with the launch's W (model.py:370-377)
+                const float mse = s_sc[RS_RESID];
+                const float sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
+                const float acc = fminf(mg_ld(SC + VJF_SC_N_TR), 500.f), tot = acc + Bf;          // running_var, size_cap=500 (model.py:375)
+                mg_st(S + P.off[VJF_SLOT_TR_LOGVAR], logf((acc / tot) * expf(sig) + (Bf / tot) * mse));
+                mg_st(SC + VJF_SC_N_TR, tot);
             }
         }
         __syncthreads();
@@ -1802,10 +1947,10 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     }
     // (the launch's last act on the triangle flag: set once every SGD workgroup has cleared its share -- they all have signalled
     //  step 0 by then; the kernel boundary makes it visible to the next launch)
-    if (sw == 0 && tid == 0 && SC[VJF_SC_TRI_CLEAN] == 0.f) {
+    if (sw == 0 && tid == 0 && mode_rls && SC[VJF_SC_TRI_CLEAN] == 0.f) {
         bool there = false;
         for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
-            if ((int)(__hip_atomic_load(A.cnt + MG_C_SGD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)A.n_sgd) >= 0) { there = true; break; }
+            if ((int)(__hip_atomic_load(A.cnt + MG_C_SGD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)n_live) >= 0) { there = true; break; }
             __builtin_amdgcn_s_sleep(2);
         }
         if (there) mg_st(SC + VJF_SC_TRI_CLEAN, 1.f);
@@ -1825,15 +1970,33 @@ __global__ __launch_bounds__(VJF_MG_THREADS) void vjf_mega_kernel(VjfPlan P, Vjf
     // front of a launch
     if (b == A.n_rls + A.n_trial + A.n_gram)
         for (int i = threadIdx.x; i < MG_C_WORDS; i += VJF_MG_THREADS) A.cnt_next[i] = 0u;
-    if (b == 0) { vjf_chol_loop<16>(P, C, lds, &s_dead); return; }
-    if (b == 1) { vjf_rls_post_loop(P, Q, lds, &s_dead, 2, 0); return; }
-    if (b < A.n_rls) { vjf_rls_post_loop(P, Q, lds, &s_dead, 1, b - 2); return; }
-    b -= A.n_rls;
-    if (b < A.n_trial) { vjf_mega_trial(P, A, lds, b); return; }
-    b -= A.n_trial;
-    if (b < A.n_gram) { vjf_mega_gram(P, A, lds, b); return; }
-    b -= A.n_gram;
-    if (b < A.n_prep) { vjf_mega_prep(P, A, lds, b); return; }
-    b -= A.n_prep;
-    vjf_mega_sgd(P, A, lds, b);
+    float* stw = A.state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
+    if (mg_grid_resident(A.cnt, stw, A.alive_extra)) {
+        if (b == 0) vjf_chol_loop<16>(P, C, lds, &s_dead);
+        else if (b == 1) vjf_rls_post_loop(P, Q, lds, &s_dead, 2, 0);
+        else if (b < A.n_rls) vjf_rls_post_loop(P, Q, lds, &s_dead, 1, b - 2);
+        else if ((b -= A.n_rls) < A.n_trial) vjf_mega_trial<true>(P, A, lds, b);
+        else if ((b -= A.n_trial) < A.n_gram) vjf_mega_gram(P, A, lds, b);
+        else if ((b -= A.n_gram) < A.n_prep) vjf_mega_prep(P, A, lds, b);
+        else vjf_mega_sgd<true>(P, A, lds, b - A.n_prep);
+    }
+    mg_tell_host(stw, A.host_word);
+}
+
+// The flag sets of VJF.filter that have no RLS update -- warm_up=True (the first epochs of fit: vjf/model.py:243-259, 148, 370),
+// update=False, sgd=False (a deployed filter: model.py:180, 206, 215) -- as ONE launch too: trial and SGD roles only (W, w_chol are
+// constants of the launch; in warm-up the SGD role's scalar lane also keeps the state-noise variance, from the residual sums the
+// trial role hands over with its loss sums).  Without sgd and update nothing changes between steps and no role waits for another
+// except through the ring of loss sums.
+__global__ __launch_bounds__(VJF_MG_THREADS) void vjf_mega_lite_kernel(VjfPlan P, VjfMegaArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int b = (int)blockIdx.x;
+    if (b == A.n_trial)                                 // (the next launch's counter block: see vjf_mega_kernel)
+        for (int i = threadIdx.x; i < MG_C_WORDS; i += VJF_MG_THREADS) A.cnt_next[i] = 0u;
+    float* stw = A.state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
+    if (mg_grid_resident(A.cnt, stw, A.alive_extra)) {
+        if (b < A.n_trial) vjf_mega_trial<false>(P, A, lds, b);
+        else vjf_mega_sgd<false>(P, A, lds, b - A.n_trial);
+    }
+    mg_tell_host(stw, A.host_word);
 }

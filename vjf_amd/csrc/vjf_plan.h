@@ -222,7 +222,7 @@ __device__ __forceinline__ void vjf_wg_signal(unsigned* count, int tid) {
 __device__ __forceinline__ bool vjf_abort_seen(const float* status) {
     if (!status) return false;
     const float f = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return ((unsigned)f & 0x1ff00u) != 0u;
+    return ((unsigned)f & VJF_STATUS_WAIT_MASK) != 0u;
 }
 // The same verdict for a whole workgroup: the lane that polled in the wait just before (vjf_wg_wait / vjf_wg_wait_sc1, given a status
 // word) read the status word once more behind its poll and left what it saw in this LDS word in front of the wait's barrier --
@@ -250,7 +250,7 @@ __device__ __forceinline__ bool vjf_wg_wait_sc1(const unsigned* count, unsigned 
         there = false;
         for (unsigned spins = 0; spins < (1u << 21); ++spins) {
             if ((int)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { there = true; break; }
-            if ((spins & 255u) == 255u && status && ((unsigned)__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x1ff00u)) break;
+            if ((spins & 255u) == 255u && status && ((unsigned)__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & VJF_STATUS_WAIT_MASK)) break;
             __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
         }
         if (fence) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -289,6 +289,14 @@ __device__ __forceinline__ double vjf_sum32(double v) {
 }
 #endif
 
+// A page of pinned host memory (one per process and device, vjf_abi.hip): every workgroup of a one-launch grid looks at the status
+// word as it leaves, and when a wait has been given up it sets the word its status scalar hashes to -- the host, which does not
+// synchronise between calls, learns of it at the start of the context's next call from a plain load (VJF_MIRROR_SLOT on both
+// sides; a collision costs another context one status read, nothing else).  [The store used to sit in vjf_status_or itself, behind
+// a __device__ pointer: in the diagnostic build that made this compiler's backend fail -- "Illegal instruction detected: Operand has
+// incorrect register class.  V_CMP_NE_U32_e32 0, $src_shared_base" -- whatever form the store took.]
+#define VJF_MIRROR_WORDS 256
+#define VJF_MIRROR_SLOT(status_ptr) ((unsigned)(((uintptr_t)(status_ptr)) >> 4) & (VJF_MIRROR_WORDS - 1))
 // OR status bits into the status scalar (a float holding a small integer).  Kernels of one step may run on two
 // streams (vjf_filter_seq), so the read-modify-write is a compare-and-swap loop.
 __device__ __forceinline__ void vjf_status_or(float* p, unsigned bits) {

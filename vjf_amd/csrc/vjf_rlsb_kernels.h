@@ -26,6 +26,7 @@ struct VjfRlsbArgs {
     float* Pacc;         // 2 x nbl tiles (accumulator order): the sums the ahead role leaves for column k (set k & 1)
     int* ok;             // [0]: 1 while every pivot so far was positive
     int k;               // block column (factorisation) or block row (inverse) of this launch
+    int absent_wg;       // test hook (VJF_DEBUG_RLSC_ABSENT = w + 1): workgroup w of the resident column loop leaves at once
 };
 
 // Loads and stores of the column sequence.  WT = false: plain (one launch per step: the kernel boundary makes them visible);
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_loop_kernel(VjfPlan
     __shared__ __attribute__((aligned(16))) VjfRlscLds L;
     __shared__ int s_go;
     if (A.ok[0] == 0) return;
+    if (A.absent_wg > 0 && (int)blockIdx.x == A.absent_wg - 1) return;   // (test hook, VJF_DEBUG_RLSC_ABSENT: this workgroup never arrives)
     const int nbl = (P.n + 31) / 32, tid = threadIdx.x;
     for (int k = 0; k <= nbl; ++k) {
         rlsc_col_step<true>(P, A, k, (int)blockIdx.x, L);
@@ -336,13 +338,21 @@ __global__ __launch_bounds__(VJF_RLSC_THREADS) void vjf_rlsc_loop_kernel(VjfPlan
             bool there = false;
             for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
                 if ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { there = true; break; }
+                if ((spins & 255u) == 255u && vjf_abort_seen(A.state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS)) break;
                 __builtin_amdgcn_s_sleep(VJF_RLSC_BARRIER_SLEEP);
             }
             s_go = there ? 1 : 0;
         }
         __syncthreads();
-        // (a wait that ran out: a workgroup of this launch was never placed -- the update is dropped like one with a failed pivot)
-        if (!s_go) { if (tid == 0) __hip_atomic_store(A.ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        // (a wait that ran out: a workgroup of this launch was never placed -- the update is dropped like one with a failed pivot, and,
+        //  unlike a failed pivot, the status word carries a wait bit: check_status() raises, the sequence does not go on unnoticed)
+        if (!s_go) {
+            if (tid == 0) {
+                __hip_atomic_store(A.ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vjf_status_or(A.state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_COLUMN);
+            }
+            return;
+        }
         if (__hip_atomic_load(A.ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     }
 }

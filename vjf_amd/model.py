@@ -687,7 +687,7 @@ class VJF(Module):
         return mu, lv, loss
 
     # sticky status bits that mean "the results of the call are not to be used" (include/vjf_hip.h: VJF_STATUS_WAIT_*)
-    _WAIT_BITS = 0x1ff00
+    _WAIT_BITS = 0x3ff00
 
     def check_status(self) -> int:
         """Read (and clear) the device's sticky status word -- one host synchronisation.  'RLS failed.' is warned about as the
