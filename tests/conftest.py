@@ -27,3 +27,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU runs: the achieved parity margins of every comparison (tests/margins.py) -> gpurun_out/parity_margins.json"""
+    try:
+        from tests import margins
+        if margins.RECORDS and _has_gpu():
+            margins.dump(os.path.join(ROOT, "gpurun_out", "parity_margins.json"))
+    except Exception:
+        pass

@@ -4,6 +4,7 @@ import torch
 
 from oracle import vjf_oracle as orc
 from tests import goldenio as gio
+from tests.margins import check_close
 
 
 def _set(t, a):
@@ -61,6 +62,10 @@ LOOSE = ("w_mean", "w_chol", "w_pchol", "w_precision")
 
 def state_close(model, ref, *, rtol, atol, rls_rtol=None, rls_atol=None, prefix=None):
     """Compare the model's device state with an OracleState (ref) or fixture arrays (ref=z, prefix)."""
+    import inspect
+    import os
+    fr = inspect.stack()[1]
+    site = f"{os.path.basename(fr.filename)}:{fr.lineno}"
     got = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in model_arrays(model).items()}
     if prefix is None:
         want = gio.state_arrays(ref)
@@ -72,5 +77,5 @@ def state_close(model, ref, *, rtol, atol, rls_rtol=None, rls_atol=None, prefix=
             continue
         rt = (rls_rtol or rtol) if k in LOOSE else rtol
         at = (rls_atol or atol) if k in LOOSE else atol
-        np.testing.assert_allclose(got[k], np.asarray(want[k], np.float64).reshape(got[k].shape), rtol=rt, atol=at,
-                                   err_msg=f"state tensor {k}")
+        check_close(got[k], np.asarray(want[k], np.float64).reshape(got[k].shape), rtol=rt, atol=at, err_msg=f"state tensor {k}",
+                    what=f"{site} state tensor {k}" + (" [rls]" if k in LOOSE else ""))

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from oracle import vjf_oracle as orc
+from tests.margins import check_close
 from tests.helpers import load_oracle_state, state_close
 
 pytestmark = pytest.mark.gpu
@@ -19,7 +20,7 @@ pytestmark = pytest.mark.gpu
 def close(a, b, **kw):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b
-    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), **kw)
+    check_close(np.asarray(a, np.float64), np.asarray(b, np.float64), **kw)      # (asserts, and records the achieved margin)
 
 
 @pytest.fixture(scope="module")
@@ -86,11 +87,11 @@ def test_sequence_at_bench_size_bitwise_and_oracle(vjf, cfg):
     for t in range(T):
         o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
         om, ol = o.mu_t, o.lv_t
-        close(mu[t], o.mu_t, rtol=5e-5, atol=5e-5)
-        close(lv[t], o.lv_t, rtol=5e-5, atol=5e-5)
-        close(loss[t], [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
-    close(m_seq.transition.logvar, s.tr_logvar, rtol=0, atol=5e-5)
-    state_close(m_seq, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3)
+        close(mu[t], o.mu_t, rtol=1e-6, atol=1e-6)
+        close(lv[t], o.lv_t, rtol=1e-6, atol=1e-6)
+        close(loss[t], [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-6, atol=1e-6)
+    close(m_seq.transition.logvar, s.tr_logvar, rtol=0, atol=1e-6)
+    state_close(m_seq, s, rtol=5e-6, atol=1e-6, rls_rtol=5e-3, rls_atol=5e-5)
 
 
 def test_config_E_full_width(vjf):
@@ -107,16 +108,16 @@ def test_config_E_full_width(vjf):
         q, loss, *comp = m.filter(y[t], None, q, verbose=True, eps=(eps[t, 0], eps[t, 1]))
         o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
         om, ol = o.mu_t, o.lv_t
-        close(q.mean, o.mu_t, rtol=5e-5, atol=5e-5)
-        close(q.logvar, o.lv_t, rtol=5e-5, atol=5e-5)
-        close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
+        close(q.mean, o.mu_t, rtol=1e-6, atol=1e-6)
+        close(q.logvar, o.lv_t, rtol=1e-6, atol=1e-6)
+        close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-6, atol=1e-6)
     mu, lv, ls = m.filter_sequence(y[2:], qs=q, eps=eps[2:])
     for t in range(2, T):
         o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
         om, ol = o.mu_t, o.lv_t
-        close(mu[t - 2], o.mu_t, rtol=1e-4, atol=1e-4)
-        close(ls[t - 2], [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-4, atol=1e-4)
-    state_close(m, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3, rls_atol=5e-5)
+        close(mu[t - 2], o.mu_t, rtol=1e-6, atol=1e-6)
+        close(ls[t - 2], [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-6, atol=1e-6)
+    state_close(m, s, rtol=5e-6, atol=1e-6, rls_rtol=5e-5, rls_atol=5e-5)
     assert m.status() == 0
     # RLS failure at 32 block columns
     lr = m.transition.velocity
@@ -149,19 +150,19 @@ def test_config_E_at_bench_size(vjf):
     yd, ed = y.cuda(), eps.cuda()
     q, loss, *comp = m.filter(yd[0], None, None, verbose=True, eps=(ed[0, 0], ed[0, 1]))
     o = orc.filter_step(s, y[0].numpy(), None, None, None, eps[0, 0].numpy(), eps[0, 1].numpy())
-    close(q.mean, o.mu_t, rtol=5e-5, atol=5e-5)
-    close(q.logvar, o.lv_t, rtol=5e-5, atol=5e-5)
-    close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
+    close(q.mean, o.mu_t, rtol=1e-6, atol=1e-6)
+    close(q.logvar, o.lv_t, rtol=1e-6, atol=1e-6)
+    close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-6, atol=1e-6)
     mu, lv, ls = m.filter_sequence(yd[1:], qs=q, eps=ed[1:])
     om, ol = o.mu_t, o.lv_t
     for t in range(1, T):
         o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
         om, ol = o.mu_t, o.lv_t
-        close(mu[t - 1], o.mu_t, rtol=1e-4, atol=1e-4)
-        close(lv[t - 1], o.lv_t, rtol=1e-4, atol=1e-4)
-        close(ls[t - 1], [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-4, atol=1e-4)
-    close(m.transition.logvar, s.tr_logvar, rtol=0, atol=5e-5)
-    state_close(m, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3, rls_atol=5e-5)
+        close(mu[t - 1], o.mu_t, rtol=2e-6, atol=2e-6)
+        close(lv[t - 1], o.lv_t, rtol=2e-6, atol=2e-6)
+        close(ls[t - 1], [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-6, atol=1e-6)
+    close(m.transition.logvar, s.tr_logvar, rtol=0, atol=1e-6)
+    state_close(m, s, rtol=5e-6, atol=1e-6, rls_rtol=5e-5, rls_atol=5e-5)
     assert m.status() == 0 and m.route() == "two-stream"
 
 
@@ -188,10 +189,10 @@ def test_config_D_one_gpu_and_shard_sum(vjf):
         q, loss, *comp = m.filter(yd[t], None, q, verbose=True, eps=(ed[t, 0], ed[t, 1]))
         o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
         om, ol = o.mu_t, o.lv_t
-        close(q.mean, o.mu_t, rtol=5e-5, atol=5e-5)
-        close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
+        close(q.mean, o.mu_t, rtol=1e-6, atol=1e-6)
+        close(torch.stack([loss, *comp]), [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-6, atol=1e-6)
         outs.append((q.mean.clone(), loss.clone()))
-    state_close(m, s, rtol=5e-4, atol=5e-5, rls_rtol=5e-3)
+    state_close(m, s, rtol=5e-6, atol=1e-6, rls_rtol=5e-4, rls_atol=5e-6)
     mu, lv, ls = m_seq.filter_sequence(yd, eps=ed)
     assert torch.equal(mu[1], outs[1][0]) and torch.equal(ls[1, 0], outs[1][1])
     assert torch.equal(m_seq._blob, m._blob) and m_seq.status() == 0
@@ -211,11 +212,11 @@ def test_config_D_one_gpu_and_shard_sum(vjf):
     N.check(L.vjf_filter_global(ctx, B, N.ptr(loss4), flags))
     s_sh = load_oracle_state(_fresh(vjf, c), np.float64)
     o = orc.filter_step(s_sh, y[0].numpy(), None, None, None, eps[0, 0].numpy(), eps[0, 1].numpy())
-    close(mu_s, o.mu_t, rtol=5e-5, atol=5e-5)
-    close(loss4, [o.loss, o.recon, o.dyn, o.entropy], rtol=5e-5, atol=5e-5)
-    state_close(m_sh, s_sh, rtol=5e-4, atol=5e-5, rls_rtol=5e-3)
-    close(mu_s, outs[0][0], rtol=1e-5, atol=1e-5)            # per-trial work does not depend on the shard
-    close(loss4[0], outs[0][1], rtol=1e-5)
+    close(mu_s, o.mu_t, rtol=1e-6, atol=1e-6)
+    close(loss4, [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-6, atol=1e-6)
+    state_close(m_sh, s_sh, rtol=5e-6, atol=1e-6, rls_rtol=5e-4, rls_atol=5e-6)
+    close(mu_s, outs[0][0], rtol=2e-6, atol=2e-6)            # per-trial work does not depend on the shard
+    close(loss4[0], outs[0][1], rtol=1e-6)
 
 
 def _fresh(vjf, c):
@@ -246,9 +247,9 @@ def test_replay_with_several_tiles_per_workgroup(vjf):
         for t in range(1, T):
             o = orc.filter_step(s, y[t].numpy(), None, om, ol, eps[t, 0].numpy(), eps[t, 1].numpy())
             om, ol = o.mu_t, o.lv_t
-            close(mu[t - 1], o.mu_t, rtol=2e-4, atol=2e-4)
-            close(loss[t - 1], [o.loss, o.recon, o.dyn, o.entropy], rtol=2e-4, atol=2e-4)
-        state_close(m, s, rtol=2e-3, atol=2e-4, rls_rtol=2e-2, rls_atol=2e-3)
+            close(mu[t - 1], o.mu_t, rtol=2e-6, atol=2e-6)
+            close(loss[t - 1], [o.loss, o.recon, o.dyn, o.entropy], rtol=2e-6, atol=2e-6)
+        state_close(m, s, rtol=2e-5, atol=2e-6, rls_rtol=2e-4, rls_atol=2e-3)
 
 
 @pytest.mark.gpu

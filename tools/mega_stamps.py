@@ -12,9 +12,10 @@ cfgA = os.environ.get("CFG", "B") == "A"                   # CFG=A: BASELINE con
 dz, dy, n = (10, 200, 200) if cfgC else (3, 10, 100) if cfgA else (10, 50, 200)
 m = vjf_amd.VJF.make_model(dy, dz, 0, n, [20] if cfgA else [128], likelihood="poisson" if cfgC else "gaussian", noise="device")
 y = torch.poisson(torch.rand(T + 8, B, dy, device="cuda")) if cfgC else torch.randn(T + 8, B, dy, device="cuda")
-m.filter_sequence(y[:8])
+FL = {"train": {}, "warmup": dict(warm_up=True), "infer": dict(sgd=False, update=False), "sgd-only": dict(update=False)}[os.environ.get("FLAGS", "train")]   # FLAGS=warmup|infer|sgd-only: the launches without an RLS update
+m.filter_sequence(y[:8], **FL)
 N.check(m._backend().vjf_debug_stamps(m._ctx, 2, None))
-m.filter_sequence(y[8:])
+m.filter_sequence(y[8:], **FL)
 torch.cuda.synchronize()
 ev = []
 TR = ["step start", "theta staged", "features done", "recognition done", "early slab out", "RLS(t-1) there", "var+mean done", "seeds+dxt done",
@@ -35,7 +36,7 @@ for t in range(max(0, T - 6), T):
             ev.append((R[i], t, ("trial: " if i < 11 else "") + nm))
     o = (ctypes.c_uint64 * 32)()
     N.check(m._backend().vjf_debug_stamps(m._ctx, 16 + ((t + 1) & 7), o))      # RLS loops: ring entry = epoch % 8, epoch = step + 1
-    R = list(o)
+    R = list(o) if not FL else [0] * 32                                        # (no RLS roles in those launches)
     for nm, i in (("chol: step start (stat wait)", 0), ("chol: operands + sigma there, chain starts", 1), ("chol: factor done", 2), ("chol: column 0 panel done (before the barrier)", 8), ("chol: column 0 panel barrier passed", 3),
                   ("chol: column 0, block (1,1) updated", 4), ("chol: column 0, chain of block (1,1) done", 5),
                   ("y/W: first column staged", 17), ("y/W: forward done, factor good, trial readers done", 18), ("y/W: backward done", 19),

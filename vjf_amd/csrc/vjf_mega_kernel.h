@@ -884,7 +884,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             }
             __syncthreads(); MG_PHASE();
             };
-            if (!RLS && !replay) { moments_a(); moments_b(); }
+            // (the slab traffic of a step flows through the same L2s and pushes L^-1 out of some of them: the workgroups of an XCD bring it
+            //  back together, a sixteenth each, before they all walk it -- measured without: one XCD's workgroups 12 us late at the gate)
+            if (!RLS && !replay && first) { mg_warm(A.xt, P.n * P.n, wg, tid); mg_warm(S + P.off[VJF_SLOT_W_MEAN], (P.n * P.dz) & ~3, wg, tid); }
+            if (!RLS && !replay) { moments_a(); moments_b(); if (first) VJF_MG_STAMPW(2); }   // (diagnostic: when this workgroup reached the gate)
             // ---- theta of the previous step.  Nothing above depends on it: the inputs and the features of a step are ready before the
             //      parameters are
             if (first && !replay) {
@@ -1120,7 +1123,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 mg_warm_issue(A.xt, P.n * P.n, wg, tid, wv_late);
                 warm_late = true;
             }
-            if (first) { VJF_MG_STAMP(5); VJF_MG_STAMPW(2); }
+            if (first) { VJF_MG_STAMP(5); if (RLS) VJF_MG_STAMPW(2); }
             if (RLS) moments_a();
             if (warm_late) mg_warm_retire(wv_late);
             if (last && tid == 0 && !replay && mode_rls) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
