@@ -228,6 +228,9 @@ def main():
                     help="the flags of VJF.filter the steps run with: train = sgd + update (the headline), warmup = sgd + update + "
                          "warm_up (the first epochs of fit, vjf/model.py:243-259), infer = sgd=False, update=False (a deployed filter), "
                          "sgd-only = sgd, no update")
+    ap.add_argument("--collectives", type=int, default=2, choices=[1, 2],
+                    help="N > 1, in-library route: sums over ranks per step -- 2: [grad | loss sums] and [G | Phi^T dx | sums] on the two "
+                         "chains of the three-stream schedule; 1: the whole reduce buffer in ONE all-reduce (SURVEY 8e), one stream")
     ap.add_argument("--dist-route", default=os.environ.get("VJF_BENCH_ROUTE", "native"), choices=["native", "caller"],
                     help="N > 1: the sums over ranks inside the library (RCCL communicators in the context) or on the caller's side "
                          "(vjf_filter_local / torch.distributed.all_reduce / vjf_filter_global)")
@@ -297,6 +300,8 @@ def main():
             m.set_overlap(False)
         if a.streams_route:
             m.set_overlap(3)
+        if a.collectives == 1:
+            m.set_collectives(1)
         return m
     model = make_model()
     Td = max(T, 100) if a.config == "B" else T                  # (the call-cost measurement behind the timed regions takes 100 steps)
@@ -532,7 +537,7 @@ def main():
                        "flags": a.flags},
             "route": route,
             "dist": None if world == 1 and not a.force_dist else {
-                "sums_over_ranks": a.dist_route, "control_plane": ctrl, "rccl_comm_ranks": rccl_ranks,
+                "sums_over_ranks": a.dist_route, "collectives_per_step": a.collectives, "control_plane": ctrl, "rccl_comm_ranks": rccl_ranks,
                 "ranks_share_a_gpu": bool(shared_gpu), "native_route_error": native_error},
             "repeats": R, "ms_per_step_repeats": [w / K * 1e3 for w in walls], "ms_per_step_median": float(np.median(walls)) / K * 1e3,
             "elbo": elbos[0], "elbo_check": elbo_check, "status_bits": status, "call_cost": call_cost,

@@ -155,7 +155,8 @@ int vjf_get_status(vjf_ctx* ctx, uint32_t* status);
 int vjf_set_overlap(vjf_ctx* ctx, int enable);
 
 /* The route a vjf_filter_seq call with these flags would take now: 1 one-launch, 3 three-stream per-step (with communicators:
- * the RCCL route), 2 per-step with the multi-launch RLS update on a second stream (T > 1), 0 one-stream per-step.
+ * the RCCL route), 2 per-step with the multi-launch RLS update on a second stream (T > 1), 4 per-step with ONE all-reduce per
+ * step (vjf_set_collectives), 0 one-stream per-step.
  * Negative on error. */
 int vjf_route(vjf_ctx* ctx, uint32_t flags);
 
@@ -167,6 +168,12 @@ int vjf_route(vjf_ctx* ctx, uint32_t flags);
  * vjf_filter_global (vjf/model.py has no multi-GPU path: SURVEY 8e). */
 int vjf_comm_unique_id(void* ids256);
 int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world);
+/* How many sums over ranks a step of vjf_filter_seq makes on the in-library route: 2 (default) -- [gradients | loss sums] on the
+ * trial chain and [Phi^T Phi | Phi^T dx | sum |dx|^2] on the statistics chain of the three-stream schedule, overlapping each other
+ * and the other chain's kernels -- or 1: the whole reduce buffer in ONE all-reduce between the trial-parallel and the serial half
+ * of the step (SURVEY.md 8e's packed layout; any flags, one stream, no overlap of the two chains).  Same results to summation
+ * order.  Also: VJF_COLLECTIVES=1 in the environment when the context is created. */
+int vjf_set_collectives(vjf_ctx* ctx, int32_t per_step);
 /* What RCCL itself says about the context's two communicators: ranks[0], ranks[1] = ncclCommCount of the gradient chain's and of
  * the statistics chain's communicator (0, 0 without communicators).  A benchmark line quotes these, not the launcher's
  * environment. */

@@ -621,6 +621,56 @@ def test_sharded_route_fake_world_of_two(vjf, monkeypatch):
     assert m1.status() == 0 and m2.status() == 0
 
 
+def test_one_collective_per_step_route(vjf, monkeypatch):
+    """`set_collectives(1)` (SURVEY.md 8e's layout: ONE all-reduce of the packed reduce buffer per step, inside the library): with a
+    one-rank communicator it is the one-stream order of the per-step kernels bit for bit (a one-rank sum is the identity), for
+    every flag set; with VJF_DEBUG_FAKE_WORLD=2 it equals the unsharded run on the batch written twice."""
+    import os
+    import torch.distributed as dist
+    z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
+    y, eps = torch.tensor(z["y"][:4]), torch.tensor(z["eps"][:4])
+    refs = {}
+    for name, kw in (("train", {}), ("warmup", dict(warm_up=True))):
+        m = _model_for(vjf, info)
+        load_fixture_state(m, z, "s0")
+        m.set_overlap(False)
+        refs[name] = (m.filter_sequence(y, None, None, eps=eps, **kw), m._blob.clone())
+    m_twice = _model_for(vjf, info)
+    load_fixture_state(m_twice, z, "s0")
+    o_twice = m_twice.filter_sequence(torch.cat([y, y], 1), None, None, eps=torch.cat([eps, eps], 2))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    os.environ["VJF_FORCE_DIST"] = "1"
+    try:
+        for name, kw in (("train", {}), ("warmup", dict(warm_up=True))):
+            m = _model_for(vjf, info)
+            load_fixture_state(m, z, "s0")
+            m.set_collectives(1)
+            o = m.filter_sequence(y, None, None, eps=eps, **kw)
+            torch.cuda.synchronize()
+            assert m.route(**{"warm_up": kw.get("warm_up", False)}) == "packed" and m.comm_ranks() == [1, 1]
+            for a_, b_ in zip(o, refs[name][0]):
+                assert torch.equal(a_, b_)
+            assert torch.equal(m._blob, refs[name][1]) and m.status() == 0
+            m.close()
+        monkeypatch.setenv("VJF_DEBUG_FAKE_WORLD", "2")
+        m2 = _model_for(vjf, info)
+        load_fixture_state(m2, z, "s0")
+        m2.set_collectives(1)
+        o2 = m2.filter_sequence(y, None, None, eps=eps)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("VJF_FORCE_DIST", None)
+        dist.destroy_process_group()
+    B = y.shape[1]
+    close(o_twice[0][:, :B], o2[0], rtol=2e-6, atol=2e-6)
+    close(o_twice[2], o2[2], rtol=2e-6, atol=2e-6)
+    close(m_twice._blob, m2._blob, rtol=2e-4, atol=2e-6)
+    assert m2.status() == 0
+
+
 def test_nonfinite_component_on_the_sharded_route(vjf, monkeypatch):
     """vjf/model.py:138-149 where trials are sharded over ranks (the in-library RCCL route, VJF_DEBUG_FAKE_WORLD=2: two ranks holding
     the same trials): with `exact_nonfinite` the step whose dynamics term overflows is replayed -- the verdict is taken on the summed

@@ -60,6 +60,7 @@ SIGNATURES = {
     "vjf_comm_unique_id": [_P],
     "vjf_comm_init": [_P, _P, _I, _I],
     "vjf_comm_ranks": [_P, C.POINTER(_I)],
+    "vjf_set_collectives": [_P, _I],
     "vjf_debug_stamps": [_P, _I, C.POINTER(C.c_uint64)],
     "vjf_filter_step": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U],
     "vjf_filter_local": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _U],

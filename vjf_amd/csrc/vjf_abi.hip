@@ -222,6 +222,34 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, uint32_t flags, MegaShape* m) 
     if (cap_t < 1) cap_t = 1;
     if (cap_t > kMegaMaxTrialWg) cap_t = kMegaMaxTrialWg;
     m->n_trial = m->ntiles < cap_t ? m->ntiles : cap_t;
+    if (m->ntiles > cap_t) {
+        // More tiles than the trial role's usual share of the chip (B > 4096 at 256 compute units: BASELINE configs[3] on ONE GPU has
+        // 1024): the step is then the trial role's tiles in sequence (~41 us each) plus the SGD role's loop, and the other roles have
+        // slack -- the SGD role may take two or three rounds of slab loads (+7 us each, once per step), the Gram role several
+        // passes of rows (22 us each, a step ahead).  The fewest tiles per trial workgroup that leave those two enough workgroups:
+        const int quads = vjf_mega_slab_layout(P).len / 4, gpw = VJF_MG_THREADS / 8, want = (quads + gpw - 1) / gpw;
+        int big_sgd = 0, big_gram = 0;
+        for (int ntl = (m->ntiles + cap_t - 1) / cap_t; ntl >= 1; --ntl) {
+            int nt = (m->ntiles + ntl - 1) / ntl;
+            if (nt > kMegaMaxTrialWg || nt > rest - 2) break;
+            bool found = false;
+            for (int rounds = 1; rounds <= 3 && !found; ++rounds) {
+                const int ns = (want + rounds - 1) / rounds;
+                int ng = rest - nt - ns;
+                if (ng > kMegaMaxGramWg) ng = kMegaMaxGramWg;
+                if (ng < nbl * (nbl + 1) / 2) continue;                        // (one Gram workgroup per lower tile at least: the slab sum's shares)
+                const int passes = ((B + ng - 1) / ng + VJF_MG_GROWS - 1) / VJF_MG_GROWS;
+                const double cycle = 41.0 * ntl + 12.0 + 7.0 * (rounds - 1), gram = 22.0 * passes + 17.0;
+                if (gram <= 0.95 * cycle) { m->n_trial = nt; big_sgd = ns; big_gram = ng; found = true; }
+            }
+            if (!found) break;
+        }
+        if (big_sgd > 0) {
+            m->n_sgd = big_sgd; m->n_gram = big_gram;
+            m->gram_rows = ((B + m->n_gram - 1) / m->n_gram + 1) & ~1;
+            return true;
+        }
+    }
     const int left = rest - m->n_trial;                                               // >= 2
     // SGD role: one 8-lane group per quad of the late slab and ROUND of slab loads; its time is the bytes of the slabs over the
     // compute units it has (a unit takes in ~33 GB/s of slabs written on other XCDs), so the fewest rounds win.  The Gram role
@@ -346,6 +374,9 @@ struct vjf_ctx {
     bool on_mega;          // the context's last sequence ran on the one-launch route (a timed-out wait then makes it leave the route)
     void* comm_a; void* comm_b;   // RCCL communicators of the two chains of the three-stream route (null: single rank)
     int world;
+    int collectives;       // sums over ranks per step on the in-library route: 2 (default) [grad | loss sums] and [G | Phi^T dx | sums], one on each
+                           // chain of the three-stream schedule; 1 ONE all-reduce of the whole reduce buffer (SURVEY 8e's layout) between the
+                           // trial-parallel and the serial half of a step, on one stream (vjf_set_collectives)
     int fake_world;        // test hook (VJF_DEBUG_FAKE_WORLD=k at vjf_comm_init, one-rank communicators): behave as rank 0 of k ranks that
                            // all hold the same trials -- every all-reduced buffer is multiplied by k and B_total = k B
 };
@@ -439,7 +470,8 @@ int vjf_ctx_create(const vjf_config* cfg, float* state, void* workspace, int64_t
     c->stream2 = c->stream3 = nullptr; c->ev_s = c->ev_c = nullptr;
     for (int i = 0; i < 2; ++i) c->ev_f[i] = c->ev_r[i] = c->ev_b[i] = c->ev_g[i] = nullptr;
     c->epoch = 0; c->k1_count = 0; c->post_count = 0; c->fwd_count = 0; c->stats_count = 0;
-    c->comm_a = c->comm_b = nullptr; c->world = 1; c->fake_world = 1;
+    c->comm_a = c->comm_b = nullptr; c->world = 1; c->fake_world = 1; c->collectives = 2;
+    if (const char* ce = getenv("VJF_COLLECTIVES")) { if (atoi(ce) == 1) c->collectives = 1; }
     hipError_t e = hipMemcpyAsync(c->ws + cv.jobs, jobs.data(), jobs.size() * sizeof(VjfJob), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red, 0, (size_t)P.red_len * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->ws + cv.red2, 0, (size_t)P.red_len * 4, c->stream);
@@ -590,7 +622,7 @@ int vjf_comm_init(vjf_ctx* ctx, const void* ids256, int32_t rank, int32_t world)
     if (world < 1 || rank < 0 || rank >= world) return fail(-20, "vjf_comm_init: rank %d of %d", rank, world);
     if (!nccl().ok) return fail(-111, "vjf_comm_init: RCCL is not available in this process");
     if (ctx->comm_a) return fail(-112, "vjf_comm_init: the context already has communicators");
-    if (!(ctx->fast_chol && ctx->post_kernels && ctx->mfma_trial))
+    if (ctx->collectives != 1 && !(ctx->fast_chol && ctx->post_kernels && ctx->mfma_trial))
         return fail(-113, "vjf_comm_init: this plan has no multi-stream route; keep the all-reduce on the caller's side (vjf_filter_local / vjf_filter_global)");
     VJF_HIP(hipSetDevice(ctx->cfg.device));
     VjfNcclId ids[2];
@@ -614,6 +646,13 @@ int vjf_comm_ranks(vjf_ctx* ctx, int32_t* ranks2) {
     VJF_NCCL(nccl().comm_count(ctx->comm_a, &na));
     VJF_NCCL(nccl().comm_count(ctx->comm_b, &nb));
     ranks2[0] = na; ranks2[1] = nb;
+    return 0;
+}
+
+int vjf_set_collectives(vjf_ctx* ctx, int32_t per_step) {
+    if (!ctx) return fail(-1, "vjf_set_collectives: null context");
+    if (per_step != 1 && per_step != 2) return fail(-20, "vjf_set_collectives: %d (1 or 2)", per_step);
+    ctx->collectives = per_step;
     return 0;
 }
 
@@ -1394,6 +1433,35 @@ int filter_global_impl(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags
     VJF_HIP(hipGetLastError());
     return 0;
 }
+// ---- the same sums as ONE collective per step ("one ncclAllReduce(sum, fp32) per step between K1 and K2 on the packed
+//      buffer"): the trial-parallel half of step t, one all-reduce of the whole reduce buffer [grad | loss sums | G | Phi^T dx | sums],
+//      the serial half -- on the caller's stream, in the one-stream order.  Fewer collectives (one latency of the ring per step
+//      instead of two on two chains), no overlap of the RLS chain with the trial chain: which of the two wins at 8 ranks is for the
+//      first 8-GPU run to say (bench.py --collectives 1|2).  Same kernels and sums as vjf_filter_local / vjf_filter_global around
+//      a caller's all-reduce, bit for bit.
+int filter_seq_packed(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float* u, const float* eps, const float* mu0,
+                      const float* lv0, float* mu, float* lv, float* loss, uint32_t flags) {
+    const VjfPlan& P = c->plan;
+    const size_t sy = (size_t)B * P.dy, su = (size_t)B * P.du, sz = (size_t)B * P.dz;
+    const int fw = c->fake_world;
+    const int Bt = B * c->world * fw;
+    float* red = (float*)(c->ws + c->cv.red);
+    const float* ms = mu0; const float* ls = lv0;
+    c->on_mega = false;
+    for (int t = 0; t < T; ++t) {
+        const bool fresh = t > 0 && c->fast_chol;
+        int rc = launch_local(c, B, y + t * sy, u ? u + t * su : nullptr, ms, ls, eps + (size_t)t * 2 * sz, eps + (size_t)t * 2 * sz + sz,
+                              mu + t * sz, lv + t * sz, flags, fresh);
+        if (rc) return rc;
+        VJF_NCCL(nccl().all_reduce(red, red, (size_t)P.red_len, kNcclFloat, kNcclSum, c->comm_a, c->stream));
+        if (fw > 1) hipLaunchKernelGGL(vjf_scale_kernel, dim3(64), dim3(256), 0, c->stream, red, (float)fw, (int)P.red_len);   // (test hook)
+        rc = filter_global_impl(c, Bt, loss ? loss + 4 * (size_t)t : nullptr, flags, nullptr);
+        if (rc) return rc;
+        ms = mu + t * sz; ls = lv + t * sz;
+    }
+    return 0;
+}
+
 }  // namespace
 
 int vjf_filter_global(vjf_ctx* c, int32_t B_total, float* loss4, uint32_t flags) {
@@ -1554,6 +1622,7 @@ int vjf_filter_step(vjf_ctx* c, int32_t B, const float* y, const float* u, const
 int vjf_route(vjf_ctx* c, uint32_t flags) {
     if (!c) return fail(-1, "vjf_route: null context");
     if (mega_route(c, flags)) return 1;
+    if (c->comm_a && c->collectives == 1) return 4;
     const bool streams = (c->comm_a || c->force_streams) && c->overlap && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP) &&
                          c->fast_chol && c->post_kernels && c->mfma_trial && (!c->stamps || c->stamps_keep_overlap);
     if (streams) return 3;
@@ -1571,6 +1640,8 @@ int vjf_filter_seq(vjf_ctx* c, int32_t T, int32_t B, const float* y, const float
     const size_t sy = (size_t)B * c->plan.dy, su = (size_t)B * c->plan.du, sz = (size_t)B * c->plan.dz;
     const bool streams = (c->comm_a || c->force_streams) && c->overlap && T > 1 && (flags & VJF_FLAG_UPDATE) && !(flags & VJF_FLAG_WARM_UP) &&
                          c->fast_chol && c->post_kernels && c->mfma_trial && (!c->stamps || c->stamps_keep_overlap);
+    if (c->comm_a && c->collectives == 1)                                  // (communicators, ONE sum over ranks per step: any flags, any T)
+        return filter_seq_packed(c, T, B, y, u, eps, mu0, lv0, mu, lv, loss, flags);
     if (mega_route(c, flags) || streams) {
         const int32_t chunk = seq_chunk();
         for (int32_t t0 = 0; t0 < T; t0 += chunk) {

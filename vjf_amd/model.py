@@ -321,7 +321,7 @@ class VJF(Module):
                                        | (N.FLAG_WARM_UP if warm_up else 0))
         if rc < 0:
             N.check(rc, "vjf_route")
-        return {1: "one-launch", 2: "two-stream", 3: "streams"}.get(rc, "per-step")
+        return {1: "one-launch", 2: "two-stream", 3: "streams", 4: "packed"}.get(rc, "per-step")
 
     # ------------------------------------------------------------------ state I/O (the reference has no format)
     _RLS_KEYS = ("w_mean", "w_chol", "w_precision", "w_pchol")
@@ -405,6 +405,8 @@ class VJF(Module):
                                  ctypes.byref(ctx)), "vjf_ctx_create")
         self._ctx, self._ctx_batch = ctx, B
         _LIVE.add(self)
+        if getattr(self, "_collectives", 2) != 2:
+            N.check(L.vjf_set_collectives(ctx, int(self._collectives)), "vjf_set_collectives")
         if getattr(self, "_overlap", 1) != 1:
             rc = L.vjf_set_overlap(ctx, int(self._overlap))
             if rc < 0:
@@ -487,6 +489,15 @@ class VJF(Module):
         N.check(L.vjf_comm_init(self._ctx, buf, dist.get_rank(), world), "vjf_comm_init")
         self._comm_ok = True
         return True
+
+    def set_collectives(self, per_step: int = 2):
+        """Sums over ranks per step on the in-library RCCL route: 2 (two all-reduces on two overlapping chains, default) or 1 (the
+        whole reduce buffer in one).  Takes effect from the next call."""
+        if per_step not in (1, 2):
+            raise ValueError("per_step must be 1 or 2")
+        self._collectives = per_step
+        if self._ctx is not None:
+            N.check(self._backend().vjf_set_collectives(self._ctx, per_step), "vjf_set_collectives")
 
     def comm_ranks(self):
         """[ranks of the gradient chain's communicator, of the statistics chain's] as RCCL reports them (ncclCommCount);
@@ -669,7 +680,7 @@ class VJF(Module):
         flags = self._flags(sgd, update, warm_up)
         L.vjf_set_stream(self._ctx, stream_ptr())
         world, sharded = self._world()
-        if not sharded or (update and not warm_up and T > 1 and self._native_comm(world)):
+        if not sharded or ((getattr(self, "_collectives", 2) == 1 or (update and not warm_up and T > 1)) and self._native_comm(world)):
             # one C-ABI call for the whole sequence; with ranks, the library sums statistics and gradients over them itself
             N.check(L.vjf_filter_seq(self._ctx, T, B, N.ptr(y), N.ptr(u), N.ptr(eps), N.ptr(mu0), N.ptr(lv0), N.ptr(mu), N.ptr(lv),
                                      N.ptr(loss), flags), "vjf_filter_seq")
