@@ -43,6 +43,16 @@ ALLOW = {
     ("vjf_mega_kernel.h", "const float l = mu_s ? mg_ld(lv_s + (size_t)b * dz + c2) : S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c2]; //  behind the waits)"): "const: the prior",
     ("vjf_mega_kernel.h", "v = fmaf(eps_s[(size_t)b * dz + c2], expf(0.5f * l), m);"): "const: the noise input",
     ("vjf_mega_kernel.h", "v = u_e[(size_t)b * du + c2 - dz];"): "const: the control input",
+    # ---- moments role, image builders (launches without an RLS update)
+    ("vjf_mega_kernel.h", "else { m = S[P.off[VJF_SLOT_PRIOR_MEAN] + c]; l = S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c]; }"): "const: the prior (the posterior is an sc1 load)",
+    ("vjf_mega_kernel.h", "if (b < nb) ep = eps_s[(size_t)(b0 + b) * dz + c];"): "const: the noise input",
+    ("vjf_mega_kernel.h", "} else if (b < nb) v = u_t[(size_t)(b0 + b) * du + c - dz];"): "const: the control input",
+    ("vjf_mega_kernel.h", "const int4 pi = *reinterpret_cast<const int4*>(A.sl_pidx + (size_t)quad * 4);"): "const: slab tables",
+    ("vjf_mega_kernel.h", "const int4 ci = *reinterpret_cast<const int4*>(A.sl_cidx + (size_t)quad * 4);"): "const: slab tables",
+    ("vjf_mega_kernel.h", "if (pi.x >= 0 && ci.x >= 0) mg_st(img + ci.x, th[pi.x]);"): "const: the parameters of a launch that does not update them",
+    ("vjf_mega_kernel.h", "if (pi.y >= 0 && ci.y >= 0) mg_st(img + ci.y, th[pi.y]);"): "const: as above",
+    ("vjf_mega_kernel.h", "if (pi.z >= 0 && ci.z >= 0) mg_st(img + ci.z, th[pi.z]);"): "const: as above",
+    ("vjf_mega_kernel.h", "if (pi.w >= 0 && ci.w >= 0) mg_st(img + ci.w, th[pi.w]);"): "const: as above",
     # ---- SGD role
     ("vjf_mega_kernel.h", "const float lr_dec = SC[VJF_SC_LR_DEC], lr_rec = SC[VJF_SC_LR_REC];"): "const: set by the host between launches",
     ("vjf_mega_kernel.h", "pi = *reinterpret_cast<const int4*>(A.sl_pidx + (size_t)quad * 4);"): "const: slab tables",

@@ -179,7 +179,7 @@ void build_jobs(const VjfPlan& P, std::vector<VjfJob>& jobs) {
 // ---- the one-launch route (vjf_mega_kernel.h): which plans it serves and how the grid's workgroups are dealt to its roles
 constexpr size_t kMegaLds = kMaxLds - 512;             // dynamic LDS of every workgroup of the launch (one workgroup per CU)
 constexpr int kMegaMaxTrialWg = 256, kMegaMaxGramWg = 64;
-struct MegaShape { int n_rls, n_trial, n_gram, n_prep, n_sgd, ntiles, gram_rows; };
+struct MegaShape { int n_rls, n_trial, n_gram, n_prep, n_sgd, ntiles, gram_rows, n_mom; };
 constexpr int kMegaRefused = 1 << 20;                  // filter_seq_mega: the grid cannot be resident as a whole (not an error code of the ABI)
 
 bool mega_plan_ok(const VjfPlan& P) {
@@ -189,6 +189,7 @@ bool mega_plan_ok(const VjfPlan& P) {
     if (vjf_post_lds_bytes(P) > kMegaLds) return false;
     if ((size_t)vjf_mega_trial_lds(P).total * 4 > kMegaLds) return false;                 // 32 trials' working set
     if (vjf_mega_gram_lds_floats(P) * 4 > kMegaLds || vjf_mega_prep_lds_floats(P) * 4 > kMegaLds) return false;
+    if (vjf_mega_mom_lds_floats(P) * 4 > kMegaLds) return false;
     if (P.du > 16) return false;                                                         // (one element of a 32 x du tile per thread)
     if (nbl * (nbl + 1) / 2 > VJF_MG_WAVES * VJF_MG_MAXQ) return false;
     return true;
@@ -202,6 +203,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, uint32_t flags, MegaShape* m) 
     m->n_rls = rls ? 2 + 2 * nbl : 0;
     m->n_prep = rls ? (P.n + 15) / 16 : 0;
     m->ntiles = (B + VJF_MG_TR - 1) / VJF_MG_TR;
+    m->n_mom = 0;
     const int rest = ncu - m->n_rls - m->n_prep;
     if (rest < 3) return false;
     if (!rls) {
@@ -209,6 +211,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, uint32_t flags, MegaShape* m) 
         // parameter image at the start of the launch), the trial role the rest
         const int quads = vjf_mega_slab_layout(P).len / 4, gpw = VJF_MG_THREADS / 8;
         int want = (quads + gpw - 1) / gpw;
+        if (!(flags & VJF_FLAG_SGD) && want > 16) want = 16;          // (no gradient steps: these only build the parameter image at the start)
         if (want > rest / 4) want = rest / 4;
         if (want < 1) want = 1;
         m->n_sgd = want;
@@ -216,6 +219,18 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, uint32_t flags, MegaShape* m) 
         if (cap > kMegaMaxTrialWg) cap = kMegaMaxTrialWg;
         m->n_trial = m->ntiles < cap ? m->ntiles : cap;
         m->n_gram = 0; m->gram_rows = 0;
+        // the moments role (vjf_mega_moments): the compute units that are left, when they can keep up -- a tile takes such a workgroup
+        // about as long as the rest of the step takes the trial role, so at most two tiles each; else the trial role forms its
+        // moments itself
+        {
+            static const bool off = getenv("VJF_NO_MOMENTS_ROLE") != nullptr;    // (A/B)
+            int nm = rest - m->n_sgd - m->n_trial;
+            if (nm > m->ntiles) nm = m->ntiles;
+            if (!(flags & (VJF_FLAG_SGD | VJF_FLAG_UPDATE))) nm += m->n_sgd;        // (the image builders go on as moments workgroups)
+            if (nm > m->ntiles) nm = m->ntiles;
+            if (!off && nm >= 1 && 2 * nm >= m->ntiles && m->ntiles <= VJF_MG_TAG_TILES && m->n_trial == m->ntiles) m->n_mom = nm;
+            if (m->n_mom > 0 && m->n_sgd > m->n_mom && !(flags & (VJF_FLAG_SGD | VJF_FLAG_UPDATE))) m->n_sgd = m->n_mom;
+        }
         return true;
     }
     int cap_t = rest * 128 / 227;
@@ -278,7 +293,7 @@ bool mega_shape(const VjfPlan& P, int B, int ncu, uint32_t flags, MegaShape* m) 
 }
 
 struct Carve {
-    size_t pscr; size_t mg_xt, mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, resid, total;
+    size_t pscr; size_t mg_mom, mg_xt, mg_early, mg_late, mg_gslab, mg_cnt, mg_stamps, mg_pidx, mg_cidx, mg_grp, mg_img, mg_pmsave; size_t E, E2, ACT, DEL, partial, partial2, slabs, red, red2, red3, tbig, wide, work, jobs, aux, post, lscr, flags, resid, total;
 };
 
 Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
@@ -315,6 +330,11 @@ Carve carve_ws(const VjfPlan& P, int max_batch, int njobs) {
         c.mg_img = take((size_t)vjf_mega_trial_lds(P, (int)(kMegaLds / 4) - 8).th_len * 4 + 64);   // the parameters in the trial role's LDS layout
         c.mg_pmsave = take((size_t)max_batch * (P.dz + 1) * 4);
         c.mg_xt = take((size_t)P.n * P.n * 4);               // row-major L^-1 (= w_chol^T) for the trial role's 16-byte operand loads
+        {   // moments role -> trial role: [tile][step parity][(2 dz + 1) x 32]
+            int nt = (max_batch + VJF_MG_TR - 1) / VJF_MG_TR;
+            if (nt > VJF_MG_TAG_TILES) nt = VJF_MG_TAG_TILES;
+            c.mg_mom = take((size_t)nt * 2 * (2 * P.dz + 1) * VJF_MG_TR * 4);
+        }
     }
     c.jobs = take((size_t)njobs * sizeof(VjfJob));
     c.aux = take((size_t)P.aux_len * 4);
@@ -1082,6 +1102,7 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     A.T = T; A.B = B; A.ntiles = m.ntiles;
     A.n_rls = m.n_rls; A.n_trial = m.n_trial; A.n_gram = m.n_gram; A.n_prep = m.n_prep; A.n_sgd = m.n_sgd;
     A.n_sgd_live = (flags & VJF_FLAG_SGD) ? m.n_sgd : 1;
+    A.n_mom = m.n_mom; A.mom = (float*)(c->ws + c->cv.mg_mom);
     A.y = y; A.u = u; A.eps = eps; A.mu0 = mu0; A.lv0 = lv0; A.mu = mu; A.lv = lv; A.loss = loss;
     A.state = c->state; A.aux = (float*)(c->ws + c->cv.aux);
     A.img = (const float*)(c->ws + c->cv.mg_img);
@@ -1121,7 +1142,8 @@ int filter_seq_mega(vjf_ctx* c, int32_t T, int32_t B, const float* y, const floa
     Q.nsteps = T; Q.step0 = 0; Q.role = 2;
     Q.xt = (float*)(c->ws + c->cv.mg_xt); Q.xt_count = cnt + MG_C_XT;
     VjfPlan Pk = P;
-    const int grid = m.n_rls + m.n_trial + m.n_gram + m.n_prep + m.n_sgd;
+    const bool ungated = !(flags & (VJF_FLAG_SGD | VJF_FLAG_UPDATE));       // (lite kernel: builders and moments workgroups are the same ones)
+    const int grid = m.n_rls + m.n_trial + m.n_gram + m.n_prep + (ungated ? (m.n_mom > m.n_sgd ? m.n_mom : m.n_sgd) : m.n_sgd + m.n_mom);
 #ifdef VJF_CHAOS
     {
         static bool told = false;

@@ -37,6 +37,7 @@
 #define VJF_MG_MAXQ 4                // 32x32 tiles of Phi^T Phi per wavefront of a Gram workgroup (28 lower tiles / 8)
 #define VJF_MG_RING 32               // loss sums of a late slab: a ring over the steps (a launch without parameter updates has no gate
                                      // between its steps: the trial role may run this many steps ahead of the role that sums them)
+#define VJF_MG_TAG_TILES 512         // most tiles a launch with a moments role has (B <= 16384)
 #define RS_RESID 5                   // late slab only: sum |dx - Phi W|^2 of a workgroup's trials (warm-up: the state-noise update
                                      // without an RLS update, model.py:373-377 with the old W)
 
@@ -62,7 +63,12 @@ enum {
     MG_C_MASK = 192 * MG_C_SPREAD,     // (step + 1) << 8 | non-finite loss components (1 recon, 2 dynamics, 4 entropy) of the last step that had one
     MG_C_COLFLAGS = 160 * MG_C_SPREAD, // [0 .. VJF_CHOL_MAXBLK]: column flags of the Cholesky loop; [VJF_CHOL_MAXBLK + 2]: its "operands loaded" word
     MG_C_ALIVE = 256 * MG_C_SPREAD,    // workgroups of the grid that have started (all of them: the launch goes on; else it ends untouched)  target gridDim.x
-    MG_C_WORDS = 272 * MG_C_SPREAD
+    // per-TILE step tags of the launches without an RLS update that have a moments role (vjf_mega_moments): one producer, one consumer each
+    MG_C_ARR = 272 * MG_C_SPREAD,      // [step % VJF_MG_RING]: trial workgroups whose loss sums of that step are in memory (a launch without
+                                       // parameter updates: the LAST arriver sums them; it puts the word back to 0)
+    MG_C_TAG_POST = (272 + 32) * MG_C_SPREAD, // [tile]: t + 1 once the posterior of step t of the tile is in memory (trial role -> moments role)
+    MG_C_TAG_MOM = MG_C_TAG_POST + VJF_MG_TAG_TILES,   // [tile]: t + 1 once the predictive moments of step t of the tile are (moments role -> trial role)
+    MG_C_WORDS = MG_C_TAG_MOM + VJF_MG_TAG_TILES
 };
 
 // The last act of every workgroup of a one-launch grid: if a wait of the launch has been given up (by this workgroup or another),
@@ -105,6 +111,8 @@ struct VjfMegaArgs {
     int n_rls, n_trial, n_gram, n_prep, n_sgd;        // grid = their sum
     unsigned* host_word;                              // this context's word of the pinned host page (null: none), see mg_tell_host
     int alive_extra;                                  // test hook (VJF_DEBUG_ABSENT=1): workgroups the residency count waits for beyond the grid's own
+    int n_mom;                                        // launches without an RLS update: workgroups of the moments role (0: the trial role forms the moments itself)
+    float* mom;                                       // [tile][step parity][(2 dz + 1) x 32]: pt.mean | Phi W | pt.logvar of the tile's trials, moments role -> trial role
     int n_sgd_live;                                   // SGD workgroups that stay for the steps (all of them; ONE when flags has no VJF_FLAG_SGD:
                                                       // the others only help to build the parameter image at the start of the launch)
     const float* y; const float* u; const float* eps; const float* mu0; const float* lv0;
@@ -567,6 +575,22 @@ __device__ __forceinline__ void mg_grad_tile(const float* D, int M, int m0, cons
     }
 }
 
+// loss sums of step t over the trial workgroups' late slabs: fp64, 32 strided partial sums per scalar, then a fixed xor tree -> s_sc[RS_*]
+// (the residual leaves as the mean square).  A workgroup-wide call (one barrier); read with sc1 loads behind the caller's wait.
+__device__ __forceinline__ void mg_sum_losses(const VjfMegaArgs& A, int t, float* s_sc, int tid, float Bf, int dz, bool want_resid) {
+    const int ring = 8 * (t % VJF_MG_RING);
+    if (tid < 32 * 5) {
+        const int sc = tid >> 5, l = tid & 31, slot = sc < RS_SDX2 ? sc : RS_RESID;
+        double d = 0.0;
+        if (sc < RS_SDX2 || want_resid)
+            for (int w = l; w < A.n_trial; w += 32) d += (double)mg_ld(A.slab_late + (size_t)w * A.late_len + A.slab_len + ring + slot);
+        d = vjf_sum32(d);
+        // (the residual leaves as the mean square: its sum over 32768 x 16 elements has more digits than a float keeps)
+        if (l == 0) s_sc[slot] = slot == RS_RESID ? (float)(d / ((double)Bf * (double)dz)) : (float)d;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------ trial role
 #define MG_PHASE()                                                        \
     do {                                                                  \
@@ -594,6 +618,9 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     constexpr bool mode_rls = RLS;                     // (the host sends a launch with do_upd && !warm to the full kernel only)
     const bool gated = RLS || do_sgd || do_upd;        // something another role produces changes between steps
     const bool want_resid = !RLS && do_upd && warm;
+    // a moments role (vjf_mega_moments) forms the features and the predictive moments of this role's tiles a step ahead: this
+    // role then neither forms features nor walks L^-1
+    const bool use_mom = !RLS && A.n_mom > 0;
     const unsigned m_dy = mg_magic(dy), m_dz = mg_magic(dz), m_du = mg_magic(du > 0 ? du : 1);
     const VjfMegaTrialLds Lo = vjf_mega_trial_lds<false>(P, A.lds_floats);
     const bool tl = Lo.theta != 0;                    // the optimised parameters are staged in LDS once per step
@@ -761,7 +788,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 __syncthreads(); MG_PHASE();
                 if (first) VJF_MG_STAMP(21);
                 // ---- stage 1: RBF features (functional.py:11-22); a replayed pass needs none (its predictive mean / variance are saved)
-                if (!replay)
+                if (!replay && !use_mom)
                 for (int e = tid; e < TR * n; e += NT) {
                     const int k = e >> 5, b = e & 31;
                     float d2 = 0.f;
@@ -806,9 +833,6 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                             const int k = e / n, j = e - k * n;
                             mg_st(xtw + (size_t)j * n + k, Wc[e]);
                         }
-                        // (a launch without a gate: the step tags of this workgroup's ring start at 0 -- the role that polls them
-                        //  waits for this count first, so it never meets a tag of an earlier launch)
-                        if (!gated && tid < VJF_MG_RING) mg_st(late + A.slab_len + 8 * tid + 7, 0.f);
                         vjf_wg_signal_wt(cnt + MG_C_XT, tid);
                     }
                     if (!vjf_wg_wait_sc1(cnt + MG_C_XT, (unsigned)(mode_rls ? A.n_rls - 2 : A.n_trial), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
@@ -886,8 +910,9 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             };
             // (the slab traffic of a step flows through the same L2s and pushes L^-1 out of some of them: the workgroups of an XCD bring it
             //  back together, a sixteenth each, before they all walk it -- measured without: one XCD's workgroups 12 us late at the gate)
-            if (!RLS && !replay && first) { mg_warm(A.xt, P.n * P.n, wg, tid); mg_warm(S + P.off[VJF_SLOT_W_MEAN], (P.n * P.dz) & ~3, wg, tid); }
-            if (!RLS && !replay) { moments_a(); moments_b(); if (first) VJF_MG_STAMPW(2); }   // (diagnostic: when this workgroup reached the gate)
+            if (!RLS && !replay && first && !use_mom) { mg_warm(A.xt, P.n * P.n, wg, tid); mg_warm(S + P.off[VJF_SLOT_W_MEAN], (P.n * P.dz) & ~3, wg, tid); }
+            if (!RLS && !replay && !use_mom) { moments_a(); moments_b(); }
+            if (!RLS && !replay && first) VJF_MG_STAMPW(2);   // (diagnostic: when this workgroup reached the gate)
             // ---- theta of the previous step.  Nothing above depends on it: the inputs and the features of a step are ready before the
             //      parameters are
             if (first && !replay) {
@@ -1025,8 +1050,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     mg_st(mrow + e, s_mu[j * LD + b]);
                     mg_st(lrow + e, s_lv[j * LD + b]);
                 }
+                if (use_mom) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the tile's posterior is in memory: its tag follows the barrier)
             }
             __syncthreads(); MG_PHASE();
+            if (use_mom && !replay && tid == 0) __hip_atomic_store(cnt + MG_C_TAG_POST + tile, (unsigned)(tc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             {
                 // sum |dx|^2 per trial (16 lanes each), then the tile's sum in trial order
                 constexpr int LPT = NT / TR;
@@ -1124,6 +1151,21 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 warm_late = true;
             }
             if (first) { VJF_MG_STAMP(5); if (RLS) VJF_MG_STAMPW(2); }
+            if (use_mom && !replay) {
+                // the tile's moments of this step from the moments role: its tag, then pt.mean | Phi W | pt.logvar with sc1 loads
+                if (!vjf_wg_wait_sc1(cnt + MG_C_TAG_MOM + tile, (unsigned)(tc + 1), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                    vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
+                if (vjf_abort_wg()) return;
+                const float* mb = A.mom + ((size_t)tile * 2 + (size_t)(tc & 1)) * (size_t)((2 * dz + 1) * TR);
+                for (int e = tid; e < TR * (2 * dz + 1); e += NT) {
+                    const int j = e >> 5, b = e & 31;
+                    const float v = mg_ld(mb + e);
+                    if (j < dz) s_pm[j * LD + b] = v;
+                    else if (j < 2 * dz) { if (want_resid) s_dmu[(j - dz) * LD + b] = v; }
+                    else s_plv[b] = v;
+                }
+                __syncthreads(); MG_PHASE();
+            }
             if (RLS) moments_a();
             if (warm_late) mg_warm_retire(wv_late);
             if (last && tid == 0 && !replay && mode_rls) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
@@ -1316,11 +1358,39 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 // the workgroup's late slab is complete: loss sums, then the signal the SGD role waits for
                 __syncthreads(); MG_PHASE();
                 if ((tid < RS_SDX2 || (tid == RS_RESID && want_resid)) && !replay) mg_st(late + A.slab_len + 8 * (tc % VJF_MG_RING) + tid, s_wg[tid]);
-                vjf_wg_signal_wt(cnt + (replay ? MG_C_REDO_B : MG_C_BWD), tid);
-                // No gate between the steps of this launch: the trial workgroups are not in step with each other, and the sum of their
-                // arrivals says nothing about any one of them.  Each tags its slot of the ring with the step instead -- behind its sums
-                // (every wavefront's stores are drained and the barrier of the signal above is behind this lane)
-                if (!gated && tid == 0) mg_st(late + A.slab_len + 8 * (tc % VJF_MG_RING) + 7, (float)(tc + 1));
+                if (gated) vjf_wg_signal_wt(cnt + (replay ? MG_C_REDO_B : MG_C_BWD), tid);
+                else {
+                    // No gate between the steps of this launch (nothing changes between them): the trial workgroups are not in step
+                    // with each other and no role waits for them.  Each counts itself in at the step's word of a ring; the one whose
+                    // add comes LAST (told by the value the add returns: every other workgroup's sums are in memory, drained before
+                    // its add) sums the step's loss terms in the fixed order, writes the loss, puts the word back to 0 and counts the
+                    // step as done -- the count that keeps any workgroup from running a ring's length ahead.
+                    vjf_chaos(tid, cnt + MG_C_ARR, 2);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) s_try[0] = __hip_atomic_fetch_add(cnt + MG_C_ARR + (tc % VJF_MG_RING), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)A.n_trial ? 1u : 0u;
+                    __syncthreads(); MG_PHASE();
+                    if (s_try[0]) {
+                        float* s_tot = s_sc;                                   // (the per-trial terms of this workgroup's tile are summed and stored)
+                        mg_sum_losses(A, tc, s_tot, tid, (float)A.B, dz, false);
+                        if (tid == 0) {
+                            const float invB = 1.0f / (float)A.B;
+                            float l_recon = s_tot[RS_LRECON] * invB, l_dyn = s_tot[RS_LDYN] * invB, ent = s_tot[RS_ENT] * invB;
+                            const bool ok_r = isfinite(l_recon), ok_d = isfinite(l_dyn), ok_h = isfinite(ent);
+                            if (!ok_r) l_recon = 0.f;
+                            if (!ok_d) l_dyn = 0.f;
+                            if (!ok_h) ent = 0.f;
+                            const float loss = warm ? l_recon - ent : l_recon - ent + l_dyn;   // model.py:146-149
+                            if (A.loss) { float* l4 = A.loss + 4 * (size_t)tc; l4[0] = loss; l4[1] = -l_recon; l4[2] = -l_dyn; l4[3] = ent; }
+                            const unsigned st = (ok_r ? 0u : VJF_STATUS_NONFINITE_RECON) | (ok_d ? 0u : VJF_STATUS_NONFINITE_DYN) | (ok_h ? 0u : VJF_STATUS_NONFINITE_ENT);
+                            if (st) vjf_status_or(SCW + VJF_SC_STATUS, st);
+                            __hip_atomic_store(cnt + MG_C_ARR + (tc % VJF_MG_RING), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __hip_atomic_fetch_add(cnt + MG_C_SGD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        __syncthreads(); MG_PHASE();
+                    }
+                }
                 VJF_MG_STAMP(9);
                 VJF_MG_STAMPX(29, 30);
                 VJF_MG_STAMPW(5);
@@ -1341,6 +1411,139 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         sig_prev = sig; rho_prev = rho;
         break;
       }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ moments role
+// Launches without an RLS update (vjf_mega_lite_kernel): W and w_chol are constants, and the predictive moments of a tile at step t
+// -- pt.mean = xs + Phi W, pt.logvar = log |L^-1 phi|^2 (module.py:64-77) -- depend on nothing but its posterior of step t - 1 and
+// the noise.  They are a third of a trial workgroup's serial work per step (RBF features ~7 us, variance and mean ~12 us of ~52), and the
+// launch has compute units to spare: these workgroups form them a step ahead, tile by tile, operation for operation what the trial role
+// does (the same bits), and hand pt.mean | Phi W | pt.logvar over through memory.  One producer and one consumer per tile: step
+// tags in the launch's counter block (MG_C_TAG_POST, MG_C_TAG_MOM), no counts.
+static inline size_t vjf_mega_mom_lds_floats(const VjfPlan& P) {
+    const size_t npad = (size_t)((P.n + 3) & ~3), LD = VJF_MG_LD;
+    return npad * P.dxu + npad + (size_t)P.dxu * LD + (size_t)P.n * LD + (size_t)VJF_MG_WAVES * VJF_MG_TR + (size_t)VJF_MG_WAVES * 16 * LD + 64;
+}
+__device__ __forceinline__ void vjf_mega_moments(const VjfPlan& P, const VjfMegaArgs& A, float* smem, const int mw) {
+    constexpr int LD = VJF_MG_LD, NW = VJF_MG_WAVES, NT = VJF_MG_THREADS, TR = VJF_MG_TR;
+    const int tid0 = threadIdx.x;
+    const int dz = P.dz, du = P.du, n = P.n, dxu = P.dxu, npad = (n + 3) & ~3;
+    const float* S = A.state;
+    float* SCW = A.state + P.off[VJF_SLOT_SCALARS];
+    float* s_cen = smem; float* s_iw = s_cen + (size_t)npad * dxu;
+    float* s_xu = s_iw + npad; float* s_phi = s_xu + (size_t)dxu * LD;
+    float* s_red = s_phi + (size_t)n * LD; float* s_part = s_red + NW * TR;
+    unsigned* cnt = A.cnt;
+    const size_t sz = (size_t)A.B * dz, su = (size_t)A.B * du;
+    constexpr int part_rows = VJF_MG_WAVES * 16;
+    {
+        const int tid = tid0;
+        const float* cen = S + P.off[VJF_SLOT_CENTROID];
+        const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
+        for (int e = tid; e < npad * dxu; e += NT) { const int c = e / npad, k = e - c * npad; s_cen[e] = k < n ? cen[k * dxu + c] : 0.f; }
+        for (int e = tid; e < npad; e += NT) { float v = 0.f; if (e < n) { const float w = expf(lw[e]); v = -0.5f / (w * w); } s_iw[e] = v; }
+    }
+    // (the row-major L^-1 of this launch: the trial workgroups' first act)
+    if (!vjf_wg_wait_sc1(cnt + MG_C_XT, (unsigned)A.n_trial, tid0, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+        vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
+    if (vjf_abort_wg()) return;
+    const bool tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
+    const int mlen = (2 * dz + 1) * TR;
+    for (int t = 0; t < A.T; ++t) {
+        const float* mu_s = t ? A.mu + (size_t)(t - 1) * sz : A.mu0;
+        const float* lv_s = t ? A.lv + (size_t)(t - 1) * sz : A.lv0;
+        const float* eps_s = A.eps + (size_t)t * 2 * sz;
+        const float* u_t = A.u ? A.u + (size_t)t * su : nullptr;
+        for (int tile = mw; tile < A.ntiles; tile += A.n_mom) {
+            int tid = tid0, lane, wave;
+            MG_PHASE();
+            const int b0 = tile * TR, nb = min(TR, A.B - b0);
+            // the tile's posterior of step t - 1 (the trial role's write-through stores, then its tag)
+            if (t > 0) {
+                if (!vjf_wg_wait_sc1(cnt + MG_C_TAG_POST + tile, (unsigned)t, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                    vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
+                if (vjf_abort_wg()) return;
+            } else __syncthreads();
+            MG_PHASE();
+            // xs = mu + eps e^{lv / 2} (util.py:11-13; the prior at the first step of a run) and the inputs u: the trial role's expression
+            for (int e = tid; e < TR * dxu; e += NT) {
+                const int c = e >> 5, b = e & 31;
+                float v = 0.f;
+                if (c < dz) {
+                    float m, l, ep = 0.f;
+                    if (mu_s) { m = b < nb ? mg_ld(mu_s + (size_t)(b0 + b) * dz + c) : 0.f; l = b < nb ? mg_ld(lv_s + (size_t)(b0 + b) * dz + c) : 0.f; }
+                    else { m = S[P.off[VJF_SLOT_PRIOR_MEAN] + c]; l = S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c]; }
+                    if (b < nb) ep = eps_s[(size_t)(b0 + b) * dz + c];
+                    v = fmaf(ep, expf(0.5f * l), m);
+                } else if (b < nb) v = u_t[(size_t)(b0 + b) * du + c - dz];
+                s_xu[c * LD + b] = v;
+            }
+            __syncthreads(); MG_PHASE();
+            for (int e = tid; e < TR * n; e += NT) {                           // RBF features (functional.py:11-22)
+                const int k = e >> 5, b = e & 31;
+                float d2 = 0.f;
+                for (int c = 0; c < dxu; ++c) { const float d = s_xu[c * LD + b] - s_cen[c * npad + k]; d2 = fmaf(d, d, d2); }
+                s_phi[k * LD + b] = expf(d2 * s_iw[k]);
+            }
+            __syncthreads(); MG_PHASE();
+            int mean_nsl = 1;
+            {   // predictive variance and mean: vjf_mega_trial's stage 2, wavefront for wavefront
+                const __amdgpu_buffer_rsrc_t r_xt = mg_rsrc(A.xt);
+                const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
+                const int ntile = (n + 15) >> 4;
+                float v2a = 0.f, v2b = 0.f;
+                const int nsl = min(NW, part_rows / 16);
+                const int msl = nsl - 1 - wave;
+                const int mper = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
+                const int mkb = msl * mper, mke = min(n, (msl + 1) * mper);
+                const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
+                float am[16];
+                if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
+                for (int r = 0; r * NW < ntile; r += 2) {
+                    int j0p[2], Kp[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int rr = r + h, idx = (rr & 1) ? rr * NW + NW - 1 - wave : rr * NW + wave;
+                        const int tt = ntile - 1 - idx;
+                        j0p[h] = (idx < ntile) ? tt * 16 : -1;
+                        Kp[h] = tri ? min(n, tt * 16 + 16) : n;
+                    }
+                    if (j0p[0] < 0) { j0p[0] = j0p[1]; Kp[0] = Kp[1]; j0p[1] = -1; }
+                    mg_var2(v2a, v2b, r_xt, n, j0p[0], Kp[0], j0p[1], Kp[1], s_phi, lane);
+                }
+                v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
+                v2b += __shfl_xor(v2b, 16, 64); v2b += __shfl_xor(v2b, 32, 64);
+                if (lane < 16) { s_red[wave * TR + lane] = v2a; s_red[wave * TR + 16 + lane] = v2b; }
+                if (wave < nsl) {
+                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, dz, 0, mkb, mke, 0, lane); }
+                    else mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, mkb, mke, lane);
+                    float* pr = s_part + (size_t)(msl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
+                }
+                mean_nsl = nsl;
+            }
+            __syncthreads(); MG_PHASE();
+            // out: [pt.mean (dz x 32) | Phi W (dz x 32) | pt.logvar (32)], write-through; then the tag
+            float* mb = A.mom + ((size_t)tile * 2 + (size_t)(t & 1)) * (size_t)mlen;
+            for (int e = tid; e < TR * dz; e += NT) {
+                const int j = e >> 5, b = e & 31;
+                float v = 0.f;
+                for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
+                mg_st(mb + e, s_xu[j * LD + b] + v);
+                mg_st(mb + TR * dz + e, v);
+            }
+            if (tid < TR) {
+                float v = 0.f;
+                for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
+                mg_st(mb + 2 * TR * dz + tid, logf(v));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(cnt + MG_C_TAG_MOM + tile, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1770,11 +1973,6 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
         vjf_wg_signal_wt(A.cnt + MG_C_IMG, tid);
     }
     if (sw >= n_live) return;                          // (no gradient steps in this launch: one workgroup sums the losses and keeps the scalars)
-    if (!RLS && !do_sgd && !do_upd) {                  // (no gate: step tags instead of counts, cleared by their owners before this count)
-        if (!vjf_wg_wait_sc1(A.cnt + MG_C_XT, (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS))
-            vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
-        if (vjf_abort_wg()) return;
-    }
     unsigned nredo = 0;
     for (int t = 0; t < A.T; ++t) {
       float l_recon = 0.f, l_dyn = 0.f, ent = 0.f;
@@ -1796,17 +1994,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
         bool have_sums = pass == 1;
         // loss sums of the step: fp64, 32 strided partial sums per scalar, then a fixed xor tree (every SGD workgroup, for the guards)
         auto take_sums = [&]() {
-            const int ring = 8 * (t % VJF_MG_RING);
-            if (tid < 32 * 5) {
-                const int sc = tid >> 5, l = tid & 31, slot = sc < RS_SDX2 ? sc : RS_RESID;
-                double d = 0.0;
-                if (sc < RS_SDX2 || (do_upd && warm))
-                    for (int w = l; w < A.n_trial; w += 32) d += (double)mg_ld(A.slab_late + (size_t)w * A.late_len + A.slab_len + ring + slot);
-                d = vjf_sum32(d);
-                // (the residual leaves as the mean square: its sum over 32768 x 16 elements has more digits than a float keeps)
-                if (l == 0) s_sc[slot] = slot == RS_RESID ? (float)(d / ((double)Bf * (double)P.dz)) : (float)d;
-            }
-            __syncthreads();
+            mg_sum_losses(A, t, s_sc, tid, Bf, P.dz, do_upd && warm);
             l_recon = s_sc[RS_LRECON] * invB; l_dyn = s_sc[RS_LDYN] * invB; ent = s_sc[RS_ENT] * invB;
             ok_r = isfinite(l_recon); ok_d = isfinite(l_dyn); ok_h = isfinite(ent);
             grad_ok = ok_r && ok_h && (warm || ok_d);
@@ -1865,24 +2053,6 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
                 if (cidx[r] >= 0) mg_st(cdst + cidx[r], wn);
             }
         };
-        if (!do_sgd && !do_upd) {
-            // (no gate in this launch, see vjf_mega_trial: every trial workgroup's tag of this step, one lane per workgroup)
-            bool all = true;
-            for (int w = tid; w < A.n_trial; w += NT) {
-                const float* tag = A.slab_late + (size_t)w * A.late_len + A.slab_len + 8 * (t % VJF_MG_RING) + 7;
-                bool there = false;
-                for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
-                    if (mg_ld(tag) == (float)(t + 1)) { there = true; break; }
-                    if ((spins & 255u) == 255u && vjf_abort_seen(SC + VJF_SC_STATUS)) break;
-                    __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
-                }
-                all = all && there;
-            }
-            if (!__syncthreads_and(all ? 1 : 0)) {
-                if (tid == 0) vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
-                return;
-            }
-        }
         if (!do_sgd) take_sums();
         else
         for (int q0 = q00; q0 < nquad || q0 == q00; q0 += qstride) {
@@ -1960,6 +2130,30 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     }
 }
 
+// The parameter image of a launch without parameter updates (nothing else for an SGD role to do there): builder `sw` of `nb`
+// stores the parameters of its quads of the slab tables at their places in the image (what vjf_mega_sgd does at the start of the
+// other launches), then counts itself in at MG_C_IMG.
+__device__ __forceinline__ void mg_build_image(const VjfPlan& P, const VjfMegaArgs& A, const int sw, const int nb) {
+    constexpr int NT = VJF_MG_THREADS;
+    const int tid = threadIdx.x, part = tid & 7;
+    if (vjf_mega_trial_lds<false>(P, A.lds_floats).theta == 0) return;    // (the trial role reads the state itself)
+    const int nquad = A.slab_len >> 2, qstride = (nb * NT) >> 3;
+    const float* th = A.state + P.train_off;
+    float* img = const_cast<float*>(A.img);
+    for (int q0 = (sw * NT) >> 3; q0 < nquad; q0 += qstride) {
+        const int quad = q0 + (tid >> 3);
+        if (quad < nquad && part == 0) {
+            const int4 pi = *reinterpret_cast<const int4*>(A.sl_pidx + (size_t)quad * 4);
+            const int4 ci = *reinterpret_cast<const int4*>(A.sl_cidx + (size_t)quad * 4);
+            if (pi.x >= 0 && ci.x >= 0) mg_st(img + ci.x, th[pi.x]);
+            if (pi.y >= 0 && ci.y >= 0) mg_st(img + ci.y, th[pi.y]);
+            if (pi.z >= 0 && ci.z >= 0) mg_st(img + ci.z, th[pi.z]);
+            if (pi.w >= 0 && ci.w >= 0) mg_st(img + ci.w, th[pi.w]);
+        }
+    }
+    vjf_wg_signal_wt(A.cnt + MG_C_IMG, tid);
+}
+
 // ------------------------------------------------------------------------------------------------ the kernel
 __global__ __launch_bounds__(VJF_MG_THREADS) void vjf_mega_kernel(VjfPlan P, VjfMegaArgs A, VjfCholArgs C, VjfPostArgs Q) {
     static_assert(VJF_CHOL_THREADS == VJF_MG_THREADS && VJF_POST_THREADS == VJF_MG_THREADS, "one workgroup size for every role");
@@ -1998,8 +2192,16 @@ __global__ __launch_bounds__(VJF_MG_THREADS) void vjf_mega_lite_kernel(VjfPlan P
         for (int i = threadIdx.x; i < MG_C_WORDS; i += VJF_MG_THREADS) A.cnt_next[i] = 0u;
     float* stw = A.state + P.off[VJF_SLOT_SCALARS] + VJF_SC_STATUS;
     if (mg_grid_resident(A.cnt, stw, A.alive_extra)) {
+        const int idx = b - A.n_trial;
         if (b < A.n_trial) vjf_mega_trial<false>(P, A, lds, b);
-        else vjf_mega_sgd<false>(P, A, lds, b - A.n_trial);
+        else if (!(A.flags & (VJF_FLAG_SGD | VJF_FLAG_UPDATE))) {
+            // nothing changes between the steps: no SGD role -- the first n_sgd of these workgroups build the parameter image, and all
+            // n_mom of them (n_mom >= n_sgd, or none) are the moments role; the loss sums are the trial role's own (its last arriver)
+            if (idx < A.n_sgd) mg_build_image(P, A, idx, A.n_sgd);
+            if (idx < A.n_mom) vjf_mega_moments(P, A, lds, idx);
+        }
+        else if (idx < A.n_mom) vjf_mega_moments(P, A, lds, idx);
+        else vjf_mega_sgd<false>(P, A, lds, idx - A.n_mom);
     }
     mg_tell_host(stw, A.host_word);
 }
