@@ -44,6 +44,11 @@ ALLOW = {
     ("vjf_mega_kernel.h", "v = fmaf(eps_s[(size_t)b * dz + c2], expf(0.5f * l), m);"): "const: the noise input",
     ("vjf_mega_kernel.h", "v = u_e[(size_t)b * du + c2 - dz];"): "const: the control input",
     # ---- moments role, image builders (launches without an RLS update)
+    ("vjf_mega_kernel.h", "for (int e = tid0; e < npad * dxu; e += NT) { const int c = e / npad, k = e - c * npad; s_cen[e] = k < n ? cen[k * dxu + c] : 0.f; }"): "const: centroids",
+    ("vjf_mega_kernel.h", "for (int e = tid0; e < npad; e += NT) { float v = 0.f; if (e < n) { const float w = expf(lw[e]); v = -0.5f / (w * w); } s_iw[e] = v; }"): "const: widths",
+    ("vjf_mega_kernel.h", "const mg_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, float_index * 4, 0, 0);"):
+        "own: mg_ld4_plain -- used for L^-1 of a launch WITHOUT an RLS update only (mg_varN): written once at the start of the launch, "
+        "read for the first time behind the MG_C_XT count (no earlier copy in this CU's L1: a launch starts with it invalidated)",
     ("vjf_mega_kernel.h", "else { m = S[P.off[VJF_SLOT_PRIOR_MEAN] + c]; l = S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c]; }"): "const: the prior (the posterior is an sc1 load)",
     ("vjf_mega_kernel.h", "if (b < nb) ep = eps_s[(size_t)(b0 + b) * dz + c];"): "const: the noise input",
     ("vjf_mega_kernel.h", "} else if (b < nb) v = u_t[(size_t)(b0 + b) * du + c - dz];"): "const: the control input",

@@ -12,6 +12,7 @@ cfgA = os.environ.get("CFG", "B") == "A"                   # CFG=A: BASELINE con
 dz, dy, n = (10, 200, 200) if cfgC else (3, 10, 100) if cfgA else (10, 50, 200)
 m = vjf_amd.VJF.make_model(dy, dz, 0, n, [20] if cfgA else [128], likelihood="poisson" if cfgC else "gaussian", noise="device")
 y = torch.poisson(torch.rand(T + 8, B, dy, device="cuda")) if cfgC else torch.randn(T + 8, B, dy, device="cuda")
+_FL_PLACEHOLDER = None
 FL = {"train": {}, "warmup": dict(warm_up=True), "infer": dict(sgd=False, update=False), "sgd-only": dict(update=False)}[os.environ.get("FLAGS", "train")]   # FLAGS=warmup|infer|sgd-only: the launches without an RLS update
 m.filter_sequence(y[:8], **FL)
 N.check(m._backend().vjf_debug_stamps(m._ctx, 2, None))
@@ -19,8 +20,9 @@ m.filter_sequence(y[8:], **FL)
 torch.cuda.synchronize()
 ev = []
 TR = ["step start", "theta staged", "features done", "recognition done", "early slab out", "RLS(t-1) there", "var+mean done", "seeds+dxt done",
-      "backward+grads done", "late slab out", "moments saved", "gram: may start", "gram: partials out", "gram: reduced",
-      "operand: inputs there", "operand: done", "sgd: late slabs there", "sgd: done", "trial: step end", "trial: deltas done", "trial: inputs in LDS", "trial: xs done",
+      "backward+grads done", "late slab out", "moments saved"] + (["gram: may start", "gram: partials out", "gram: reduced",
+      "operand: inputs there", "operand: done"] if not os.environ.get("FLAGS") else ["moments role: posterior(t-1) there", "moments role: xs done", "moments role: features done",
+      "moments role: variance + mean done", "moments role: moments out, tags posted"]) + [ "sgd: late slabs there", "sgd: done", "trial: step end", "trial: deltas done", "trial: inputs in LDS", "trial: xs done",
       "trial: wave0 variance tiles done", "trial: rec layers done", "trial: heads partials done", "trial: xt/post/decoder done", "trial: early slab stored"]
 for t in range(max(0, T - 6), T):
     o = (ctypes.c_uint64 * 32)()

@@ -251,6 +251,11 @@ typedef unsigned mg_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mg_rsrc(const float* uniform_base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_base), 0, 0x7fffffff, 0x00020000);
 }
+// the same as a PLAIN load (through this CU's L1): only for bytes that are constants of the launch by the time they are first read
+__device__ __forceinline__ float4 mg_ld4_plain(__amdgpu_buffer_rsrc_t r, int float_index) {
+    const mg_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, float_index * 4, 0, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
 __device__ __forceinline__ float4 mg_ld4(__amdgpu_buffer_rsrc_t r, int float_index) {
     const mg_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, float_index * 4, 0, 16);               // aux 16 = sc1
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
@@ -1422,128 +1427,288 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
 // does (the same bits), and hand pt.mean | Phi W | pt.logvar over through memory.  One producer and one consumer per tile: step
 // tags in the launch's counter block (MG_C_TAG_POST, MG_C_TAG_MOM), no counts.
 static inline size_t vjf_mega_mom_lds_floats(const VjfPlan& P) {
-    const size_t npad = (size_t)((P.n + 3) & ~3), LD = VJF_MG_LD;
-    return npad * P.dxu + npad + (size_t)P.dxu * LD + (size_t)P.n * LD + (size_t)VJF_MG_WAVES * VJF_MG_TR + (size_t)VJF_MG_WAVES * 16 * LD + 64;
+    const size_t npad = (size_t)((P.n + 3) & ~3), LD = 65;                     // (two tiles side by side: 64 columns + 1)
+    return npad * P.dxu + npad + (size_t)P.dxu * LD + (size_t)P.n * LD + (size_t)VJF_MG_WAVES * 64 + (size_t)VJF_MG_WAVES * 16 * LD + 64;
 }
-__device__ __forceinline__ void vjf_mega_moments(const VjfPlan& P, const VjfMegaArgs& A, float* smem, const int mw) {
-    constexpr int LD = VJF_MG_LD, NW = VJF_MG_WAVES, NT = VJF_MG_THREADS, TR = VJF_MG_TR;
+
+// mg_var2 / mg_mma2_mm16 for NG column groups of 16 trials (NG = 2: one tile, LD = 33, the trial role's routines instruction for
+// instruction; NG = 4: two tiles side by side, LD = 65 -- every operand load of L^-1 and W then feeds twice the multiply-adds).  A
+// trial's sums run over k in the same order whatever NG is: the same bits.
+template <int NG, int LD>
+__device__ __forceinline__ void mg_varN(float (&v2)[NG], __amdgpu_buffer_rsrc_t rx, int n, int j0A, int KA, int j0B, int KB, const float* Xs, int lane,
+                                        const bool upper = true) {        // upper = false (uniform): column groups 2, 3 hold no trials, their multiply-adds are skipped
+    if (j0A < 0) return;
+    const int i = lane & 15, kk = lane >> 4;
+    const bool rvA = (j0A + i) < n, rvB = j0B >= 0 && (j0B + i) < n;
+    const int offA = (rvA ? j0A + i : 0) * n + 4 * kk, offB = (rvB ? j0B + i : 0) * n + 4 * kk;
+    const float* xp = Xs + i;
+    const int ntA = (KA + 15) >> 4, ntB = j0B >= 0 ? (KB + 15) >> 4 : 0;
+    const int SA = (ntA + 3) >> 2, SB = (ntB + 3) >> 2, S = SA + SB;
+    vjf_f32x4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = vjf_f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fold = [&]() {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) v2[g] = fmaf(acc[g][0], acc[g][0], fmaf(acc[g][1], acc[g][1], fmaf(acc[g][2], acc[g][2], fmaf(acc[g][3], acc[g][3], v2[g]))));
+    };
+    auto ldb = [&](float4 (&a)[4], int sb) {
+        const bool inB = sb >= SA;
+        const int t0 = 4 * (inB ? sb - SA : sb), off = inB ? offB : offA;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int kq = 16 * (t0 + q) + 4 * kk; a[q] = mg_ld4_plain(rx, off + (kq + 3 < n ? 16 * (t0 + q) : 0)); }   // (plain: L^-1 of a launch without an RLS update is written once, before its first read)
+    };
+    auto mmb = [&](const float4 (&a)[4], int sb) {
+        const bool inB = sb >= SA;
+        const int t0 = 4 * (inB ? sb - SA : sb), nt = inB ? ntB : ntA, ke = inB ? KB : KA;
+        const bool rv = inB ? rvB : rvA;
+        if (sb == SA && SA > 0) {
+            fold();
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = vjf_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (t0 + q < nt) {
+                const int k0 = 16 * (t0 + q) + 4 * kk;
+                const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = k0 + c, kc = min(k, ke - 1);
+                    const float v = (rv && k < ke) ? av[c] : 0.f;
+#pragma unroll
+                    for (int g = 0; g < (NG < 2 ? NG : 2); ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, xp[kc * LD + 16 * g], acc[g], 0, 0, 0);
+                    if (NG > 2 && upper) {
+#pragma unroll
+                        for (int g = 2; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, xp[kc * LD + 16 * g], acc[g], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    float4 a0[4], a1[4], a2[4];
+    ldb(a0, 0);
+    if (S > 1) ldb(a1, 1);
+    if (S > 2) ldb(a2, 2);
+    for (int sb = 0; sb < S; sb += 3) {
+        mmb(a0, sb);
+        if (sb + 3 < S) ldb(a0, sb + 3);
+        if (sb + 1 < S) { mmb(a1, sb + 1); if (sb + 4 < S) ldb(a1, sb + 4); }
+        if (sb + 2 < S) { mmb(a2, sb + 2); if (sb + 5 < S) ldb(a2, sb + 5); }
+    }
+    fold();
+}
+template <int NG, int LD>
+__device__ __forceinline__ void mg_mmaN_mm16(vjf_f32x4 (&acc)[NG], const float (&a)[16], const float* Xs, int M, int m0, int kb, int ke, int s0, int lane,
+                                             const bool upper = true) {
+    const int i = lane & 15, kk = lane >> 4;
+    const bool rv = (m0 + i) < M;
+    const float* xp = Xs + i;
+    const int nst = (ke - kb + 3) >> 2, klast = ke - 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (s0 + q < nst) {
+            const int k = kb + 4 * (s0 + q) + kk;
+            const int kc = min(k, klast);
+            const float av = (rv && k < ke) ? a[q] : 0.f;
+#pragma unroll
+            for (int g = 0; g < (NG < 2 ? NG : 2); ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD + 16 * g], acc[g], 0, 0, 0);
+            if (NG > 2 && upper) {
+#pragma unroll
+                for (int g = 2; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD + 16 * g], acc[g], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// one pass of the moments role: NG / 2 tiles (tile0, and tile1 when NG = 4 and tile1 >= 0) of step t, from their posterior tags to their
+// moments tags
+template <int NG>
+__device__ __forceinline__ bool mg_moments_pass(const VjfPlan& P, const VjfMegaArgs& A, float* smem, const int t, const int tile0, const int tile1, const bool tri) {
+    constexpr int LD = 16 * NG + 1, NW = VJF_MG_WAVES, NT = VJF_MG_THREADS, TR = VJF_MG_TR, NC = 16 * NG;   // NC columns = NG / 2 tiles
+    const bool two = NG == 4 && tile1 >= 0;
+    const int ncol = two ? NC : TR;                    // columns that hold trials (the elementwise loops stop there)
     const int tid0 = threadIdx.x;
+    int tid = tid0, lane, wave;
+    MG_PHASE();
     const int dz = P.dz, du = P.du, n = P.n, dxu = P.dxu, npad = (n + 3) & ~3;
     const float* S = A.state;
     float* SCW = A.state + P.off[VJF_SLOT_SCALARS];
     float* s_cen = smem; float* s_iw = s_cen + (size_t)npad * dxu;
     float* s_xu = s_iw + npad; float* s_phi = s_xu + (size_t)dxu * LD;
-    float* s_red = s_phi + (size_t)n * LD; float* s_part = s_red + NW * TR;
+    float* s_red = s_phi + (size_t)n * LD; float* s_part = s_red + NW * NC;
     unsigned* cnt = A.cnt;
     const size_t sz = (size_t)A.B * dz, su = (size_t)A.B * du;
     constexpr int part_rows = VJF_MG_WAVES * 16;
+    const float* mu_s = t ? A.mu + (size_t)(t - 1) * sz : A.mu0;
+    const float* lv_s = t ? A.lv + (size_t)(t - 1) * sz : A.lv0;
+    const float* eps_s = A.eps + (size_t)t * 2 * sz;
+    const float* u_t = A.u ? A.u + (size_t)t * su : nullptr;
+    // the tiles' posterior of step t - 1 (the trial role's write-through stores, then its tags)
+    if (t > 0) {
+        bool ok = vjf_wg_wait_sc1(cnt + MG_C_TAG_POST + tile0, (unsigned)t, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u);
+        bool gone = vjf_abort_wg();
+        if (two && !gone) { ok = vjf_wg_wait_sc1(cnt + MG_C_TAG_POST + tile1, (unsigned)t, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) && ok; gone = vjf_abort_wg(); }
+        if (!ok) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
+        if (gone) return false;
+    } else __syncthreads();
+    MG_PHASE();
+    const int wg = tile0;                              // (diagnostic stamps: the workgroup that owns tile 0)
+    VJF_MG_STAMP(11);
+    // xs = mu + eps e^{lv / 2} (util.py:11-13; the prior at the first step of a run) and the inputs u: the trial role's expression
+    for (int e = tid; e < NC * dxu; e += NT) {
+        const int c = e / NC, col = e - c * NC, b = col & 31;
+        if (col >= ncol) { s_xu[c * LD + col] = 0.f; continue; }
+        const int b0 = (col < TR ? tile0 : tile1) * TR, nb = min(TR, A.B - b0);
+        float v = 0.f;
+        if (c < dz) {
+            float m, l, ep = 0.f;
+            if (mu_s) { m = b < nb ? mg_ld(mu_s + (size_t)(b0 + b) * dz + c) : 0.f; l = b < nb ? mg_ld(lv_s + (size_t)(b0 + b) * dz + c) : 0.f; }
+            else { m = S[P.off[VJF_SLOT_PRIOR_MEAN] + c]; l = S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c]; }
+            if (b < nb) ep = eps_s[(size_t)(b0 + b) * dz + c];
+            v = fmaf(ep, expf(0.5f * l), m);
+        } else if (b < nb) v = u_t[(size_t)(b0 + b) * du + c - dz];
+        s_xu[c * LD + col] = v;
+    }
+    __syncthreads(); MG_PHASE();
+    VJF_MG_STAMP(12);
+    // RBF features (functional.py:11-22): four centres per thread and column (one 16-byte LDS read of the centres per input dimension
+    // instead of four 4-byte ones; per element the trial role's operations in the trial role's order: the same bits)
+    for (int e = tid; e < NC * (npad >> 2); e += NT) {
+        const int k4 = e / NC, col = e - k4 * NC, k = 4 * k4;
+        float d2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (col < ncol) {
+            auto dim = [&](float x, const float4& cc) {                        // (one input dimension: the trial role's order of operations)
+                float d;
+                d = x - cc.x; d2[0] = fmaf(d, d, d2[0]); d = x - cc.y; d2[1] = fmaf(d, d, d2[1]);
+                d = x - cc.z; d2[2] = fmaf(d, d, d2[2]); d = x - cc.w; d2[3] = fmaf(d, d, d2[3]);
+            };
+            int c = 0;
+            for (; c + 3 < dxu; c += 4) {                                      // four dimensions' LDS loads in flight together (a loop of
+                const float x0 = s_xu[c * LD + col], x1 = s_xu[(c + 1) * LD + col], x2 = s_xu[(c + 2) * LD + col], x3 = s_xu[(c + 3) * LD + col];   // single loads is a chain of LDS round trips)
+                const float4 c0 = *reinterpret_cast<const float4*>(s_cen + c * npad + k);
+                const float4 c1 = *reinterpret_cast<const float4*>(s_cen + (c + 1) * npad + k);
+                const float4 c2 = *reinterpret_cast<const float4*>(s_cen + (c + 2) * npad + k);
+                const float4 c3 = *reinterpret_cast<const float4*>(s_cen + (c + 3) * npad + k);
+                dim(x0, c0); dim(x1, c1); dim(x2, c2); dim(x3, c3);
+            }
+            for (; c < dxu; ++c) dim(s_xu[c * LD + col], *reinterpret_cast<const float4*>(s_cen + c * npad + k));
+        }
+        const float4 iw = *reinterpret_cast<const float4*>(s_iw + k);
+        const float iwv[4] = {iw.x, iw.y, iw.z, iw.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (k + q < n) s_phi[(k + q) * LD + col] = col < ncol ? expf(d2[q] * iwv[q]) : 0.f;
+    }
+    __syncthreads(); MG_PHASE();
+    VJF_MG_STAMP(13);
+    int mean_nsl = 1;
+    {   // predictive variance and mean: vjf_mega_trial's stage 2, wavefront for wavefront
+        const __amdgpu_buffer_rsrc_t r_xt = mg_rsrc(A.xt);
+        const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
+        const int ntile = (n + 15) >> 4;
+        float v2[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) v2[g] = 0.f;
+        const int nsl = min(NW, part_rows / 16);
+        const int msl = nsl - 1 - wave;
+        const int mper = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
+        const int mkb = msl * mper, mke = min(n, (msl + 1) * mper);
+        const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
+        float am[16];
+        if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
+        for (int r = 0; r * NW < ntile; r += 2) {
+            int j0p[2], Kp[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = r + h, idx = (rr & 1) ? rr * NW + NW - 1 - wave : rr * NW + wave;
+                const int tt = ntile - 1 - idx;
+                j0p[h] = (idx < ntile) ? tt * 16 : -1;
+                Kp[h] = tri ? min(n, tt * 16 + 16) : n;
+            }
+            if (j0p[0] < 0) { j0p[0] = j0p[1]; Kp[0] = Kp[1]; j0p[1] = -1; }
+            mg_varN<NG, LD>(v2, r_xt, n, j0p[0], Kp[0], j0p[1], Kp[1], s_phi, lane, two);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v2[g] += __shfl_xor(v2[g], 16, 64); v2[g] += __shfl_xor(v2[g], 32, 64);
+            if (lane < 16) s_red[wave * NC + 16 * g + lane] = v2[g];
+        }
+        if (wave < nsl) {
+            vjf_f32x4 acc[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = vjf_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mpre) { if (mke > mkb) mg_mmaN_mm16<NG, LD>(acc, am, s_phi, dz, 0, mkb, mke, 0, lane, two); }
+            else {
+                // (more than 512 features: the slice in batches of 16 k-steps)
+                for (int s0 = 0; 4 * s0 < mke - mkb; s0 += 16) {
+                    float a2[16];
+                    mg_mma2_ld16(a2, Wm, dz, dz, 0, mkb, mke, s0, lane);
+                    mg_mmaN_mm16<NG, LD>(acc, a2, s_phi, dz, 0, mkb, mke, s0, lane, two);
+                }
+            }
+            float* pr = s_part + (size_t)(msl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) pr[r * LD + 16 * g] = acc[g][r];
+        }
+        mean_nsl = nsl;
+    }
+    __syncthreads(); MG_PHASE();
+    VJF_MG_STAMP(14);
+    // out, per tile: [pt.mean (dz x 32) | Phi W (dz x 32) | pt.logvar (32)], write-through; then the tags
+    const int mlen = (2 * dz + 1) * TR;
+    for (int e = tid; e < NC * dz; e += NT) {
+        const int j = e / NC, col = e - j * NC, b = col & 31;
+        if (col >= ncol) continue;
+        float* mb = A.mom + ((size_t)(col < TR ? tile0 : tile1) * 2 + (size_t)(t & 1)) * (size_t)mlen;
+        float v = 0.f;
+        for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + col];
+        mg_st(mb + j * TR + b, s_xu[j * LD + col] + v);
+        mg_st(mb + TR * dz + j * TR + b, v);
+    }
+    if (tid < ncol) {
+        float* mb = A.mom + ((size_t)(tid < TR ? tile0 : tile1) * 2 + (size_t)(t & 1)) * (size_t)mlen;
+        float v = 0.f;
+        for (int w = 0; w < NW; ++w) v += s_red[w * NC + tid];
+        mg_st(mb + 2 * TR * dz + (tid & 31), logf(v));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(cnt + MG_C_TAG_MOM + tile0, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (two) __hip_atomic_store(cnt + MG_C_TAG_MOM + tile1, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    VJF_MG_STAMP(15);
+    return true;
+}
+
+__device__ __forceinline__ void vjf_mega_moments(const VjfPlan& P, const VjfMegaArgs& A, float* smem, const int mw) {
+    constexpr int NT = VJF_MG_THREADS;
+    const int tid0 = threadIdx.x;
+    const int n = P.n, dxu = P.dxu, npad = (n + 3) & ~3;
+    const float* S = A.state;
+    float* SCW = A.state + P.off[VJF_SLOT_SCALARS];
+    float* s_cen = smem; float* s_iw = s_cen + (size_t)npad * dxu;
     {
-        const int tid = tid0;
         const float* cen = S + P.off[VJF_SLOT_CENTROID];
         const float* lw = S + P.off[VJF_SLOT_LOGWIDTH];
-        for (int e = tid; e < npad * dxu; e += NT) { const int c = e / npad, k = e - c * npad; s_cen[e] = k < n ? cen[k * dxu + c] : 0.f; }
-        for (int e = tid; e < npad; e += NT) { float v = 0.f; if (e < n) { const float w = expf(lw[e]); v = -0.5f / (w * w); } s_iw[e] = v; }
+        for (int e = tid0; e < npad * dxu; e += NT) { const int c = e / npad, k = e - c * npad; s_cen[e] = k < n ? cen[k * dxu + c] : 0.f; }
+        for (int e = tid0; e < npad; e += NT) { float v = 0.f; if (e < n) { const float w = expf(lw[e]); v = -0.5f / (w * w); } s_iw[e] = v; }
     }
     // (the row-major L^-1 of this launch: the trial workgroups' first act)
-    if (!vjf_wg_wait_sc1(cnt + MG_C_XT, (unsigned)A.n_trial, tid0, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+    if (!vjf_wg_wait_sc1(A.cnt + MG_C_XT, (unsigned)A.n_trial, tid0, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
         vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
     if (vjf_abort_wg()) return;
     const bool tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
-    const int mlen = (2 * dz + 1) * TR;
     for (int t = 0; t < A.T; ++t) {
-        const float* mu_s = t ? A.mu + (size_t)(t - 1) * sz : A.mu0;
-        const float* lv_s = t ? A.lv + (size_t)(t - 1) * sz : A.lv0;
-        const float* eps_s = A.eps + (size_t)t * 2 * sz;
-        const float* u_t = A.u ? A.u + (size_t)t * su : nullptr;
-        for (int tile = mw; tile < A.ntiles; tile += A.n_mom) {
-            int tid = tid0, lane, wave;
-            MG_PHASE();
-            const int b0 = tile * TR, nb = min(TR, A.B - b0);
-            // the tile's posterior of step t - 1 (the trial role's write-through stores, then its tag)
-            if (t > 0) {
-                if (!vjf_wg_wait_sc1(cnt + MG_C_TAG_POST + tile, (unsigned)t, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
-                    vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
-                if (vjf_abort_wg()) return;
-            } else __syncthreads();
-            MG_PHASE();
-            // xs = mu + eps e^{lv / 2} (util.py:11-13; the prior at the first step of a run) and the inputs u: the trial role's expression
-            for (int e = tid; e < TR * dxu; e += NT) {
-                const int c = e >> 5, b = e & 31;
-                float v = 0.f;
-                if (c < dz) {
-                    float m, l, ep = 0.f;
-                    if (mu_s) { m = b < nb ? mg_ld(mu_s + (size_t)(b0 + b) * dz + c) : 0.f; l = b < nb ? mg_ld(lv_s + (size_t)(b0 + b) * dz + c) : 0.f; }
-                    else { m = S[P.off[VJF_SLOT_PRIOR_MEAN] + c]; l = S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c]; }
-                    if (b < nb) ep = eps_s[(size_t)(b0 + b) * dz + c];
-                    v = fmaf(ep, expf(0.5f * l), m);
-                } else if (b < nb) v = u_t[(size_t)(b0 + b) * du + c - dz];
-                s_xu[c * LD + b] = v;
-            }
-            __syncthreads(); MG_PHASE();
-            for (int e = tid; e < TR * n; e += NT) {                           // RBF features (functional.py:11-22)
-                const int k = e >> 5, b = e & 31;
-                float d2 = 0.f;
-                for (int c = 0; c < dxu; ++c) { const float d = s_xu[c * LD + b] - s_cen[c * npad + k]; d2 = fmaf(d, d, d2); }
-                s_phi[k * LD + b] = expf(d2 * s_iw[k]);
-            }
-            __syncthreads(); MG_PHASE();
-            int mean_nsl = 1;
-            {   // predictive variance and mean: vjf_mega_trial's stage 2, wavefront for wavefront
-                const __amdgpu_buffer_rsrc_t r_xt = mg_rsrc(A.xt);
-                const float* Wm = S + P.off[VJF_SLOT_W_MEAN];
-                const int ntile = (n + 15) >> 4;
-                float v2a = 0.f, v2b = 0.f;
-                const int nsl = min(NW, part_rows / 16);
-                const int msl = nsl - 1 - wave;
-                const int mper = (((n + 3) >> 2) + nsl - 1) / nsl * 4;
-                const int mkb = msl * mper, mke = min(n, (msl + 1) * mper);
-                const bool mpre = wave < nsl && ((mke - mkb + 3) >> 2) <= 16;
-                float am[16];
-                if (mpre && mke > mkb) mg_mma2_ld16(am, Wm, dz, dz, 0, mkb, mke, 0, lane);
-                for (int r = 0; r * NW < ntile; r += 2) {
-                    int j0p[2], Kp[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int rr = r + h, idx = (rr & 1) ? rr * NW + NW - 1 - wave : rr * NW + wave;
-                        const int tt = ntile - 1 - idx;
-                        j0p[h] = (idx < ntile) ? tt * 16 : -1;
-                        Kp[h] = tri ? min(n, tt * 16 + 16) : n;
-                    }
-                    if (j0p[0] < 0) { j0p[0] = j0p[1]; Kp[0] = Kp[1]; j0p[1] = -1; }
-                    mg_var2(v2a, v2b, r_xt, n, j0p[0], Kp[0], j0p[1], Kp[1], s_phi, lane);
-                }
-                v2a += __shfl_xor(v2a, 16, 64); v2a += __shfl_xor(v2a, 32, 64);
-                v2b += __shfl_xor(v2b, 16, 64); v2b += __shfl_xor(v2b, 32, 64);
-                if (lane < 16) { s_red[wave * TR + lane] = v2a; s_red[wave * TR + 16 + lane] = v2b; }
-                if (wave < nsl) {
-                    vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    if (mpre) { if (mke > mkb) mg_mma2_mm16(acc0, acc1, am, s_phi, dz, 0, mkb, mke, 0, lane); }
-                    else mg_mma2(acc0, acc1, Wm, dz, dz, 0, s_phi, mkb, mke, lane);
-                    float* pr = s_part + (size_t)(msl * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
-                }
-                mean_nsl = nsl;
-            }
-            __syncthreads(); MG_PHASE();
-            // out: [pt.mean (dz x 32) | Phi W (dz x 32) | pt.logvar (32)], write-through; then the tag
-            float* mb = A.mom + ((size_t)tile * 2 + (size_t)(t & 1)) * (size_t)mlen;
-            for (int e = tid; e < TR * dz; e += NT) {
-                const int j = e >> 5, b = e & 31;
-                float v = 0.f;
-                for (int sl = 0; sl < mean_nsl; ++sl) v += s_part[(size_t)(sl * 16 + j) * LD + b];
-                mg_st(mb + e, s_xu[j * LD + b] + v);
-                mg_st(mb + TR * dz + e, v);
-            }
-            if (tid < TR) {
-                float v = 0.f;
-                for (int w = 0; w < NW; ++w) v += s_red[w * TR + tid];
-                mg_st(mb + 2 * TR * dz + tid, logf(v));
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(cnt + MG_C_TAG_MOM + tile, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // this workgroup's tiles mw, mw + n_mom, ..: two at a time side by side (every operand load of L^-1 serves both), a last one alone
+        // (ONE instantiation of the pass, four column groups, for both cases -- tile1 < 0: the second half idles.  With a two-group
+        //  instantiation beside it hipcc (ROCm 7.2.0) fails in its backend: "Illegal instruction detected ... $src_shared_base",
+        //  DESIGN.md section 3 "Toolchain note"; either instantiation alone compiles)
+        int tile = mw;
+        for (; tile < A.ntiles; tile += 2 * A.n_mom)
+            if (!mg_moments_pass<4>(P, A, smem, t, tile, tile + A.n_mom < A.ntiles ? tile + A.n_mom : -1, tri)) return;
     }
 }
 
