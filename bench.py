@@ -464,7 +464,7 @@ def main():
         try:                                                    # HBM-side bytes per step from the committed PMC passes of this build
             if a.config != "B" or world != 1 or a.no_overlap or a.streams_route or a.force_dist or a.flags != "train":
                 raise LookupError("the committed PMC passes are of the headline configuration on the one-launch route")
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
             traffic, traffic_note = float(tj["bytes_per_step_corrected"]), tj.get("note")
         except Exception:
             pass
@@ -472,18 +472,18 @@ def main():
         try:                                                    # the committed rocprofv3 --kernel-trace --stats summary of this build
             import csv
             if a.config == "E":                                 # (tools/profile_configE.sh: every kernel of the per-step route)
-                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_configE_kernel_stats.csv"))))
+                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_configE_kernel_stats.csv"))))
                 nst = 23
-                kstats = {"file": "profiles/r03_configE_kernel_stats.csv",
+                kstats = {"file": "profiles/r04_configE_kernel_stats.csv",
                           "command": "rocprofv3 --kernel-trace --stats -- python bench.py --config E --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-elbo-check",
                           "steps_in_profile": nst,
                           "kernels": [{"name": r_["Name"].split("(")[0].replace("void ", ""), "calls": int(r_["Calls"]), "avg_us": float(r_["AverageNs"]) / 1e3,
                                        "us_per_step": float(r_["TotalDurationNs"]) / 1e3 / nst} for r_ in rows if "vjf_" in r_["Name"]]}
             elif a.config == "B":
-                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_kernel_stats.csv"))))
-                meta = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_stats_meta.json")))
+                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_kernel_stats.csv"))))
+                meta = json.load(open(os.path.join(ROOT, "profiles", "r04_kernel_stats_meta.json")))
                 nst = meta.get("steps_in_all_launches")
-                kstats = {"file": "profiles/r03_kernel_stats.csv", "command": meta.get("command"), "steps_per_launch": meta.get("steps_per_launch"),
+                kstats = {"file": "profiles/r04_kernel_stats.csv", "command": meta.get("command"), "steps_per_launch": meta.get("steps_per_launch"),
                           "note": meta.get("note"), "mega_launches_us": meta.get("mega_launches_us"),
                           "kernels": [{"name": r_["Name"].split("(")[0].replace("void ", ""), "calls": int(r_["Calls"]), "avg_us": float(r_["AverageNs"]) / 1e3,
                                        "max_us": float(r_["MaxNs"]) / 1e3,

@@ -3,7 +3,7 @@
 #   rocprofv3 --kernel-trace --stats of bench.py --config E  -> gpurun_out/<tag>_configE_kernel_stats.csv
 set -o pipefail
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out
 mkdir -p $O
 rm -rf $O/${TAG}_configE_stats

@@ -7,7 +7,7 @@
 # The program itself follows `--` (no env / bash -c hop under the profiler).
 set -o pipefail
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
 K=${2:-200}
 W=20
 O=gpurun_out
