@@ -36,9 +36,9 @@ ALLOW = {
     ("vjf_mega_kernel.h", "vs[0] = S[P.off[VJF_SLOT_PRIOR_MEAN] + j]; vs[1] = S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j];"): "const: the prior",
     ("vjf_mega_kernel.h", "mg_st(xtw + (size_t)j * n + k, Wc[e]);"): "const: w_chol of a launch without an RLS update",
     ("vjf_mega_kernel.h", "else if (j < dz) s_pm[j * LD + b] = *sv;"): "own: the predictive moments this workgroup saved for a replay of its step",
-    ("vjf_mega_kernel.h", "const float bf = bias[f];"): "acq: LDS when the parameters are staged; else the state, behind the gate's acquire (!tl)",
-    ("vjf_mega_kernel.h", "if (f < dz) s_mu[f * LD + b] = v; else s_lv[(f - dz) * LD + b] = v + bl[f - dz];"): "acq: as the layer biases",
-    ("vjf_mega_kernel.h", "if (f < dy) { const float df = d[f]; s_py[f * LD + (lane & 15)] = acc0[r] + df; s_py[f * LD + 16 + (lane & 15)] = acc1[r] + df; }"): "acq: as the layer biases",
+    ("vjf_mega_kernel.h", "const float bf = tl ? ((mg_lds_cf*)bias_l)[f] : ((mg_glb_cf*)bias_g)[f];"): "acq: LDS when the parameters are staged; else the state, behind the gate's acquire (!tl)",
+    ("vjf_mega_kernel.h", "if (f < dz) s_mu[f * LD + b] = v; else s_lv[(f - dz) * LD + b] = v + (tl ? ((mg_lds_cf*)bl_l)[f - dz] : ((mg_glb_cf*)bl_g)[f - dz]);"): "acq: as the layer biases",
+    ("vjf_mega_kernel.h", "if (f < dy) { const float df = tl ? ((mg_lds_cf*)d_l)[f] : ((mg_glb_cf*)d_g)[f]; s_py[f * LD + (lane & 15)] = acc0[r] + df; s_py[f * LD + 16 + (lane & 15)] = acc1[r] + df; }"): "acq: as the layer biases",
     ("vjf_mega_kernel.h", "const float m = mu_s ? mg_ld(mu_s + (size_t)b * dz + c2) : S[P.off[VJF_SLOT_PRIOR_MEAN] + c2];   // (sc1: no acquire"): "const: the prior (the posterior is an sc1 load)",
     ("vjf_mega_kernel.h", "const float l = mu_s ? mg_ld(lv_s + (size_t)b * dz + c2) : S[P.off[VJF_SLOT_PRIOR_LOGVAR] + c2]; //  behind the waits)"): "const: the prior",
     ("vjf_mega_kernel.h", "v = fmaf(eps_s[(size_t)b * dz + c2], expf(0.5f * l), m);"): "const: the noise input",

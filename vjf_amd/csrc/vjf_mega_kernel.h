@@ -74,14 +74,7 @@ enum {
 // The last act of every workgroup of a one-launch grid: if a wait of the launch has been given up (by this workgroup or another),
 // say so where the host sees it without a synchronisation (vjf_plan.h, VJF_MIRROR_SLOT).
 __device__ __forceinline__ void mg_tell_host(const float* status, unsigned* host_word) {
-#ifdef VJF_CHAOS
-    // (the diagnostic build goes without: with this routine behind the roles hipcc (ROCm 7.2.0) fails in its backend -- "Illegal
-    //  instruction detected: Operand has incorrect register class.  V_CMP_NE_U32_e32 0, $src_shared_base" -- as it did for two other
-    //  harmless edits of this kernel, DESIGN.md section 3 "Toolchain note"; the status word itself still carries the bits)
-    (void)status; (void)host_word;
-#else
     if (threadIdx.x == 0 && host_word && vjf_abort_seen(status)) __hip_atomic_store(host_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
 }
 
 // The first act of every workgroup of a one-launch grid: count itself in and wait until the WHOLE grid has -- every wait of the
@@ -580,6 +573,9 @@ __device__ __forceinline__ void mg_grad_tile(const float* D, int M, int m0, cons
     }
 }
 
+typedef __attribute__((address_space(3))) const float mg_lds_cf;    // an LDS pointer by type / a global-memory pointer by type: a value that
+typedef __attribute__((address_space(1))) const float mg_glb_cf;    // lives in LDS in one plan and in memory in another is read through one of
+                                                                    // these on either side of a select, never through a selected generic pointer
 // loss sums of step t over the trial workgroups' late slabs: fp64, 32 strided partial sums per scalar, then a fixed xor tree -> s_sc[RS_*]
 // (the residual leaves as the mean square).  A workgroup-wide call (one barrier); read with sc1 loads behind the caller's wait.
 __device__ __forceinline__ void mg_sum_losses(const VjfMegaArgs& A, int t, float* s_sc, int tid, float Bf, int dz, bool want_resid) {
@@ -977,7 +973,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     const float* WT = A.aux + P.aux_recT[l];                   // (kin, hl)
                     int th_w = 0, th_ldw = 0, th_b = 0;
                     if (tl) mg_theta_layer(P, Lo.th0, l, th_w, th_ldw, th_b);
-                    const float* bias = tl ? smem + th_b : S + P.off[VJF_SLOT_REC_B0 + 2 * l];
+                    // (bias values through a select of two TYPED loads, never a load through a selected pointer: a pointer that is LDS on
+                    //  one side and memory on the other is a generic one, and the aperture test the backend builds for it is the instruction
+                    //  this compiler rejects -- "V_CMP_NE_U32_e32 0, $src_shared_base", found with -mllvm -verify-machineinstrs)
+                    const float* bias_l = smem + th_b; const float* bias_g = S + P.off[VJF_SLOT_REC_B0 + 2 * l];
                     float* out = s_act + aoff * LD;
                     const int hl = P.h[l], mt = (hl + 15) >> 4;
                     for (int tt = wave; tt < mt; tt += NW) {
@@ -988,7 +987,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                         for (int r = 0; r < 4; ++r) {
                             const int f = tt * 16 + 4 * (lane >> 4) + r;
                             if (f < hl) {
-                                const float bf = bias[f];
+                                const float bf = tl ? ((mg_lds_cf*)bias_l)[f] : ((mg_glb_cf*)bias_g)[f];
                                 out[f * LD + (lane & 15)] = tanhf(acc0[r] + bf);
                                 out[f * LD + 16 + (lane & 15)] = tanhf(acc1[r] + bf);
                             }
@@ -1015,12 +1014,12 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
                 __syncthreads(); MG_PHASE();
                 if (first) VJF_MG_STAMP(24);
-                const float* bl = tl ? smem + Lo.th_bl : S + P.off[VJF_SLOT_LV_B];
+                const float* bl_l = smem + Lo.th_bl; const float* bl_g = S + P.off[VJF_SLOT_LV_B];
                 for (int e = tid; e < TR * 2 * dz; e += NT) {
                     const int f = e >> 5, b = e & 31;
                     float v = 0.f;
                     for (int sl = 0; sl < nsl; ++sl) v += s_part[(size_t)((sl * mt + (f >> 4)) * 16 + (f & 15)) * LD + b];
-                    if (f < dz) s_mu[f * LD + b] = v; else s_lv[(f - dz) * LD + b] = v + bl[f - dz];
+                    if (f < dz) s_mu[f * LD + b] = v; else s_lv[(f - dz) * LD + b] = v + (tl ? ((mg_lds_cf*)bl_l)[f - dz] : ((mg_glb_cf*)bl_g)[f - dz]);
                 }
             }
             __syncthreads(); MG_PHASE();
@@ -1070,7 +1069,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             }
             {
                 const float* CT = A.aux + P.aux_decT;                          // (dz, dy)
-                const float* d = tl ? smem + Lo.th_bd : S + P.off[VJF_SLOT_DEC_B];
+                const float* d_l = smem + Lo.th_bd; const float* d_g = S + P.off[VJF_SLOT_DEC_B];
                 const int mt = (dy + 15) >> 4;
                 for (int tt = wave; tt < mt; tt += NW) {
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -1079,7 +1078,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int f = tt * 16 + 4 * (lane >> 4) + r;
-                        if (f < dy) { const float df = d[f]; s_py[f * LD + (lane & 15)] = acc0[r] + df; s_py[f * LD + 16 + (lane & 15)] = acc1[r] + df; }
+                        if (f < dy) { const float df = tl ? ((mg_lds_cf*)d_l)[f] : ((mg_glb_cf*)d_g)[f]; s_py[f * LD + (lane & 15)] = acc0[r] + df; s_py[f * LD + 16 + (lane & 15)] = acc1[r] + df; }
                     }
                 }
             }
@@ -1435,13 +1434,13 @@ static inline size_t vjf_mega_mom_lds_floats(const VjfPlan& P) {
 // instruction; NG = 4: two tiles side by side, LD = 65 -- every operand load of L^-1 and W then feeds twice the multiply-adds).  A
 // trial's sums run over k in the same order whatever NG is: the same bits.
 template <int NG, int LD>
-__device__ __forceinline__ void mg_varN(float (&v2)[NG], __amdgpu_buffer_rsrc_t rx, int n, int j0A, int KA, int j0B, int KB, const float* Xs, int lane,
+__device__ __forceinline__ void mg_varN(float (&v2)[NG], __amdgpu_buffer_rsrc_t rx, int n, int j0A, int KA, int j0B, int KB, mg_lds_cf* Xs, int lane,
                                         const bool upper = true) {        // upper = false (uniform): column groups 2, 3 hold no trials, their multiply-adds are skipped
     if (j0A < 0) return;
     const int i = lane & 15, kk = lane >> 4;
     const bool rvA = (j0A + i) < n, rvB = j0B >= 0 && (j0B + i) < n;
     const int offA = (rvA ? j0A + i : 0) * n + 4 * kk, offB = (rvB ? j0B + i : 0) * n + 4 * kk;
-    const float* xp = Xs + i;
+    mg_lds_cf* xp = Xs + i;
     const int ntA = (KA + 15) >> 4, ntB = j0B >= 0 ? (KB + 15) >> 4 : 0;
     const int SA = (ntA + 3) >> 2, SB = (ntB + 3) >> 2, S = SA + SB;
     vjf_f32x4 acc[NG];
@@ -1471,15 +1470,28 @@ __device__ __forceinline__ void mg_varN(float (&v2)[NG], __amdgpu_buffer_rsrc_t 
             if (t0 + q < nt) {
                 const int k0 = 16 * (t0 + q) + 4 * kk;
                 const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+                // the four k-steps' B operands first, then their multiply-adds: ONE LDS round trip per block of 16 k instead of one per
+                // k-step (the ISA of the trial role's mg_var2 waits on lgkmcnt in front of nearly every pair of MFMAs)
+                float bv[4][NG];
+                float vv[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int k = k0 + c, kc = min(k, ke - 1);
-                    const float v = (rv && k < ke) ? av[c] : 0.f;
+                    vv[c] = (rv && k < ke) ? av[c] : 0.f;
 #pragma unroll
-                    for (int g = 0; g < (NG < 2 ? NG : 2); ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, xp[kc * LD + 16 * g], acc[g], 0, 0, 0);
+                    for (int g = 0; g < (NG < 2 ? NG : 2); ++g) bv[c][g] = xp[kc * LD + 16 * g];
                     if (NG > 2 && upper) {
 #pragma unroll
-                        for (int g = 2; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, xp[kc * LD + 16 * g], acc[g], 0, 0, 0);
+                        for (int g = 2; g < NG; ++g) bv[c][g] = xp[kc * LD + 16 * g];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int g = 0; g < (NG < 2 ? NG : 2); ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[c], bv[c][g], acc[g], 0, 0, 0);
+                    if (NG > 2 && upper) {
+#pragma unroll
+                        for (int g = 2; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[c], bv[c][g], acc[g], 0, 0, 0);
                     }
                 }
             }
@@ -1626,7 +1638,7 @@ __device__ __forceinline__ bool mg_moments_pass(const VjfPlan& P, const VjfMegaA
                 Kp[h] = tri ? min(n, tt * 16 + 16) : n;
             }
             if (j0p[0] < 0) { j0p[0] = j0p[1]; Kp[0] = Kp[1]; j0p[1] = -1; }
-            mg_varN<NG, LD>(v2, r_xt, n, j0p[0], Kp[0], j0p[1], Kp[1], s_phi, lane, two);
+            mg_varN<NG, LD>(v2, r_xt, n, j0p[0], Kp[0], j0p[1], Kp[1], (mg_lds_cf*)s_phi, lane, two);
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
