@@ -41,23 +41,35 @@ def _launch_own_ranks(argv):
             n = int(a.split("=", 1)[1])
     if n <= 1 or "WORLD_SIZE" in os.environ:
         return None
-    with socket.socket() as s:                                   # a free port for the rendezvous
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
-    lines = [l for l in r.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{") and '"metric"' in l]
+    def attempt(extra):
+        with socket.socket() as s:                               # a free port for the rendezvous
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + list(argv) + extra
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=float(os.environ.get("VJF_BENCH_ATTEMPT_TIMEOUT", "900")))
+            rc, out = r.returncode, r.stdout
+        except subprocess.TimeoutExpired as e:
+            rc, out = 124, e.stdout or b""
+        return rc, [l for l in out.decode("utf-8", "replace").splitlines() if l.startswith("{") and '"metric"' in l]
+    rc, lines = attempt([])
+    # The in-library RCCL route has never run with >= 2 ranks on the builder's one-GPU boxes.  The ranks themselves fall back to the
+    # caller-side sums when a wait of its warm-up steps gives up; a run that dies or hangs instead is started over once, on the
+    # caller-side route from the beginning -- the line then says so ("sums_over_ranks": "caller").
+    if (rc != 0 or not lines) and "--dist-route" not in " ".join(argv) and os.environ.get("VJF_BENCH_ROUTE", "native") == "native":
+        print(f"bench.py: the ranks ended with code {rc}{'' if lines else ' and no result line'}; once more with --dist-route caller", file=sys.stderr)
+        rc, lines = attempt(["--dist-route", "caller"])
     if lines:
         sys.stdout.write(lines[-1] + "\n")
         sys.stdout.flush()
-    if r.returncode == 0 and not lines:
+    if rc == 0 and not lines:
         print("bench.py: the ranks exited 0 without a result line", file=sys.stderr)
         return 4
-    return r.returncode
+    return rc
 
 
 if __name__ == "__main__":
@@ -345,6 +357,18 @@ def main():
         torch.cuda.synchronize()
         return q_
     native_error = None
+    watchdog = None
+    if world > 1 and a.dist_route == "native":
+        # (a collective that never completes -- a rank that died, a route that deadlocks -- would hang the run for good: the warm-up
+        #  steps get two minutes, then the rank ends itself and its launcher starts the run over on the caller-side route)
+        import threading
+
+        def _give_up():
+            print(f"bench.py[rank {rank}]: the warm-up steps on the in-library RCCL route did not finish in time", file=sys.stderr, flush=True)
+            os._exit(86)
+        watchdog = threading.Timer(float(os.environ.get("VJF_BENCH_WARMUP_TIMEOUT", "120")), _give_up)
+        watchdog.daemon = True
+        watchdog.start()
     try:
         q = warm_up_steps(model)
         wst = model.status()
@@ -354,6 +378,13 @@ def main():
         if world == 1:
             raise
         native_error = f"{type(e).__name__}: {e}"
+    if watchdog is not None:
+        watchdog.cancel()
+    if os.environ.get("VJF_BENCH_FAKE_NATIVE_FAILURE") == "1" and world > 1 and not getattr(main, "_faked", False):
+        main._faked = True                                       # (test hook: rank 0 reports a failed warm-up once, as the in-library route would)
+        if rank == 0:
+            native_error = "injected (VJF_BENCH_FAKE_NATIVE_FAILURE)"
+        a.dist_route = "native"
     if world > 1 and agree_max(1 if native_error else 0):
         # The in-library RCCL route failed on some rank (it cannot be rehearsed with >= 2 ranks on the builder's one-GPU boxes): every
         # rank starts over on the caller-side route -- a fresh model from the same seed, the sums over ranks through torch.distributed

@@ -50,3 +50,14 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
     assert j["elbo_check"]["ok"]
+
+
+def test_bench_falls_back_when_the_in_library_route_fails_in_its_warm_up():
+    """The in-library RCCL route has never run with two real ranks on the builder's boxes; if a wait of its warm-up steps gives up
+    (or the library returns an error) on ANY rank, every rank starts over with a fresh model on the caller-side sums and the line
+    says so.  Injected here (rank 0 reports a failed warm-up once): the run still ends with a valid line whose ELBO matches."""
+    j = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline"],
+             {"VJF_BENCH_BACKEND": "gloo", "VJF_BENCH_FAKE_NATIVE_FAILURE": "1"})
+    d = j["dist"]
+    assert d["sums_over_ranks"].startswith("caller (") and "injected" in d["native_route_error"]
+    assert j["n_gpus"] == 2 and j["elbo_check"]["ok"] and j["elbo_check"]["trials"] == 2 * 4096 and j["status_bits"] == 0
