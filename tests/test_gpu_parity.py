@@ -1195,3 +1195,37 @@ def test_flag_sets_at_bench_size(vjf, flags):
         close(mu[t], o.mu_t, rtol=1e-6, atol=1e-6)
         close(loss[t], [o.loss, o.recon, o.dyn, o.entropy], rtol=1e-6, atol=1e-6)
     assert torch.isfinite(loss).all()
+
+
+@pytest.mark.parametrize("shape", ["full", "upper"])
+@pytest.mark.parametrize("flags", ["infer", "sgd-only"])
+def test_launch_without_rls_update_looks_at_w_chol_itself(vjf, flags, shape):
+    """A launch without an RLS update has `w_chol` as a constant and no triangle flag to go by when the state was just loaded (the flag
+    is an RLS update's to set): the trial workgroups look at the matrix while they transpose it.  A FULL `w_chol` (what `kalman`
+    leaves, module.py:140-142) must take the square product, an upper triangular one the triangle -- both against the fp64 oracle,
+    and the one-launch route against the per-step kernels, which go by the flag alone."""
+    kw = FLAG_SETS[flags]
+    z, info, _ = gio.traj_case("g5_medium_gaussian_f32")
+    m1, m3 = (_model_for(vjf, info, lr=1e-3) for _ in range(2))
+    for m in (m1, m3):
+        load_fixture_state(m, z, "s0")
+    st = m1.get_state()
+    n = st["transition.velocity.w_chol"].shape[0]
+    g = np.random.default_rng(3)
+    w = 0.05 * g.standard_normal((n, n)).astype(np.float32) + 0.3 * np.eye(n, dtype=np.float32)
+    st["transition.velocity.w_chol"] = np.triu(w) if shape == "upper" else w
+    for m in (m1, m3):
+        m.set_state(st)
+    m3.set_overlap(False)
+    s = load_oracle_state(m1, np.float64)
+    y, eps = torch.tensor(z["y"]), torch.tensor(z["eps"])
+    mu, lv, loss = m1.filter_sequence(y, None, None, eps=eps, **kw)
+    assert m1.route(**kw) == "one-launch"
+    o3 = m3.filter_sequence(y, None, None, eps=eps, **kw)
+    ro = orc.filter_sequence(s, z["y"].astype(np.float64), None, z["eps"].astype(np.float64), **kw)
+    close(mu, ro[0], **POST)
+    close(lv, ro[1], **POST)
+    close(loss, ro[2], rtol=5e-6, atol=5e-6)
+    for a, b in zip((mu, lv, loss), o3):
+        close(a, b, rtol=2e-6, atol=2e-6)
+    assert m1.status() == 0 and m3.status() == 0

@@ -60,6 +60,7 @@ enum {
     MG_C_IMG = 208 * MG_C_SPREAD,      // SGD workgroups whose share of the parameter image is in memory (start of the launch)  target n_sgd
     MG_C_SIGW = 224 * MG_C_SPREAD,     // 8 bytes: {epoch, sigma} from the y / W loop to the Cholesky loop of the next step
     MG_C_XT = 240 * MG_C_SPREAD,       // inverse workgroups whose share of xt = w_chol^T is in memory (start of the launch)              target 2 nbl
+                                       // [+ 1]: launches without an RLS update: trial workgroups that met a nonzero BELOW the diagonal of w_chol
     MG_C_MASK = 192 * MG_C_SPREAD,     // (step + 1) << 8 | non-finite loss components (1 recon, 2 dynamics, 4 entropy) of the last step that had one
     MG_C_COLFLAGS = 160 * MG_C_SPREAD, // [0 .. VJF_CHOL_MAXBLK]: column flags of the Cholesky loop; [VJF_CHOL_MAXBLK + 2]: its "operands loaded" word
     MG_C_ALIVE = 256 * MG_C_SPREAD,    // workgroups of the grid that have started (all of them: the launch goes on; else it ends untouched)  target gridDim.x
@@ -647,6 +648,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     const size_t sy = (size_t)A.B * dy, su = (size_t)A.B * du, sz = (size_t)A.B * dz;
     int ntl = 0;
     for (int tile = wg; tile < A.ntiles; tile += A.n_trial) ++ntl;
+    bool tri_launch = false;                           // a launch without an RLS update: its constant w_chol was SEEN to be upper triangular (below)
 
     // centroids (transposed: [input dim][centre], 16-byte rows) and -1/(2 w^2): constant for the launch (functional.py:11-22)
     const int npad = (n + 3) & ~3;
@@ -823,22 +825,34 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
                 if (rls_in) {
                     sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
-                    tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;               // w_chol known upper triangular
+                    tri = tri_launch || mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;  // w_chol known upper triangular
                 }
                 if (t == 0) {                                                 // (the row-major copy of L^-1 of this launch: the inverse loops' first act)
                     if (!mode_rls) {
                         // no RLS roles in this launch: w_chol is a constant of it, and the trial workgroups transpose a share each
+                        // (and look at what they move: the state's triangle flag is only set by an RLS update -- a model that has never had
+                        //  one, torch.eye (module.py:52), or a state that was just loaded would pay the full square in every variance
+                        //  product of the launch although its w_chol is triangular.  A nonzero below the diagonal is counted in the word
+                        //  behind the hand-off's own; both travel with the same signal)
                         const float* Wc = S + P.off[VJF_SLOT_W_CHOL];
                         float* xtw = const_cast<float*>(A.xt);
+                        bool below = false;
                         for (int e = wg * NT + tid; e < n * n; e += A.n_trial * NT) {
                             const int k = e / n, j = e - k * n;
-                            mg_st(xtw + (size_t)j * n + k, Wc[e]);
+                            const float v = Wc[e];
+                            below = below || (k > j && v != 0.f);
+                            mg_st(xtw + (size_t)j * n + k, v);
                         }
+                        if (__syncthreads_or(below ? 1 : 0) && tid == 0) __hip_atomic_fetch_add(cnt + MG_C_XT + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         vjf_wg_signal_wt(cnt + MG_C_XT, tid);
                     }
                     if (!vjf_wg_wait_sc1(cnt + MG_C_XT, (unsigned)(mode_rls ? A.n_rls - 2 : A.n_trial), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                         vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
                     if (vjf_abort_wg()) return;
+                    if (!mode_rls) {
+                        tri_launch = __hip_atomic_load(cnt + MG_C_XT + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+                        tri = tri || tri_launch;
+                    }
                 }
             }
             // (the two halves of stage 2 as routines: the training kernel runs them behind the RLS hand-off, where they always were;
@@ -940,7 +954,8 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
                 if (vjf_abort_wg()) return;
             }
-            if (first && tl && !replay) {                                      // (a replayed pass: they are in LDS, untouched since its step)
+            if (first && tl && !replay && (gated || t == 0)) {                 // (a replayed pass: they are in LDS, untouched since its step; a launch
+                                                                               //  that updates nothing: they are the launch's constants, staged once)
                 // the parameters of this step into LDS: the image the SGD role keeps has the layout of the region, so this is a flat
                 // 16-byte copy with all of a thread's loads in flight -- one round trip
                 const __amdgpu_buffer_rsrc_t r_img = mg_rsrc(A.img);
@@ -1712,13 +1727,18 @@ __device__ __forceinline__ void vjf_mega_moments(const VjfPlan& P, const VjfMega
     if (!vjf_wg_wait_sc1(A.cnt + MG_C_XT, (unsigned)A.n_trial, tid0, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
         vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
     if (vjf_abort_wg()) return;
-    const bool tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f;
+    // (w_chol upper triangular: the state's flag, or what the trial workgroups saw while they transposed it)
+    const bool tri = mg_ld(SCW + VJF_SC_TRI_CLEAN) != 0.f || __hip_atomic_load(A.cnt + MG_C_XT + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
     for (int t = 0; t < A.T; ++t) {
         // this workgroup's tiles mw, mw + n_mom, ..: two at a time side by side (every operand load of L^-1 serves both), a last one alone
         // (ONE instantiation of the pass, four column groups, for both cases -- tile1 < 0: the second half idles.  With a two-group
         //  instantiation beside it hipcc (ROCm 7.2.0) fails in its backend: "Illegal instruction detected ... $src_shared_base",
         //  DESIGN.md section 3 "Toolchain note"; either instantiation alone compiles)
         int tile = mw;
+        if (A.n_mom >= A.ntiles) {                       // (uniform) a workgroup per tile: the one-tile layout, the trial role's own
+            if (tile < A.ntiles && !mg_moments_pass<2>(P, A, smem, t, tile, -1, tri)) return;
+            continue;
+        }
         for (; tile < A.ntiles; tile += 2 * A.n_mom)
             if (!mg_moments_pass<4>(P, A, smem, t, tile, tile + A.n_mom < A.ntiles ? tile + A.n_mom : -1, tri)) return;
     }
