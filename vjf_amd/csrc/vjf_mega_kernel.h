@@ -2171,6 +2171,14 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
     }
     if (sw >= n_live) return;                          // (no gradient steps in this launch: one workgroup sums the losses and keeps the scalars)
     unsigned nredo = 0;
+    // The scalars this role's first lane keeps -- the likelihood's log-variance and its sample count; in warm-up the state noise and its
+    // count -- are its own stores of the step before: read ONCE, kept in registers (a load per step was a chain of two to four
+    // memory round trips, 2-4 us, on the path of every gated step: the gate waits for this workgroup too)
+    float k_rho = 0.f, k_nlik = 0.f, k_sig = 0.f, k_ntr = 0.f;
+    if (sw == 0 && tid == 0) {
+        k_rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]); k_nlik = mg_ld(SC + VJF_SC_N_LIK);
+        if (do_upd && warm) { k_sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]); k_ntr = mg_ld(SC + VJF_SC_N_TR); }
+    }
     for (int t = 0; t < A.T; ++t) {
       float l_recon = 0.f, l_dyn = 0.f, ent = 0.f;
       bool ok_r = true, ok_d = true, ok_h = true, grad_ok = true;
@@ -2286,7 +2294,7 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
             if (st) vjf_status_or(SC + VJF_SC_STATUS, st);
             if (P.lik == VJF_LIK_GAUSSIAN) {
                 const float sse_y = s_sc[RS_SSEY];
-                float rho = mg_ld(S + P.off[VJF_SLOT_LIK_LOGVAR]);
+                float rho = k_rho;
                 if (do_sgd && ok_r) {                                          // (its gradient comes from the reconstruction term alone)
                     float g = 0.5f * ((float)P.dy - expf(-rho) * sse_y * invB);
                     g = fminf(fmaxf(g, -1.f), 1.f);
@@ -2294,18 +2302,21 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
                 }
                 if (do_upd) {                                                  // likelihood.py:28-40
                     const float mse = sse_y / (Bf * (float)P.dy);
-                    const float acc = fminf(mg_ld(SC + VJF_SC_N_LIK), 1000.f), tot = acc + Bf;
+                    const float acc = fminf(k_nlik, 1000.f), tot = acc + Bf;
                     rho = logf((acc / tot) * expf(rho) + (Bf / tot) * mse);
+                    k_nlik = tot;
                     mg_st(SC + VJF_SC_N_LIK, tot);
                 }
+                k_rho = rho;
                 if (do_sgd || do_upd) mg_st(S + P.off[VJF_SLOT_LIK_LOGVAR], rho);
             }
             if (do_upd && warm) {
                 // warm-up: no RLS update, the state-noise running variance from the residual with the launch's W (model.py:370-377)
                 const float mse = s_sc[RS_RESID];
-                const float sig = mg_ld(S + P.off[VJF_SLOT_TR_LOGVAR]);
-                const float acc = fminf(mg_ld(SC + VJF_SC_N_TR), 500.f), tot = acc + Bf;          // running_var, size_cap=500 (model.py:375)
-                mg_st(S + P.off[VJF_SLOT_TR_LOGVAR], logf((acc / tot) * expf(sig) + (Bf / tot) * mse));
+                const float acc = fminf(k_ntr, 500.f), tot = acc + Bf;                            // running_var, size_cap=500 (model.py:375)
+                k_sig = logf((acc / tot) * expf(k_sig) + (Bf / tot) * mse);
+                k_ntr = tot;
+                mg_st(S + P.off[VJF_SLOT_TR_LOGVAR], k_sig);
                 mg_st(SC + VJF_SC_N_TR, tot);
             }
         }
