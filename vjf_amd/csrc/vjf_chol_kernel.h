@@ -421,6 +421,126 @@ __device__ __forceinline__ bool potrf_inv_chain2(float* dk, float* inv, int lane
     return (dmin > 0.f) && (slast == slast) && (fabsf(slast) < 3.0e38f);
 }
 
+// (Not on the product path either: `tools/chain_follow_bench.hip` and DESIGN.md section 3 "The streamed column chain" -- round 4 built the
+//  column loop on these two routines and measured it: correct, and no faster, because the first columns are bound by the helpers' bulk.)
+#ifndef VJF_FOLLOW_PHASE
+#define VJF_FOLLOW_PHASE 4                // rounds per phase of the follower wavefront (potrf_follow)
+#endif
+// ---- The streamed column chain: the chain wavefront publishes every round, a FOLLOWER wavefront on another SIMD rides on them.
+// A SIMD of this part runs either MFMA or VALU instructions, never both (tools/mfma_valu_overlap.hip: a wavefront's -- or its SIMD
+// neighbour's -- VALU work waits while a v_mfma_f32_32x32x2_f32 runs its 16 passes), so whatever else the chain wavefront does is added
+// to the dependent chain; what can ride on the chain's rounds belongs on another SIMD.  The follower applies round m of block column k
+//   * to T = tile (k+1,k), TRANSPOSED, in the chain's own register layout: the 2x2 step of the inverse's accumulator (same scalars
+//     s1, e, s2, same A operand -v): a forward substitution L_{k+1,k} = A_{k+1,k} L_kk^-T that ends with the chain, in place of the
+//     16-MFMA product with the finished inverse behind it;
+//   * to N = tile (k+1,k+1): the finished column pair of L_{k+1,k} is BOTH operands of one rank-2 update N -= l l^T -- the trailing
+//     update of the next diagonal block from registers, in place of a second 16-MFMA product through LDS.
+// The chain wavefront is left with its two MFMAs a round and three LDS stores: the pair of scaled columns (64 floats), the three
+// scalars, and -- one round later, when an s_waitcnt on them costs nothing -- the count of published rounds.
+// (the ring and its count are handed over as LDS-typed pointers: through generic ones hipcc's backend fails on this code with
+//  "Illegal instruction detected: Operand has incorrect register class ... $src_shared_base", DESIGN.md section 3 "Toolchain note")
+typedef __attribute__((address_space(3))) float vjf_lds_f;
+typedef __attribute__((address_space(3))) volatile int vjf_lds_vi;
+__device__ __forceinline__ bool potrf_inv_chain2_bcast(float* dk, float* inv, int lane, vjf_lds_f* ring_v, vjf_lds_f* ring_sc, vjf_lds_vi* rnd, const int rnd_base) {
+    const int c = lane & 31, h = lane >> 5;
+    const int lc = 2 * ((c & 3) + 4 * (c >> 3)) + ((c >> 2) & 1);   // logical column held by this lane
+    vjf_f32x16 acc, racc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lr = 2 * r + h;                                   // logical row of (register r, half h)
+        acc[r] = dk[vsw(lr, lc)];
+        racc[r] = (lr == lc) ? 1.f : 0.f;
+    }
+    float vcol[16], xcol[16];
+    float dmin = 3.0e38f, slast = 1.f;
+    const int l3 = lane % 3;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int p1 = (m & 3) + 8 * (m >> 2), p2 = p1 + 4;         // physical columns of logical 2m and 2m + 1
+        const float d1 = vrl(acc[m], p1);                           // T[2m][2m]
+        const float q2 = vrl(acc[m], 32 + p2);                      // T[2m+1][2m+1], before column 2m is eliminated
+        const float s1 = __builtin_amdgcn_rsqf(d1);
+        const float l1 = acc[m] * s1;                               // lanes 0..31: L[.][2m]
+        const float e = vrl(l1, p2);                                // L[2m+1][2m]
+        const float t = fmaf(-e, vlo2both(l1), acc[m]);             // lanes 32..63: row 2m+1 with column 2m eliminated
+        const float d2 = fmaf(-e, e, q2);
+        const float s2 = __builtin_amdgcn_rsqf(d2);
+        const float v = h ? t * s2 : l1;                            // L[.][2m] | L[.][2m+1] by half = the k slot
+        // Publish the round: every lane stores (no exec masks, no branches: lanes that share a word store the same value), and the
+        // count of round m - 1 goes out with round m's data -- the LDS executes a wavefront's instructions in order, and by now
+        // those stores are hundreds of cycles old anyway; nothing here waits.
+        if (m > 0) *rnd = rnd_base + m;
+        ring_v[m * 64 + lane] = v;
+        ring_sc[m * 3 + l3] = l3 == 0 ? s1 : l3 == 1 ? e : s2;
+        const float x1 = racc[m] * s1;                              // lanes 0..31: Linv[2m][.]
+        const float x2 = fmaf(-e, vlo2both(x1), racc[m]) * s2;      // lanes 32..63: Linv[2m+1][.]
+        const float b = h ? x2 : x1;
+        const float nv = -v;
+        dmin = fminf(dmin, fminf(d1, d2));
+        slast = s2;
+        vcol[m] = v;
+        xcol[m] = b;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nv, v, acc, 0, 0, 0);
+        racc = __builtin_amdgcn_mfma_f32_32x32x2f32(nv, b, racc, 0, 0, 0);
+    }
+    *rnd = rnd_base + 16;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int j = 2 * m + h;
+        if (lc >= j) dk[vsw(lc, j)] = vcol[m];
+        inv[vsw(j, lc)] = (lc <= j) ? xcol[m] : 0.f;
+    }
+    return (dmin > 0.f) && (slast == slast) && (fabsf(slast) < 3.0e38f);
+}
+// The follower's side: t1 = tile (k+1,k) (natural order, as panel_tile leaves it; L_{k+1,k} on return), n11 = tile (k+1,k+1) (updated on
+// return, where the next chain loads its block from).  Returns false if a published round did not come (`alive()` false or the bound).
+template <class AliveFn>
+__device__ __forceinline__ bool potrf_follow(float* t1, float* n11, int lane, const vjf_lds_f* ring_v, const vjf_lds_f* ring_sc, vjf_lds_vi* rnd, const int rnd_base, AliveFn alive) {
+    const int c = lane & 31, h = lane >> 5;
+    const int lc = 2 * ((c & 3) + 4 * (c >> 3)) + ((c >> 2) & 1);
+    vjf_f32x16 tacc, nacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        tacc[r] = t1[vsw(lc, 2 * r + h)];                           // T^T: row 2r + h = column 2r + h of the tile
+        nacc[r] = n11[vsw(2 * r + h, lc)];
+    }
+    // The rounds in PHASES of VJF_FOLLOW_PHASE: one poll for the phase's last round, its operands read together (one LDS round trip),
+    // then its rounds as straight-line code -- control flow between single rounds made the compiler park both accumulators in VGPRs at
+    // every join and sink the operand reads behind the poll (tools/chain_follow_bench.hip: 410 cycles a round against 150 here).  A
+    // follower that joins late (the product: its tiles arrive ~2 us into the chain) runs through the published phases without waiting;
+    // when the chain ends, at most one phase is left to do.
+    constexpr int PH = VJF_FOLLOW_PHASE;
+    float tcol[16];
+    bool ok = true;
+    unsigned spins = 0;
+#pragma unroll
+    for (int p0 = 0; p0 < 16; p0 += PH) {
+        while (ok && *rnd - rnd_base < p0 + PH) {                   // (uniform)
+            if ((++spins & 63u) == 0u && (spins > (1u << 22) || !alive())) ok = false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        float vv[PH], s1v[PH], ev[PH], s2v[PH];
+#pragma unroll
+        for (int q = 0; q < PH; ++q) { const int j = p0 + q; vv[q] = ring_v[j * 64 + lane]; s1v[q] = ring_sc[j * 3]; ev[q] = ring_sc[j * 3 + 1]; s2v[q] = ring_sc[j * 3 + 2]; }
+#pragma unroll
+        for (int q = 0; q < PH; ++q) {
+            const int j = p0 + q;
+            const float y1 = tacc[j] * s1v[q];                              // lanes 0..31: L_{k+1,k}[.][2j]
+            const float y2 = fmaf(-ev[q], vlo2both(y1), tacc[j]) * s2v[q];   // lanes 32..63: L_{k+1,k}[.][2j+1]
+            const float y = h ? y2 : y1;
+            tcol[j] = y;
+            tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-vv[q], y, tacc, 0, 0, 0);
+            nacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-y, y, nacc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) t1[vsw(lc, 2 * m + h)] = tcol[m];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) n11[vsw(2 * r + h, lc)] = nacc[r];
+    return ok;
+}
+
 // (Not on the product path: kept for `tools/potrf_chain_bench3.hip`, which times the alternatives the rank-2 chain above was chosen
 //  against -- potrf alone 5088 cycles, inverse 4868, panel solve 4112, rank-2 chain with the inverse 5292.)
 // The same column chain split in three, so that each is a pure one-MFMA-per-step dependent chain (the merged chain
