@@ -61,3 +61,25 @@ def test_bench_falls_back_when_the_in_library_route_fails_in_its_warm_up():
     d = j["dist"]
     assert d["sums_over_ranks"].startswith("caller (") and "injected" in d["native_route_error"]
     assert j["n_gpus"] == 2 and j["elbo_check"]["ok"] and j["elbo_check"]["trials"] == 2 * 4096 and j["status_bits"] == 0
+
+
+def test_bench_measures_the_caller_side_route_first_and_keeps_its_line():
+    """N > 1 under somebody else's launcher: the caller-side route is measured first and its line kept; the in-library RCCL route
+    follows under a watchdog.  Here (two ranks on ONE GPU, where RCCL cannot make its communicators) the in-library attempt fails
+    one way or another -- an error of the communicator's creation, or no answer until the watchdog -- and the run still ends with
+    exit code 0 and a valid line of the caller-side route that says what happened."""
+    j = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline"],
+             {"VJF_BENCH_BACKEND": "gloo", "VJF_BENCH_TEST_SAFE": "1", "VJF_BENCH_WARMUP_TIMEOUT": "40"})
+    d = j["dist"]
+    assert d["native_route_error"], d
+    assert d["sums_over_ranks"].startswith("caller"), d
+    assert j["n_gpus"] == 2 and j["elbo_check"]["ok"] and j["elbo_check"]["trials"] == 2 * 4096 and j["status_bits"] == 0
+    assert abs(j["value"] - 2 * 4096 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]
+
+
+def test_bench_ends_with_the_kept_line_when_the_in_library_route_never_comes_back():
+    j = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline"],
+             {"VJF_BENCH_BACKEND": "gloo", "VJF_BENCH_TEST_SAFE": "1", "VJF_BENCH_FAKE_NATIVE_HANG": "1", "VJF_BENCH_WARMUP_TIMEOUT": "25"})
+    d = j["dist"]
+    assert "did not finish in time" in d["native_route_error"], d
+    assert d["sums_over_ranks"] == "caller" and j["elbo_check"]["ok"] and j["status_bits"] == 0
