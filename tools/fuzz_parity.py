@@ -3,6 +3,7 @@ trial path; Gaussian / Poisson; control input; 1-3 layers; ragged batches) throu
 with the tolerances of tests/test_gpu_parity.py.
 
     python tools/fuzz_parity.py [n_cases] [seed] [only_case]
+    FUZZ_FLAGS=warmup|infer|sgd-only|infer-warm|mix python tools/fuzz_parity.py ...   the other flag sets of VJF.filter (mix: by case index)
 
 `draw_cases` / `run_case` are also what tests/test_gpu_handoffs.py calls: the random sweep with a fixed seed, and the configurations
 that once failed (B << n: ill-conditioned precision matrices), pinned by their full description."""
@@ -31,6 +32,19 @@ def draw_cases(N, seed):
         overlap = fam != 1
         out.append((case, dict(fam=fam, B=B, dz=dz, dy=dy, du=du, n=n, hidden=hidden, lik=lik, seq=seq, overlap=overlap)))
     return out
+
+
+FLAG_KW = {"train": dict(sgd=True, update=True, warm_up=False), "warmup": dict(sgd=True, update=True, warm_up=True),
+           "infer": dict(sgd=False, update=False, warm_up=False), "sgd-only": dict(sgd=True, update=False, warm_up=False),
+           "infer-warm": dict(sgd=False, update=True, warm_up=True)}
+
+
+def flag_kw(case):
+    """the flags of VJF.filter a case runs with (FUZZ_FLAGS; the draw of the configurations does not depend on it)"""
+    f = os.environ.get("FUZZ_FLAGS", "train")
+    if f == "mix":
+        f = ("warmup", "infer", "sgd-only", "infer-warm", "train")[(case // 4) % 5]
+    return FLAG_KW[f]
 
 
 class Judge:
@@ -62,6 +76,7 @@ def run_case(case, desc, verbose=False, T=3):
     from oracle import vjf_oracle as orc
     from tests.helpers import load_oracle_state, state_close
     dz, dy, du, n, hidden, lik, B, seq, overlap = (desc[k] for k in ("dz", "dy", "du", "n", "hidden", "lik", "B", "seq", "overlap"))
+    kw = flag_kw(case)
     judge = Judge(verbose)
     torch.manual_seed(100 + case)
     m = vjf.VJF.make_model(dy, dz, du, n, hidden, likelihood=lik, lr=1e-3)
@@ -74,20 +89,20 @@ def run_case(case, desc, verbose=False, T=3):
     u = torch.randn(T, B, du, generator=g) if du else None
     eps = torch.randn(T, 2, B, dz, generator=g)
     if seq:
-        mus, lvs, losses = m.filter_sequence(y, u, None, eps=eps)
+        mus, lvs, losses = m.filter_sequence(y, u, None, eps=eps, **kw)
     mu = lv = mu32 = lv32 = None; q = None
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for t in range(T):
             ut = None if u is None else u[t]
             un = None if u is None else ut.numpy()
-            o = orc.filter_step(s, y[t].numpy(), un, mu, lv, eps[t, 0].numpy(), eps[t, 1].numpy())
-            o32 = orc.filter_step(s32, y[t].numpy(), un, mu32, lv32, eps[t, 0].numpy(), eps[t, 1].numpy())
+            o = orc.filter_step(s, y[t].numpy(), un, mu, lv, eps[t, 0].numpy(), eps[t, 1].numpy(), **kw)
+            o32 = orc.filter_step(s32, y[t].numpy(), un, mu32, lv32, eps[t, 0].numpy(), eps[t, 1].numpy(), **kw)
             mu, lv, mu32, lv32 = o.mu_t, o.lv_t, o32.mu_t, o32.lv_t
             if seq:
                 gm, gl, gloss = mus[t], lvs[t], losses[t]
             else:
-                q, l1, *comp = m.filter(y[t], ut, q, verbose=True, eps=(eps[t, 0], eps[t, 1]))
+                q, l1, *comp = m.filter(y[t], ut, q, verbose=True, eps=(eps[t, 0], eps[t, 1]), **kw)
                 gm, gl, gloss = q.mean, q.logvar, torch.stack([l1, *comp])
             judge(f"t={t} mean", gm, o.mu_t, o32.mu_t, 5e-5, 5e-5)
             judge(f"t={t} logvar", gl, o.lv_t, o32.lv_t, 5e-5, 5e-5)
@@ -117,7 +132,7 @@ def run_case(case, desc, verbose=False, T=3):
             raise                                          # (state_close failed, yet no tensor is out of its tolerance: not explained)
     st = m.status()
     assert st == 0, hex(st)
-    return m.route(), list(judge.notes)
+    return m.route(**kw), list(judge.notes)
 
 
 # Configurations that failed in round 2's sweeps (seeds 21, 22, 33 and an earlier draw order): B = 1 ... 9 trials against 214 ... 1289
