@@ -6,6 +6,7 @@ An access that is ordered only by the usual timing of the roles -- not by a coun
 configs[1]'s shape with the Cholesky or the operand workgroups held, one fresh process in fifty without any hold).
 
     python -m vjf_amd._build --chaos && VJF_LIB=chaos python tools/chaos_handoffs.py [reps_small] [reps_configB]
+    CHAOS_FLAGS=warmup|infer|sgd-only ...   the same for the launches without an RLS update
 
 Holds: every workgroup; workgroups 0..11 one at a time; eight slices of 32 workgroups.  Exit code 1 if any sequence deviates."""
 import os, sys
@@ -16,12 +17,14 @@ import vjf_amd as vjf
 from vjf_amd import _native
 
 assert _native.LIB_PATH.endswith("libvjf_hip_chaos.so"), "run with VJF_LIB=chaos"
+# CHAOS_FLAGS=warmup|infer|sgd-only: the launches without an RLS update (trial + SGD + moments roles: tags, the ring of loss sums)
+KW = {"train": {}, "warmup": dict(warm_up=True), "infer": dict(sgd=False, update=False), "sgd-only": dict(update=False)}[os.environ.get("CHAOS_FLAGS", "train")]
 
 
 def run(make, y, u, eps, reps, tag, overlap, expect_status=0):
     ref_model = make(); ref_model.set_overlap(False)
     os.environ["VJF_CHAOS_LO"], os.environ["VJF_CHAOS_HI"] = "0", "0"            # (nothing held while the comparison values are formed)
-    ref = ref_model.filter_sequence(y, u, None, eps=eps)
+    ref = ref_model.filter_sequence(y, u, None, eps=eps, **KW)
     holds = [(0, 1 << 30)] + [(i, i + 1) for i in range(12)] + [(32 * i, 32 * i + 32) for i in range(8)]
     bad = 0
     for lo, hi in holds:
@@ -30,7 +33,7 @@ def run(make, y, u, eps, reps, tag, overlap, expect_status=0):
             m = make()
             if overlap != 1:
                 m.set_overlap(overlap)
-            out = m.filter_sequence(y, u, None, eps=eps)
+            out = m.filter_sequence(y, u, None, eps=eps, **KW)
             st = m.status()
             dl = float(((out[2] - ref[2]).abs().amax(1) / ref[2].abs().amax(1)).max())
             dm = float((out[0] - ref[0]).abs().max())
