@@ -24,6 +24,62 @@ __device__ __forceinline__ void v0(f32x4& acc0, f32x4& acc1, const float* Ws, co
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD + 16], acc1, 0, 0, 0);
     }
 }
+// V4: V0 with the shape as RUN-TIME values (what the product kernel has: K, the row stride and M come from the plan)
+__device__ __forceinline__ void v4(f32x4& acc0, f32x4& acc1, const float* Ws, const float* Xs, int m0, int lane, int Kr, int ldw, int Mr) {
+    const int i = lane & 15, kk = lane >> 4;
+    const bool rv = (m0 + i) < Mr;
+    const int mi = rv ? m0 + i : 0;
+    const float* xp = Xs + i;
+    const int klast = Kr - 1;
+#pragma unroll 4
+    for (int ks = 0; ks < Kr; ks += 4) {
+        const int k = ks + kk, kc = min(k, klast);
+        const float w = Ws[mi * ldw + kc];
+        const float av = (rv && k < Kr) ? w : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD + 16], acc1, 0, 0, 0);
+    }
+}
+// V5: run-time shape, chunks of CH k-steps: a chunk's operands are read with immediate offsets from ONE base per chunk (no clamp, no mask:
+// rows beyond M are computed and discarded by the caller; only the last, partial k-step is clamped and masked), the next chunk's reads are
+// issued before this chunk's MFMAs
+template <int CH>
+__device__ __forceinline__ void v5(f32x4& acc0, f32x4& acc1, const float* Ws, const float* Xs, int m0, int lane, int Kr, int ldw, int Mr) {
+    const int i = lane & 15, kk = lane >> 4;
+    const int mi = (m0 + i) < Mr ? m0 + i : 0;
+    const float* wp = Ws + mi * ldw + kk;
+    const float* xp = Xs + i + kk * LD;
+    const int nf = Kr >> 2;                              // full k-steps
+    float a0[CH], p0[CH], q0[CH], a1[CH], p1[CH], q1[CH];
+    auto ld = [&](float (&a)[CH], float (&b0)[CH], float (&b1)[CH], int s0) {
+        const float* w = wp + 4 * s0; const float* x = xp + 4 * s0 * LD;
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { a[q] = w[4 * q]; b0[q] = x[4 * q * LD]; b1[q] = x[4 * q * LD + 16]; }
+    };
+    auto mm = [&](const float (&a)[CH], const float (&b0)[CH], const float (&b1)[CH], int s0) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+            if (s0 + q < nf) {                             // (uniform)
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b0[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b1[q], acc1, 0, 0, 0);
+            }
+    };
+    // (reads of a chunk's steps beyond nf touch rows < 4 nf + 4 CH of the operands: inside the LDS allocation, values unused)
+    if (nf > 0) ld(a0, p0, q0, 0);
+    for (int s0 = 0; s0 < nf; s0 += 2 * CH) {
+        if (s0 + CH < nf) ld(a1, p1, q1, s0 + CH);
+        mm(a0, p0, q0, s0);
+        if (s0 + 2 * CH < nf) ld(a0, p0, q0, s0 + 2 * CH);
+        if (s0 + CH < nf) mm(a1, p1, q1, s0 + CH);
+    }
+    if (Kr & 3) {                                          // the partial step
+        const int k = 4 * nf + kk, kc = min(k, Kr - 1);
+        const float w = Ws[mi * ldw + kc];
+        const float av = k < Kr ? w : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Xs[kc * LD + i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Xs[kc * LD + i + 16], acc1, 0, 0, 0);
+    }
+}
 // V1: every operand of the tile read into registers first (18 k-steps: 54 values), then the 36 MFMAs
 __device__ __forceinline__ void v1(f32x4& acc0, f32x4& acc1, const float* Ws, const float* Xs, int m0, int lane) {
     const int i = lane & 15, kk = lane >> 4;
@@ -86,7 +142,7 @@ __device__ __forceinline__ void v3(f32x16& acc, const float* Ws, const float* Xs
 }
 
 template <int V>
-__global__ __launch_bounds__(NT) void bench(float* out, unsigned long long* tks, int R) {
+__global__ __launch_bounds__(NT) void bench(float* out, unsigned long long* tks, int R, int Kr, int ldw, int Mr) {
     extern __shared__ float lds[];
     float* Ws = lds; float* Xs = lds + M * LDW; float* Os = Xs + K * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,11 +152,14 @@ __global__ __launch_bounds__(NT) void bench(float* out, unsigned long long* tks,
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int it = 0; it < R; ++it) {
-        if (V < 3) {
+        if (V != 3) {
             f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
             if (V == 0) v0(acc0, acc1, Ws, Xs, wave * 16, lane);
             if (V == 1) v1(acc0, acc1, Ws, Xs, wave * 16, lane);
             if (V == 2) v2(acc0, acc1, Ws, Xs, wave * 16, lane);
+            if (V == 4) v4(acc0, acc1, Ws, Xs, wave * 16, lane, Kr, ldw, Mr);
+            if (V == 5) v5<8>(acc0, acc1, Ws, Xs, wave * 16, lane, Kr, ldw, Mr);
+            if (V == 6) v5<4>(acc0, acc1, Ws, Xs, wave * 16, lane, Kr, ldw, Mr);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = wave * 16 + 4 * (lane >> 4) + r;
@@ -131,11 +190,11 @@ int main() {
     const size_t lds = (size_t)(M * LDW + K * LD + M * LD) * 4;
     auto run = [&](auto kern, const char* name) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(G), dim3(NT), lds, 0, out, tk, 10);
+        hipLaunchKernelGGL(kern, dim3(G), dim3(NT), lds, 0, out, tk, 10, K, LDW, M);
         hipDeviceSynchronize();
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(G), dim3(NT), lds, 0, out, tk, R);
+        hipLaunchKernelGGL(kern, dim3(G), dim3(NT), lds, 0, out, tk, R, K, LDW, M);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%-34s %7.3f us per layer product (2 wavefronts per SIMD x 36 v_mfma_f32_16x16x4_f32 x 32 cycles = 2304 cycles = 0.96 us at 2.4 GHz if the matrix pipe never waited)\n", name, ms * 1e3 / R);
@@ -144,5 +203,8 @@ int main() {
     run(bench<1>, "V1 operands first, then MFMAs");
     run(bench<2>, "V2 four chains per wavefront");
     run(bench<3>, "V3 32x32x2, K split over wave pairs");
+    run(bench<4>, "V4 = V0, shape at run time");
+    run(bench<5>, "V5 run-time shape, chunks of 8 steps");
+    run(bench<6>, "V5 run-time shape, chunks of 4 steps");
     return 0;
 }

@@ -255,6 +255,27 @@ __device__ __forceinline__ float4 mg_ld4(__amdgpu_buffer_rsrc_t r, int float_ind
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
 
+// tanh for the recognition layers (recognition.py:31-42), branch-free: the library's tanhf is ~70 VALU instructions with both of its
+// branches taken in every wavefront, eight calls per lane and layer -- 1.2 us of a 32-trial tile's 4.5-us layer on a part whose SIMDs
+// run VALU and MFMA instructions one after the other.  |x| < 0.55: x + x^3 P(x^2), the odd series through
+// x^15; else 1 - 2 / (e^{2|x|} + 1) on the hardware exp2 and reciprocal (within 1 ulp each): <= ~2-3 ulp of the result, <= 1.1e-7
+// absolute (emulated against fp64 over [-12, 12]: 1.8 ulp with exact exp2 / division); saturates to +-1 beyond |x| ~ 9, NaN stays NaN.
+__device__ __forceinline__ float mg_tanh(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);          // e^{2|x|}
+    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+    const float z = x * x;
+    float p = -1.4558343870513183e-3f;                                         // -929569/638512875
+    p = fmaf(p, z, 3.5921280365724810e-3f);                                    // 21844/6081075
+    p = fmaf(p, z, -8.8632355299021966e-3f);                                   // -1382/155925
+    p = fmaf(p, z, 2.1869488536155203e-2f);                                    // 62/2835
+    p = fmaf(p, z, -5.3968253968253971e-2f);                                   // -17/315
+    p = fmaf(p, z, 1.3333333333333333e-1f);                                    // 2/15
+    p = fmaf(p, z, -3.3333333333333331e-1f);                                   // -1/3
+    const float small = fmaf(p * z, x, x);
+    return ax < 0.55f ? small : copysignf(big, x);
+}
+
 // acc_g(row = 4*(lane>>4)+r, col = lane&15) += sum_{kb <= k < ke} Ag[k*lda + m0 + row] * Xs[k*LD + 16 g + col]   (g = 0, 1)
 // Rows m0 + i >= M contribute 0 (their A operand is read from a clamped address and masked at use).  kb is a multiple of 4.  The A operands come straight from L2 (k-major matrices: row k contiguous over the output features), 16 k-steps per batch,
 // two batches in flight: while one batch's 32 MFMAs issue the next one's loads are on their way (and the SIMD's other wavefront
@@ -460,19 +481,47 @@ __device__ __forceinline__ void mg_var2(float& v2a, float& v2b, __amdgpu_buffer_
 template <bool TRN>
 __device__ __forceinline__ void mg_mma2_lds(vjf_f32x4& acc0, vjf_f32x4& acc1, const float* Ws, int ldw, int M, int m0, const float* Xs,
                                             int kb, int ke, int lane) {
-    constexpr int LD = VJF_MG_LD;
+    // The shape is the plan's -- run-time values -- and a plain loop over the k-steps (clamped k, masked A, addresses recomputed per
+    // step, an LDS round trip per unrolled group) took 2.85 us for a (128, 70) layer where the same loop with the shape as compile-time
+    // constants takes 1.6 (tools/lds_mma_bench.hip).  So: chunks of four k-steps whose operands are read with immediate offsets from one
+    // base per chunk -- no clamp, no mask: rows beyond M are computed from row 0 and discarded by every caller, only the last, partial
+    // k-step is clamped and masked -- and the next chunk's reads are issued before this chunk's MFMAs: 1.67 us.  (A chunk's steps
+    // beyond the last full one read LDS behind the operands -- inside the allocation or, past its end, zeros --; their MFMAs are skipped.)
+    constexpr int LD = VJF_MG_LD, CH = 4;
+    if (ke <= kb) return;                              // (uniform: an empty K slice)
     const int i = lane & 15, kk = lane >> 4;
-    const bool rv = (m0 + i) < M;
-    const int mi = rv ? m0 + i : 0;
-    const float* xp = Xs + i;
-    const int klast = ke - 1;
-#pragma unroll 4
-    for (int ks = kb; ks < ke; ks += 4) {
-        const int k = ks + kk, kc = min(k, klast);
-        const float w = TRN ? Ws[kc * ldw + mi] : Ws[mi * ldw + kc];
-        const float av = (rv && k < ke) ? w : 0.f;
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[kc * LD + 16], acc1, 0, 0, 0);
+    const int mi = (m0 + i) < M ? m0 + i : 0;
+    const int nf = (ke - kb) >> 2;                     // full k-steps (kb is a multiple of 4)
+    const int astep = TRN ? 4 * ldw : 4;               // floats between two k-steps of the A operand
+    const float* wp = TRN ? Ws + (size_t)(kb + kk) * ldw + mi : Ws + (size_t)mi * ldw + kb + kk;
+    const float* xp = Xs + i + (kb + kk) * LD;
+    float a0[CH], p0[CH], q0[CH], a1[CH], p1[CH], q1[CH];
+    auto ld = [&](float (&a)[CH], float (&b0)[CH], float (&b1)[CH], int s0) {
+        const float* w = wp + s0 * astep; const float* x = xp + 4 * s0 * LD;
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { a[q] = w[q * astep]; b0[q] = x[4 * q * LD]; b1[q] = x[4 * q * LD + 16]; }
+    };
+    auto mm = [&](const float (&a)[CH], const float (&b0)[CH], const float (&b1)[CH], int s0) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+            if (s0 + q < nf) {                         // (uniform)
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b0[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b1[q], acc1, 0, 0, 0);
+            }
+    };
+    if (nf > 0) ld(a0, p0, q0, 0);
+    for (int s0 = 0; s0 < nf; s0 += 2 * CH) {
+        if (s0 + CH < nf) ld(a1, p1, q1, s0 + CH);
+        mm(a0, p0, q0, s0);
+        if (s0 + 2 * CH < nf) ld(a0, p0, q0, s0 + 2 * CH);
+        if (s0 + CH < nf) mm(a1, p1, q1, s0 + CH);
+    }
+    if ((ke - kb) & 3) {                               // the partial step: clamped row of X, masked A
+        const int k = kb + 4 * nf + kk, kc = min(k, ke - 1);
+        const float w = TRN ? Ws[(size_t)kc * ldw + mi] : Ws[(size_t)mi * ldw + kc];
+        const float av = k < ke ? w : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Xs[kc * LD + i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Xs[kc * LD + i + 16], acc1, 0, 0, 0);
     }
 }
 
@@ -1003,8 +1052,8 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                             const int f = tt * 16 + 4 * (lane >> 4) + r;
                             if (f < hl) {
                                 const float bf = tl ? ((mg_lds_cf*)bias_l)[f] : ((mg_glb_cf*)bias_g)[f];
-                                out[f * LD + (lane & 15)] = tanhf(acc0[r] + bf);
-                                out[f * LD + 16 + (lane & 15)] = tanhf(acc1[r] + bf);
+                                out[f * LD + (lane & 15)] = mg_tanh(acc0[r] + bf);
+                                out[f * LD + 16 + (lane & 15)] = mg_tanh(acc1[r] + bf);
                             }
                         }
                     }
