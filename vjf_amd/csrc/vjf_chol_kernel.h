@@ -767,8 +767,11 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         //      All loads of a thread are issued before its first LDS store.
         auto diag_chain = [&](int k) {                                  // L_kk and L_kk^-1 in one chain (one wavefront)
             float* dk = s_blk + (size_t)vtri(k, k) * 1024;
-            if (!potrf_inv_chain2(dk, s_aux + (size_t)k * 1024, lane, min(32, n - 32 * k)) && lane == 0) s_flag[0] = 0;
+            const bool good = potrf_inv_chain2(dk, s_aux + (size_t)k * 1024, lane, min(32, n - 32 * k));
+            if (!good && lane == 0) s_flag[0] = 0;
+            return good;
         };
+        bool chain_good = true;                                         // wavefront 0: every pivot so far was positive
         auto pad4 = [](int gi, int gj) {                                // identity padding outside the matrix
             return make_float4(gi == gj ? 1.f : 0.f, gi == gj + 1 ? 1.f : 0.f, gi == gj + 2 ? 1.f : 0.f, gi == gj + 3 ? 1.f : 0.f);
         };
@@ -860,7 +863,7 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
                 if (A.post) *reinterpret_cast<float4*>(A.pscr + (size_t)idx * 4) = v[q];
             }
         }
-        if (wave == 0) diag_chain(0);
+        if (wave == 0) chain_good = diag_chain(0);
         else if (!A.post)                                               // (post mode: g goes to vjf_rls_post_kernel, not here)
             for (int e = t2; e < npad * DZP; e += NT) {
                 const int r = e / DZP, j = e - r * DZP;
@@ -962,20 +965,30 @@ __device__ __forceinline__ void vjf_chol_body(const VjfPlan& P, const VjfCholArg
         };
         int kdone = 0;                                                  // wavefront 4: columns written out (their flags stored)
         if (wave == 0) {
-            for (int k = 0; k < nbl; ++k) {                             // (chain(0) ran before the barrier above)
-                if (!v_ok[0]) break;
+            // Nothing but the chain's own work on this wavefront's path: it is the only one that can fail a pivot, so the verdict
+            // stays in a register (v_ok[0] re-read from LDS was a round trip at each of three places per column), and the two words
+            // it waits for per column -- both posted by the helpers ~2 us earlier -- are read together, once.
+            auto wait_ab = [&](int target) {                            // tiles (k+1,k) and (k+1,k+1) carry the updates of columns < k
+                for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                    const int a = s_ctl[C_A], b = s_ctl[C_B];
+                    if (a >= target && b >= target) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
+                    if (!v_ok[0]) return false;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                v_ok[0] = 0;                                            // (cannot happen: ends the step as a failed factorisation)
+                return false;
+            };
+            bool good = chain_good;
+            for (int k = 0; k < nbl && good; ++k) {                     // (chain(0) ran before the barrier above)
                 lds_post(C_CHAIN, k + 1);
                 if (k + 1 < nbl) {
-                    if (k >= 1) lds_wait(C_A, k);                       // tile (k+1,k) carries the updates of columns < k
-                    if (!v_ok[0]) break;
+                    if (k >= 1 && !wait_ab(k)) break;
                     panel_tile(k + 1, k);
                     lds_post(C_P1, k + 1);
                     if (k == 0) VJF_STAMP(8);
-                    if (k >= 1) lds_wait(C_B, k);                       // tile (k+1,k+1) carries the updates of columns < k
-                    if (!v_ok[0]) break;
                     trail_tile(k + 1, k + 1, k);
                     if (k == 0) VJF_STAMP(4);
-                    diag_chain(k + 1);
+                    good = diag_chain(k + 1);
                     if (k == 0) VJF_STAMP(5);
                 }
                 if (k < 7) VJF_STAMP(9 + k);
