@@ -35,6 +35,7 @@ ALLOW = {
         "const / own: y, u, eps are inputs; mu_s, lv_s of step t are rows THIS workgroup stored at step t - 1, at addresses written once per launch",
     ("vjf_mega_kernel.h", "vs[0] = S[P.off[VJF_SLOT_PRIOR_MEAN] + j]; vs[1] = S[P.off[VJF_SLOT_PRIOR_LOGVAR] + j];"): "const: the prior",
     ("vjf_mega_kernel.h", "const float v = Wc[e];"): "const: w_chol of a launch without an RLS update",
+    ("vjf_mega_kernel.h", "if (tp) touch = *tp;"): "const: the observations and the noise of the NEXT step (a cache touch in launches without updates, value unused)",
     ("vjf_mega_kernel.h", "else if (j < dz) s_pm[j * LD + b] = *sv;"): "own: the predictive moments this workgroup saved for a replay of its step",
     ("vjf_mega_kernel.h", "const float bf = tl ? ((mg_lds_cf*)bias_l)[f] : ((mg_glb_cf*)bias_g)[f];"): "acq: LDS when the parameters are staged; else the state, behind the gate's acquire (!tl)",
     ("vjf_mega_kernel.h", "if (f < dz) s_mu[f * LD + b] = v; else s_lv[(f - dz) * LD + b] = v + (tl ? ((mg_lds_cf*)bl_l)[f - dz] : ((mg_glb_cf*)bl_g)[f - dz]);"): "acq: as the layer biases",

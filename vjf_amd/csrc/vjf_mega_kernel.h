@@ -719,6 +719,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
     // Nothing of this costs the usual step anything but one more word read beside rho.  Step index T is the gate alone.
     float sig_prev = 0.f, rho_prev = 0.f;
     unsigned nredo = 0;
+    unsigned ring_seen = 0u;                           // a launch without parameter updates: the count of summed steps as last looked at
     for (int t = 0; t <= A.T; ++t) {
       bool replay = false, replayed = false;
       unsigned rbits = 0;
@@ -857,9 +858,26 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 rls_in = t == 0 || !mode_rls;
                 // (no parameter updates at all: nothing holds this role back between steps but the ring of loss sums -- the role
                 //  that sums them must be through with the slot this step will write)
-                if (!gated && t >= VJF_MG_RING) {
-                    if (!vjf_wg_wait_sc1(cnt + MG_C_SGD, (unsigned)(t - VJF_MG_RING + 1) * (unsigned)A.n_sgd_live, tid, SCW + VJF_SC_STATUS))
-                        vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
+                // (the count only grows: what the last look saw usually covers the next ~30 steps -- a look per step was a memory round
+                //  trip and a barrier, 1.2 us of a 20-us step)
+                if (!gated && t >= VJF_MG_RING && (int)(ring_seen - (unsigned)(t - VJF_MG_RING + 1) * (unsigned)A.n_sgd_live) < 0) {
+                    const unsigned need = (unsigned)(t - VJF_MG_RING + 1) * (unsigned)A.n_sgd_live;
+                    vjf_chaos(tid, cnt + MG_C_SGD, 1);
+                    if (tid == 0) {
+                        bool there = false;
+                        unsigned v = 0u;
+                        for (unsigned spins = 0; spins < (1u << 21); ++spins) {
+                            v = __hip_atomic_load(cnt + MG_C_SGD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((int)(v - need) >= 0) { there = true; break; }
+                            if ((spins & 255u) == 255u && ((unsigned)__hip_atomic_load(SCW + VJF_SC_STATUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & VJF_STATUS_WAIT_MASK)) break;
+                            __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
+                        }
+                        if (!there) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
+                        s_try[1] = v;
+                        vjf_s_abort_word = (!there || vjf_abort_seen(SCW + VJF_SC_STATUS)) ? 1 : 0;
+                    }
+                    __syncthreads();
+                    ring_seen = s_try[1];
                     if (vjf_abort_wg()) return;
                 }
                 if (t > 0 && mode_rls) {
@@ -1118,10 +1136,10 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     mg_st(mrow + e, s_mu[j * LD + b]);
                     mg_st(lrow + e, s_lv[j * LD + b]);
                 }
-                if (use_mom) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the tile's posterior is in memory: its tag follows the barrier)
+                // (the moments role's tag for this posterior goes out behind the decoder, below: its stores are acknowledged by then, and
+                //  a drain here was 1.5 us on the path of every step; the moments role is a step ahead)
             }
             __syncthreads(); MG_PHASE();
-            if (use_mom && !replay && tid == 0) __hip_atomic_store(cnt + MG_C_TAG_POST + tile, (unsigned)(tc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             {
                 // sum |dx|^2 per trial (16 lanes each), then the tile's sum in trial order
                 constexpr int LPT = NT / TR;
@@ -1178,7 +1196,25 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             //  still storing their slab tiles: see fuse_fwd)
             if (tid == 0 && first && last && !replay && !rls_in)
                 s_wg[15] = ((int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0) ? 1.f : 0.f;
+            if (use_mom && !replay) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the tile's posterior is in memory: its tag follows the barrier)
             __syncthreads(); MG_PHASE();
+            if (use_mom && !replay && tid == 0) __hip_atomic_store(cnt + MG_C_TAG_POST + tile, (unsigned)(tc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // A launch without parameter updates has nothing between its steps to hide the next step's inputs behind (2.5 us of a 20-us
+            // step: y, the noise): one load per 128-byte line of them goes out here and is retired behind the moments' own loads --
+            // the staging of the next step then finds them in the caches.
+            float touch = 0.f;
+            if (!gated && !replay && last && tc + 1 < A.T) {
+                const int tn = wg;                                   // (the next step starts with this workgroup's first tile)
+                const int b0n = tn * TR, nbn = min(TR, A.B - b0n);
+                const int ly = (nbn * dy + 31) / 32 + 1, le = (nbn * dz + 31) / 32 + 1;
+                const float* yn = A.y + (size_t)(tc + 1) * sy + (size_t)b0n * dy;
+                const float* en = A.eps + (size_t)(tc + 1) * 2 * sz + (size_t)b0n * dz;
+                const float* tp = nullptr;
+                if (tid < ly) tp = yn + min(tid * 32, nbn * dy - 1);
+                else if (tid < ly + le) tp = en + min((tid - ly) * 32, nbn * dz - 1);
+                else if (tid < ly + 2 * le) tp = en + sz + min((tid - ly - le) * 32, nbn * dz - 1);
+                if (tp) touch = *tp;
+            }
             if (tid == 0 && !replay && mode_rls) {
                 float v = 0.f;
                 for (int bb = 0; bb < TR; ++bb) v += s_sc[bb * RS_N + RS_SDX2];
@@ -1234,6 +1270,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 }
                 __syncthreads(); MG_PHASE();
             }
+            asm volatile("" ::"v"(touch));
             if (RLS) moments_a();
             if (warm_late) mg_warm_retire(wv_late);
             if (last && tid == 0 && !replay && mode_rls) __hip_atomic_fetch_add(cnt + MG_C_K1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // W, w_chol, sigma read
