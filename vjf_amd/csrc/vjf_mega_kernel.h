@@ -762,7 +762,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                     for (unsigned spins = 0; spins < VJF_WAIT_SPINS; ++spins) {
                         if ((int)(__hip_atomic_load(cnt + MG_C_SGD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * (unsigned)(RLS ? A.n_sgd : A.n_sgd_live)) >= 0) { there = true; break; }
                         if ((spins & 255u) == 255u && vjf_abort_seen(SCW + VJF_SC_STATUS)) break;
-                        __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
+                        __builtin_amdgcn_s_sleep(RLS ? VJF_POLL_SLEEP : VJF_POLL_SLEEP_LITE);
                     }
                     const bool rls = !rls_in && (int)(__hip_atomic_load(cnt + MG_C_PDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t * npost) >= 0;
                     const unsigned mw = __hip_atomic_load(cnt + MG_C_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -870,7 +870,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                             v = __hip_atomic_load(cnt + MG_C_SGD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((int)(v - need) >= 0) { there = true; break; }
                             if ((spins & 255u) == 255u && ((unsigned)__hip_atomic_load(SCW + VJF_SC_STATUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & VJF_STATUS_WAIT_MASK)) break;
-                            __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
+                            __builtin_amdgcn_s_sleep(RLS ? VJF_POLL_SLEEP : VJF_POLL_SLEEP_LITE);
                         }
                         if (!there) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
                         s_try[1] = v;
@@ -913,7 +913,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                         if (__syncthreads_or(below ? 1 : 0) && tid == 0) __hip_atomic_fetch_add(cnt + MG_C_XT + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         vjf_wg_signal_wt(cnt + MG_C_XT, tid);
                     }
-                    if (!vjf_wg_wait_sc1(cnt + MG_C_XT, (unsigned)(mode_rls ? A.n_rls - 2 : A.n_trial), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                    if (!vjf_wg_wait_sc1<RLS ? VJF_POLL_SLEEP : VJF_POLL_SLEEP_LITE>(cnt + MG_C_XT, (unsigned)(mode_rls ? A.n_rls - 2 : A.n_trial), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                         vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
                     if (vjf_abort_wg()) return;
                     if (!mode_rls) {
@@ -1017,7 +1017,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
                 rls_in = true;
             }
             if (first && tl && !replay && t == 0) {                            // (the image of this launch: the SGD role's first act)
-                if (!vjf_wg_wait_sc1(cnt + MG_C_IMG, (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                if (!vjf_wg_wait_sc1<RLS ? VJF_POLL_SLEEP : VJF_POLL_SLEEP_LITE>(cnt + MG_C_IMG, (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
                 if (vjf_abort_wg()) return;
             }
@@ -1236,7 +1236,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             float4 wv_late[2];
             bool warm_late = false;
             if (first && !rls_in) {
-                if (!vjf_wg_wait_sc1(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                if (!vjf_wg_wait_sc1<RLS ? VJF_POLL_SLEEP : VJF_POLL_SLEEP_LITE>(cnt + MG_C_PDONE, (unsigned)t * npost, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
                 if (vjf_abort_wg()) return;
                 // (sigma and the triangle flag first, then this workgroup's share of the L2 warm-up with its loads left in flight: the
@@ -1257,7 +1257,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             if (first) { VJF_MG_STAMP(5); if (RLS) VJF_MG_STAMPW(2); }
             if (use_mom && !replay) {
                 // the tile's moments of this step from the moments role: its tag, then pt.mean | Phi W | pt.logvar with sc1 loads
-                if (!vjf_wg_wait_sc1(cnt + MG_C_TAG_MOM + tile, (unsigned)(tc + 1), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+                if (!vjf_wg_wait_sc1<RLS ? VJF_POLL_SLEEP : VJF_POLL_SLEEP_LITE>(cnt + MG_C_TAG_MOM + tile, (unsigned)(tc + 1), tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                     vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
                 if (vjf_abort_wg()) return;
                 const float* mb = A.mom + ((size_t)tile * 2 + (size_t)(tc & 1)) * (size_t)((2 * dz + 1) * TR);
@@ -1506,7 +1506,7 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
         if (replay) {
             // the SGD role's step on the replayed late slabs; then this step starts over (inputs, features, parameters)
             ++nredo;
-            if (!(tl ? vjf_wg_wait_sc1(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u)
+            if (!(tl ? vjf_wg_wait_sc1<RLS ? VJF_POLL_SLEEP : VJF_POLL_SLEEP_LITE>(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u)
                      : vjf_wg_wait(cnt + MG_C_REDO_S, nredo * (unsigned)A.n_sgd, tid, SCW + VJF_SC_STATUS)))
                 vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE);
             if (vjf_abort_wg()) return;
@@ -1658,9 +1658,9 @@ __device__ __forceinline__ bool mg_moments_pass(const VjfPlan& P, const VjfMegaA
     const float* u_t = A.u ? A.u + (size_t)t * su : nullptr;
     // the tiles' posterior of step t - 1 (the trial role's write-through stores, then its tags)
     if (t > 0) {
-        bool ok = vjf_wg_wait_sc1(cnt + MG_C_TAG_POST + tile0, (unsigned)t, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u);
+        bool ok = vjf_wg_wait_sc1<VJF_POLL_SLEEP_LITE>(cnt + MG_C_TAG_POST + tile0, (unsigned)t, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u);
         bool gone = vjf_abort_wg();
-        if (two && !gone) { ok = vjf_wg_wait_sc1(cnt + MG_C_TAG_POST + tile1, (unsigned)t, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) && ok; gone = vjf_abort_wg(); }
+        if (two && !gone) { ok = vjf_wg_wait_sc1<VJF_POLL_SLEEP_LITE>(cnt + MG_C_TAG_POST + tile1, (unsigned)t, tid, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u) && ok; gone = vjf_abort_wg(); }
         if (!ok) vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_GATE2);
         if (gone) return false;
     } else __syncthreads();
@@ -1810,7 +1810,7 @@ __device__ __forceinline__ void vjf_mega_moments(const VjfPlan& P, const VjfMega
         for (int e = tid0; e < npad; e += NT) { float v = 0.f; if (e < n) { const float w = expf(lw[e]); v = -0.5f / (w * w); } s_iw[e] = v; }
     }
     // (the row-major L^-1 of this launch: the trial workgroups' first act)
-    if (!vjf_wg_wait_sc1(A.cnt + MG_C_XT, (unsigned)A.n_trial, tid0, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+    if (!vjf_wg_wait_sc1<VJF_POLL_SLEEP_LITE>(A.cnt + MG_C_XT, (unsigned)A.n_trial, tid0, SCW + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
         vjf_status_or(SCW + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_K1);
     if (vjf_abort_wg()) return;
     // (w_chol upper triangular: the state's flag, or what the trial workgroups saw while they transposed it)
@@ -2272,11 +2272,11 @@ __device__ __forceinline__ void vjf_mega_sgd(const VjfPlan& P, const VjfMegaArgs
       // the parameters alone and publishes which components the trial role is to drop; pass 1 steps on its replayed late slabs
       for (int pass = 0; pass < 2; ++pass) {
         if (pass == 0) {
-            if (!vjf_wg_wait_sc1(A.cnt + MG_C_BWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+            if (!vjf_wg_wait_sc1<RLS ? VJF_POLL_SLEEP : VJF_POLL_SLEEP_LITE>(A.cnt + MG_C_BWD, (unsigned)(t + 1) * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                 vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
         } else {
             ++nredo;
-            if (!vjf_wg_wait_sc1(A.cnt + MG_C_REDO_B, nredo * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
+            if (!vjf_wg_wait_sc1<RLS ? VJF_POLL_SLEEP : VJF_POLL_SLEEP_LITE>(A.cnt + MG_C_REDO_B, nredo * (unsigned)A.n_trial, tid, SC + VJF_SC_STATUS, (A.flags & VJF_FLAG_HANDOFF_ACQUIRE) != 0u))
                 vjf_status_or(SC + VJF_SC_STATUS, VJF_STATUS_RLS_FAILED | VJF_STATUS_WAIT_RESIDENT);
             grad_ok = true;
         }

@@ -179,6 +179,9 @@ struct VjfJob {
 // 40: 52.3-52.8, 64: 53.2 (same box, two runs each; a poll every ~1 us costs less in detection latency than the contention of
 // faster ones; four out-of-phase pollers per workgroup: 60.4).  Spreading the counters over 4-KB pages of their own changed nothing.
 // (Config C, whose trial role takes its operands from L2, would like 64 better: 74.8 against 76.5 us a step; config B 53.2 against 52.5.)
+#ifndef VJF_POLL_SLEEP_LITE
+#define VJF_POLL_SLEEP_LITE 16
+#endif
 #ifndef VJF_POLL_SLEEP
 #define VJF_POLL_SLEEP 40
 #endif
@@ -243,6 +246,9 @@ __device__ __forceinline__ void vjf_wg_signal_wt(unsigned* count, int tid) {
 // lane polls, the workgroup barrier, then the sc1 loads.
 // `fence` = true adds the acquire (VJF_HANDOFF_ACQUIRE=1; the default of the one-launch route is the sc1 loads alone).
 #define VJF_FLAG_HANDOFF_ACQUIRE 0x40000000u      /* internal flag bit of the kernels' `flags` words */
+// (SLEEP: the pause between two polls, in units of 64 cycles -- the training launch has ~250 workgroups polling one 1-KB block and
+//  wants them a microsecond apart, VJF_POLL_SLEEP; the launches without an RLS update have a third of the pollers and take 16)
+template <int SLEEP = VJF_POLL_SLEEP>
 __device__ __forceinline__ bool vjf_wg_wait_sc1(const unsigned* count, unsigned target, int tid, const float* status = nullptr, bool fence = false) {
     bool there = true;
     vjf_chaos(tid, count, 1);
@@ -251,7 +257,7 @@ __device__ __forceinline__ bool vjf_wg_wait_sc1(const unsigned* count, unsigned 
         for (unsigned spins = 0; spins < (1u << 21); ++spins) {
             if ((int)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { there = true; break; }
             if ((spins & 255u) == 255u && status && ((unsigned)__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & VJF_STATUS_WAIT_MASK)) break;
-            __builtin_amdgcn_s_sleep(VJF_POLL_SLEEP);
+            __builtin_amdgcn_s_sleep(SLEEP);
         }
         if (fence) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         vjf_s_abort_word = (!there || vjf_abort_seen(status)) ? 1 : 0;
