@@ -1372,6 +1372,32 @@ __device__ __forceinline__ void vjf_mega_trial(const VjfPlan& P, const VjfMegaAr
             {
                 const float* C = S + P.off[VJF_SLOT_DEC_W];                    // (dy, dz): k-major for this product
                 const int mt = (dz + 15) >> 4;
+                // dz <= 16 rows = ONE tile: the K range (the observations) is split over the wavefronts, as the heads' is -- one wavefront
+                // alone took 3.9 us for it while seven waited.  The partial tiles meet in rows that are dead here: the decoder's
+                // means (consumed by the losses) or the delta buffers (written from the next stage on).
+                float* s_kp = compact ? s_py : s_dd;
+                const int rows_av = compact ? dy : Lo.nd * P.hmax;
+                const int nslb = min(NW / mt, rows_av / (16 * mt));
+                if (nslb >= 2) {
+                    if (wave < mt * nslb) {
+                        const int tt = wave / nslb, sl = wave - tt * nslb;
+                        const int per = (((dy + 3) >> 2) + nslb - 1) / nslb * 4;
+                        vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                        if (tl) mg_mma2_lds<true>(acc0, acc1, smem + Lo.th_dec, Lo.th_ldd, dz, tt * 16, s_dpy, sl * per, min(dy, (sl + 1) * per), lane);
+                        else mg_mma2(acc0, acc1, C, dz, dz, tt * 16, s_dpy, sl * per, min(dy, (sl + 1) * per), lane);
+                        float* pr = s_kp + (size_t)((sl * mt + tt) * 16 + 4 * (lane >> 4)) * LD + (lane & 15);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { pr[r * LD] = acc0[r]; pr[r * LD + 16] = acc1[r]; }
+                    }
+                    __syncthreads(); MG_PHASE();
+                    for (int e = tid; e < TR * dz; e += NT) {
+                        const int j = e >> 5, b = e & 31;
+                        float a = 0.f;
+                        for (int sl = 0; sl < nslb; ++sl) a += s_kp[(size_t)((sl * mt + (j >> 4)) * 16 + (j & 15)) * LD + b];   // (padding trials: dpy = 0, so a = 0)
+                        s_dmu[j * LD + b] += a;
+                        s_dlv[j * LD + b] = fmaf(a * s_e2[j * LD + b], 0.5f * expf(0.5f * s_lv[j * LD + b]), s_dlv[j * LD + b]);
+                    }
+                } else
                 for (int tt = wave; tt < mt; tt += NW) {
                     vjf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                     if (tl) mg_mma2_lds<true>(acc0, acc1, smem + Lo.th_dec, Lo.th_ldd, dz, tt * 16, s_dpy, 0, dy, lane);
